@@ -1,0 +1,201 @@
+/*
+ * scanpaths_amd.h -- C ABI of the MI355X (gfx950) hot path of chenxy99/Scanpaths.
+ *
+ * Drop-in boundary: the reference has no FFI -- its hot path is stock torch.nn
+ * modules called from Python (AiR/models/baseline_attention.py, models/resnet.py, models/loss.py,
+ * AiR/train.py:188-205).  Every entry point below is the device arithmetic of one group of those
+ * calls; the host-side Python mirror (scanpaths_amd/models/) binds them with ctypes and exposes the
+ * reference's nn.Module / loss / optimiser surface.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers borrowed from the caller
+ *     (must outlive the stream op); no allocation, no global state, never synchronises the device;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - activations are NHWC fp32 ("channels_last"), conv weights are [Cout][KH][KW][Cin] fp32
+ *     (== a torch OIHW tensor in channels_last memory format, so reference checkpoints load as-is);
+ *   - return 0 on success, negative SP_E* on a rejected argument, positive hipError_t if a launch
+ *     failed (the Python wrapper raises RuntimeError).
+ */
+#ifndef SCANPATHS_AMD_H
+#define SCANPATHS_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_EINVAL (-1)   /* unsupported shape / alignment */
+#define SP_ENULL (-2)    /* required pointer is NULL */
+
+#define SP_ABI_VERSION 1
+int sp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.
+ * One descriptor serves forward conv, data-gradient, dense/batched GEMM (KH=KW=1, H=W=1).
+ * Replaces: F.conv2d / nn.Conv2d.forward and its autograd dgrad for every conv on the path
+ *   (models/resnet.py:57-152; baseline_attention.py:19-50,204,212-215,270,304-309) and nn.Linear
+ *   (baseline_attention.py:207-208,72-88).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sp_conv_desc {
+    /* A operand source: NHWC tensor [batchN, Hi, Wi, Kc] with pixel stride ldx (>= Kc) */
+    int N_img, Hi, Wi, Kc, ldx;
+    /* output: NHWC [batchN, Ho, Wo, Nout] with pixel stride ldc (>= Nout) */
+    int Ho, Wo, Nout, ldc;
+    int KH, KW, stride, pad, dil;
+    /* mode 0 (forward / NK): out[m][n] = sum_{tap,c} X[pix(m,tap)][c] * W[n][tap][c],  W row stride ldw (>= KH*KW*Kc)
+     * mode 1 (dgrad   / KN): out[m][n] = sum_{tap,c} X[pixT(m,tap)][c] * W[c][tap][n], W "row" (c,tap) stride ldw (>= Nout)
+     *         pixT gathers dY at (y + pad - ky*dil)/stride when divisible (transposed conv) */
+    int mode, ldw;
+    /* epilogue: out = relu?( alpha*acc + bias[n] + beta*out ) ; bias may be NULL, beta in {0,1} */
+    float alpha;
+    int beta, relu;
+    /* batched GEMM: grid.y = nbatch, element strides between batch items (0 = shared) */
+    int nbatch;
+    int64_t strideX, strideW, strideC;
+} sp_conv_desc;
+
+int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float* W, const float* bias, float* out, void* stream);
+
+/* Weight gradient (TN GEMM, reduction over output pixels), deterministic split over pixel ranges.
+ *   dW[co][tap][ci] (+)= sum_m dY[m][co] * X[pix(m,tap)][ci]
+ * Replaces the wgrad half of conv2d/linear backward (autograd of the modules above).
+ * workspace: at least sp_conv_wgrad_workspace(d) bytes (0 allowed when it returns 0). */
+typedef struct sp_wgrad_desc {
+    int N_img, Hi, Wi, Ci, ldx;      /* X: NHWC input of the conv                       */
+    int Ho, Wo, Co, ldy;             /* dY: NHWC output-gradient of the conv            */
+    int KH, KW, stride, pad, dil;
+    int ldo;                         /* row stride of dW rows (>= KH*KW*Ci)             */
+    int beta;                        /* 0: overwrite, 1: accumulate into dW             */
+    float alpha;
+    int nbatch;                      /* batched TN GEMM (KH=KW=1), strides in elements  */
+    int64_t strideX, strideY, strideO;
+} sp_wgrad_desc;
+
+int64_t sp_conv_wgrad_workspace(const sp_wgrad_desc* d);
+int sp_conv_wgrad(const sp_wgrad_desc* d, const float* X, const float* dY, float* dW, void* workspace, void* stream);
+
+/* column sums of a row-major [M][C] matrix (ld = row stride): out[c] = beta*out[c] + sum_m x[m][c]
+ * (bias gradients).  workspace >= sp_colsum_workspace(M, C) bytes. */
+int64_t sp_colsum_workspace(int64_t M, int C);
+int sp_colsum(const float* x, int64_t M, int C, int ld, float* out, int beta, void* workspace, void* stream);
+/* row means: out[m] = scale * sum_c x[m][c]  (mean_c(vf): baseline_attention.py:240-244) and its backward
+ * dx[m][c] += scale * dout[m] */
+int sp_rowsum(const float* x, int64_t M, int C, float scale, float* out, void* stream);
+int sp_rowsum_bwd(const float* dout, int64_t M, int C, float scale, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (+ReLU, + residual add), NHWC, train and eval mode.  models/resnet.py:29-46,63-90.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sp_bn_workspace(int64_t M, int C);
+/* train-mode statistics over M=N*H*W rows: mean[C], invstd[C]; updates running stats in place
+ * (momentum 0.1, unbiased var) when running_mean != NULL. */
+int sp_bn_stats(const float* x, int64_t M, int C, float eps, float momentum, float* mean, float* invstd,
+                float* running_mean, float* running_var, void* workspace, void* stream);
+/* eval mode: mean/invstd from running stats */
+int sp_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                     float* invstd, void* stream);
+/* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) */
+int sp_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                const float* residual, int relu, int64_t M, int C, float* y, void* stream);
+/* backward.  dy_eff = dy * (y>0 if relu).  train: dx = gamma*invstd*(dy_eff - mean(dy_eff) - xhat*mean(dy_eff*xhat));
+ * eval: dx = gamma*invstd*dy_eff.  dgamma/dbeta always.  dres (optional) receives dy_eff. */
+int sp_bn_backward(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                   const float* gamma, int relu, int training, int64_t M, int C, float* dx, float* dres,
+                   float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/* MaxPool2d(3, stride 2, pad 0, ceil_mode=True), NHWC.  models/resnet.py:104. */
+int sp_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int Ho, int Wo, void* stream);
+int sp_maxpool3s2_bwd(const float* dy, const float* x, const float* y, int N, int H, int W, int C, float* dx, int Ho,
+                      int Wo, void* stream);
+/* NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] (Cp >= C, extra channels zero) and generic last-dim pad/crop copy */
+int sp_nchw_to_nhwc_pad(const float* x, int N, int C, int H, int W, int Cp, float* y, void* stream);
+int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, void* stream);
+/* dx = dy * (y > 0)  (ReLU fused into a conv epilogue, e.g. F.relu(sal_conv(x)) baseline_attention.py:270) */
+int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
+/* out = a + b (residual joins in backward), n elements */
+int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attentive ConvLSTM decoder pieces (AiR/models/baseline_attention.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* ConvLSTM cell pointwise (:44-54).  pre = xg (+ hg) with gate-major channels [i|f|o|g] of width C each;
+ * i,f,o = sigmoid, g = tanh, c' = f*c + i*g, h' = o*c' (no tanh on the cell).  c_prev/hg may be NULL (= 0).
+ * gates[rows][4C] keeps the activated gates for backward. */
+int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const float* c_prev, int64_t rows, int C, float* gates,
+                          float* c_out, float* h_out, void* stream);
+/* dpre[rows][4C], dc_prev[rows][C] from dh, dc (either may be NULL = 0) */
+int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                          const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, void* stream);
+
+/* 3x3 zero-padded im2col of single-channel maps [R][H][W] into columns [koff,koff+9) of col[r][p][ldk], and adjoint.
+ * Feeds the rank-1 gate convolutions conv3x3(W, spatial (x) semantic) (baseline_attention.py:40-50) and the
+ * spatial attention score map (:111-124) as small GEMMs. */
+int sp_im2col3x3_1ch(const float* maps, int R, int H, int W, int koff, int ldk, float* col, void* stream);
+int sp_col2im3x3_1ch(const float* dcol, int R, int H, int W, int koff, int ldk, float* dmaps, void* stream);
+
+/* attention over a growing memory list (semantic_att :77-88 / spatial_att :111-124 after removing the terms that are
+ * constant along the softmax axis): score[t][r] = <L[t][r][:], u>; a = softmax_t; mem[r][:] = sum_t a[t][r]*L[t][r][:]
+ * L: [T][R][D]; alpha: [T][R]; du_partial: [R][D] (column-sum it for du). T <= 40. */
+int sp_listatt_fwd(const float* L, const float* u, int T, int R, int D, float* mem, float* alpha, void* stream);
+int sp_listatt_bwd(const float* dmem, const float* L, const float* u, const float* alpha, int T, int R, int D, float* dL,
+                   float* du_partial, void* stream);
+
+/* out[i] = relu(a[i]*b[i % nb]) and backward (get_spatial_semantic after hoisting mean_c(vf), :240-244,277-278);
+ * db_partial has n elements (sum the n/nb periods for db). */
+int sp_mulrelu_fwd(const float* a, const float* b, int64_t n, int64_t nb, float* out, void* stream);
+int sp_mulrelu_bwd(const float* dout, const float* a, const float* b, const float* out, int64_t n, int64_t nb, float* da,
+                   float* db_partial, void* stream);
+
+/* per-sample good/poor selection (:360-374): out[r][:] = sel[r] ? a[r][:] : b[r][:] , and adjoint */
+int sp_select_rows(const float* a, const float* b, const unsigned char* sel, int64_t rows, int64_t len, float* out,
+                   void* stream);
+int sp_select_rows_bwd(const float* dout, const unsigned char* sel, int64_t rows, int64_t len, float* da, float* db,
+                       void* stream);
+
+/* predict_head after head composition (:149-174).  Z[b][p][ldz] holds, per head hd at column base hd*HC (HC >= 52):
+ *   col 0 terminate map (sal_layer_2 o 5x5), col 1 action map (sal_layer_3 o 5x5), cols 2..50 the 49 taps of
+ *   drt_layer_1 o 5x5.  cb: composed biases [nheads][HC] (cb[.][51] = drt_layer_1.bias); w2/b2: drt_layer_2 [2][dh*dw],[2].
+ * Outputs per head: logits [nheads][B][1+P] (col 0 = terminate; probabilities when softmax != 0, i.e. eval mode :161-162),
+ * amap [nheads][B][P] (relu action map, always pre-softmax), mu/sigma2 [nheads][B], drt [nheads][B][dh*dw] (post-relu). */
+int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
+                       const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
+                       float* sigma2, float* drt, void* stream);
+/* dlogits is the gradient w.r.t. the `logits` output (probabilities if softmax).  dZ is fully written for the nheads*HC
+ * columns.  Partials are per sample: dcb [B][nheads][HC], dw2 [B][nheads][2][dh*dw], db2 [B][nheads][2]. */
+int sp_head_finish_bwd(const float* dlogits, const float* damap /* nullable, [nheads][B][P] */, const float* dmu,
+                       const float* dsigma2, const float* logits,
+                       const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
+                       int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
+                       float* dw2_partial, float* db2_partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss (models/loss.py:10-14,27-32; AiR/train.py:192-197) -- value and gradient in one pass.
+ * z [B][T][A] logits, gt soft one-hot, masks [B][T]; mask_sums = {sum(action_mask), sum(duration_mask)} on device
+ * (all-reduced by the caller under data parallelism so the loss is normalised by the GLOBAL mask sums).
+ * out3 = {loss, loss_actions, loss_duration} (local numerators / given sums); dz, dmu, dsigma2 = d loss / d input.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sp_scanpath_loss_workspace(int B, int T);
+int sp_scanpath_loss(const float* z, const float* gt, const float* amask, const float* mu, const float* sigma2,
+                     const float* dur, const float* dmask, int B, int T, int A, float lambda1, const float* mask_sums,
+                     float* out3, float* dz, float* dmu, float* dsigma2, void* workspace, void* stream);
+/* out = x * (*scale) with the scalar on the device (chain-rule factor of the loss, no host sync) */
+int sp_scale_by(const float* x, const float* scale, int64_t n, float* out, void* stream);
+/* deterministic sums (fp64 accumulation); workspace >= sp_sumsq_workspace(n) bytes for both */
+int64_t sp_sumsq_workspace(int64_t n);
+int sp_sum(const float* x, int64_t n, float* out, void* workspace, void* stream);
+int sp_sumsq(const float* g, int64_t n, double* out, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * clip_grad_norm_ + Adam (L2 folded into the gradient) over one flat fp32 buffer.  AiR/train.py:116-117,200-202.
+ * g_eff = g*gscale (gscale = 1/world_size after a sum all-reduce); total_norm = sqrt(*sumsq)*gscale;
+ * coef = min(1, clip/(total_norm+1e-6)) (clip <= 0: no clipping); bc1 = 1-beta1^t, bc2 = 1-beta2^t from the host.
+ * ---------------------------------------------------------------------------------------------- */
+int sp_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float gscale, float clip,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,489 @@
+// HBM-bound NHWC kernels of the encoder: BatchNorm2d (train/eval, +ReLU, +residual), column/row reductions,
+// MaxPool(3,2,ceil), layout packing.  All reductions are two-stage with a fixed order (deterministic) and
+// accumulate in fp64 so E[x^2]-E[x]^2 does not cancel (the reference uses Welford-style stats in torch).
+// Access pattern: channels are the contiguous axis, every thread moves float4 (16 B/lane), a 16-lane group
+// covers 256 contiguous bytes of one pixel row.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ int64_t sp_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int CB = 64;        // channels per block column (16 float4 lanes)
+constexpr int RL = 16;        // row lanes per block (256 threads = 16 x 16)
+constexpr int MAX_G = 256;    // row-slab count upper bound
+
+inline int pick_G(int64_t M, int C) {
+    const int64_t colblocks = sp_cdiv(C, CB);
+    int64_t g = sp_cdiv(2048, colblocks);              // ~8 blocks per CU overall
+    g = std::min<int64_t>(g, sp_cdiv(M, RL * 8));      // at least 8 rows per thread
+    g = std::min<int64_t>(g, MAX_G);
+    return (int)std::max<int64_t>(g, 1);
+}
+
+// Generic column reduction: for every channel c accumulate NV values produced by f(row, c4) over a row slab.
+// partial layout: [G][NV][C] doubles.
+template <int NV, typename F>
+__device__ __forceinline__ void col_reduce(int64_t M, int C, int G, double* partial, F f) {
+    __shared__ double sh[NV][RL][CB + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * CB + tx * 4;
+    const int g = blockIdx.y;
+    const int64_t rows_per = sp_cdiv_dev(M, G);
+    const int64_t r0 = (int64_t)g * rows_per, r1 = min(M, r0 + rows_per);
+    double acc[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[v][k] = 0.0;
+    if (c < C) {
+        for (int64_t r = r0 + ty; r < r1; r += RL) {
+            float4 vals[NV];
+            f(r, c, vals);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                acc[v][0] += (double)vals[v].x;
+                acc[v][1] += (double)vals[v].y;
+                acc[v][2] += (double)vals[v].z;
+                acc[v][3] += (double)vals[v].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[v][ty][tx * 4 + k] = acc[v][k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV * CB; i += 256) {
+        const int v = i / CB, cc = i % CB;
+        double s = 0.0;
+#pragma unroll
+        for (int y = 0; y < RL; ++y) s += sh[v][y][cc];
+        const int cg = blockIdx.x * CB + cc;
+        if (cg < C) partial[((int64_t)g * NV + v) * C + cg] = s;
+    }
+}
+
+// ---------------------------------------------------------------- BN statistics
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* x, int64_t M, int C, int G, double* partial) {
+    col_reduce<2>(M, C, G, partial, [&](int64_t r, int c, float4* v) {
+        const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+        v[0] = a;
+        v[1] = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+    });
+}
+
+__global__ void bn_stats_final(const double* partial, int64_t M, int C, int G, float eps, float momentum, float* mean,
+                               float* invstd, float* rmean, float* rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < G; ++g) {
+        s += partial[((int64_t)g * 2 + 0) * C + c];
+        q += partial[((int64_t)g * 2 + 1) * C + c];
+    }
+    const double mu = s / (double)M;
+    double var = q / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_stats(const float* rmean, const float* rvar, int C, float eps, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+// ---------------------------------------------------------------- BN apply (+res, +relu)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* mean, const float* invstd,
+                                                       const float* gamma, const float* beta, const float* res,
+                                                       int relu, int64_t n4, int C, float* y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = (a.x - mu.x) * is.x * ga.x + be.x;
+        o.y = (a.y - mu.y) * is.y * ga.y + be.y;
+        o.z = (a.z - mu.z) * is.z * ga.z + be.z;
+        o.w = (a.w - mu.w) * is.w * ga.w + be.w;
+        if (res) {
+            const float4 rr = reinterpret_cast<const float4*>(res)[i];
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- BN backward
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* dy, const float* x, const float* y, const float* mean,
+                                                      const float* invstd, int relu, int64_t M, int C, int G,
+                                                      double* partial) {
+    col_reduce<2>(M, C, G, partial, [&](int64_t r, int c, float4* v) {
+        float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
+        const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+        if (relu) {
+            const float4 yy = *reinterpret_cast<const float4*>(y + r * C + c);
+            d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
+            d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+        }
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        v[0] = d;
+        v[1] = make_float4(d.x * (a.x - mu.x) * is.x, d.y * (a.y - mu.y) * is.y, d.z * (a.z - mu.z) * is.z,
+                           d.w * (a.w - mu.w) * is.w);
+    });
+}
+
+// coef[0][c] = sum dy_eff / M ; coef[1][c] = sum dy_eff*xhat / M
+__global__ void bn_bwd_final(const double* partial, int64_t M, int C, int G, float* dgamma, float* dbeta, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = 0; g < G; ++g) {
+        s1 += partial[((int64_t)g * 2 + 0) * C + c];
+        s2 += partial[((int64_t)g * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / (double)M);
+    coef[C + c] = (float)(s2 / (double)M);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean,
+                                                    const float* invstd, const float* gamma, const float* coef,
+                                                    int relu, int training, int64_t n4, int C, float* dx, float* dres) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        float4 d = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            const float4 yy = reinterpret_cast<const float4*>(y)[i];
+            d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f;
+            d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+        }
+        if (dres) reinterpret_cast<float4*>(dres)[i] = d;
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        float4 o;
+        if (training) {
+            const float4 a = reinterpret_cast<const float4*>(x)[i];
+            const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+            const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
+            const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
+            o.x = ga.x * is.x * (d.x - k1.x - (a.x - mu.x) * is.x * k2.x);
+            o.y = ga.y * is.y * (d.y - k1.y - (a.y - mu.y) * is.y * k2.y);
+            o.z = ga.z * is.z * (d.z - k1.z - (a.z - mu.z) * is.z * k2.z);
+            o.w = ga.w * is.w * (d.w - k1.w - (a.w - mu.w) * is.w * k2.w);
+        } else {
+            o.x = ga.x * is.x * d.x; o.y = ga.y * is.y * d.y; o.z = ga.z * is.z * d.z; o.w = ga.w * is.w * d.w;
+        }
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- column sums / row sums
+__global__ __launch_bounds__(256) void colsum_partial(const float* x, int64_t M, int C, int ld, int G, double* partial) {
+    col_reduce<1>(M, C, G, partial, [&](int64_t r, int c, float4* v) {
+        v[0] = *reinterpret_cast<const float4*>(x + r * ld + c);
+    });
+}
+__global__ void colsum_final(const double* partial, int C, int G, float* out, int beta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += partial[(int64_t)g * C + c];
+    out[c] = (beta ? out[c] : 0.f) + (float)s;
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* x, int64_t M, int C, float scale, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave0; r < M; r += nwaves) {
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[r] = s * scale;
+    }
+}
+__global__ __launch_bounds__(256) void rowsum_bwd_kernel(const float* dout, int64_t n4, int C, float scale, float* dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = (i * 4) / C;
+        const float g = dout[r] * scale;
+        float4 a = reinterpret_cast<float4*>(dx)[i];
+        a.x += g; a.y += g; a.z += g; a.w += g;
+        reinterpret_cast<float4*>(dx)[i] = a;
+    }
+}
+
+// ---------------------------------------------------------------- maxpool 3x3 s2 ceil, NHWC
+// argmax rule = first maximum in row-major window order (strict >), as ATen's CPU max_pool2d.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int N, int H, int W, int C, float* y, int Ho,
+                                                          int Wo) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t r = i / C4;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = yo * 2 + ky;
+            if (iy >= H) break;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = xo * 2 + kx;
+                if (ix >= W) break;
+                const float4 a = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + iy) * W + ix) * C + c4 * 4);
+                m.x = a.x > m.x ? a.x : m.x; m.y = a.y > m.y ? a.y : m.y;
+                m.z = a.z > m.z ? a.z : m.z; m.w = a.w > m.w ? a.w : m.w;
+            }
+        }
+        reinterpret_cast<float4*>(y)[i] = m;
+    }
+}
+
+// gather form (no atomics): each input element sums dy of the windows whose FIRST maximum it is.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const float* x, const float* y, int N, int H,
+                                                          int W, int C, float* dx, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int n = (int)(r / H);
+        const float v = x[i];
+        float g = 0.f;
+        const int oy_lo = max(0, (iy - 1) / 2), oy_hi = min(Ho - 1, iy / 2);   // windows with 2*oy <= iy <= 2*oy+2
+        const int ox_lo = max(0, (ix - 1) / 2), ox_hi = min(Wo - 1, ix / 2);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (iy - 2 * oy > 2) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ix - 2 * ox > 2) continue;
+                const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C + c;
+                if (y[o] != v) continue;
+                // am I the first element equal to the max in this window (row-major scan, strict >)?
+                const int mine = (iy - 2 * oy) * 3 + (ix - 2 * ox);
+                bool first = true;
+                for (int q = 0; q < mine; ++q) {
+                    const int yy = oy * 2 + q / 3, xx = ox * 2 + q % 3;
+                    if (yy < H && xx < W && x[(((int64_t)n * H + yy) * W + xx) * C + c] == v) { first = false; break; }
+                }
+                if (first) g += dy[o];
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+// ---------------------------------------------------------------- layout helpers
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* x, int N, int C, int H, int W, int Cp, float* y) {
+    const int64_t total = (int64_t)N * H * W * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        int64_t r = i / Cp;
+        const int w = (int)(r % W); r /= W;
+        const int hh = (int)(r % H);
+        const int n = (int)(r / H);
+        y[i] = c < C ? x[(((int64_t)n * C + c) * H + hh) * W + w] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void pad_lastdim_kernel(const float* x, int64_t rows, int Cin, int Cout, float* y) {
+    const int64_t total = rows * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cout);
+        const int64_t r = i / Cout;
+        y[i] = c < Cin ? x[r * Cin + c] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* o, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(o)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+__global__ __launch_bounds__(256) void add_tail_kernel(const float* a, const float* b, float* o, int64_t start, int64_t n) {
+    const int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dy, const float* y, int64_t n, float* dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n, 256), 2048)); }
+
+}  // namespace
+
+extern "C" int64_t sp_bn_workspace(int64_t M, int C) {
+    return (int64_t)pick_G(M, C) * 2 * C * (int64_t)sizeof(double) + 2 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+extern "C" int sp_bn_stats(const float* x, int64_t M, int C, float eps, float momentum, float* mean, float* invstd,
+                           float* running_mean, float* running_var, void* workspace, void* stream) {
+    if (!x || !mean || !invstd || !workspace) return SP_ENULL;
+    if (C % 4 || M <= 0) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = pick_G(M, C);
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(bn_stats_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, x, M, C, G, partial);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_final, dim3((unsigned)sp_cdiv(C, 128)), dim3(128), 0, s, partial, M, C, G, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                                float* invstd, void* stream) {
+    if (!running_mean || !running_var || !mean || !invstd) return SP_ENULL;
+    hipLaunchKernelGGL(bn_eval_stats, dim3((unsigned)sp_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
+                       running_var, C, eps, mean, invstd);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* residual, int relu, int64_t M, int C, float* y, void* stream) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma,
+                       beta, residual, relu, n4, C, y);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_backward(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                              const float* gamma, int relu, int training, int64_t M, int C, float* dx, float* dres,
+                              float* dgamma, float* dbeta, void* workspace, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return SP_ENULL;
+    if (relu && !y) return SP_ENULL;
+    if (C % 4 || M <= 0) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = pick_G(M, C);
+    double* partial = (double*)workspace;
+    float* coef = (float*)(partial + (int64_t)G * 2 * C);
+    hipLaunchKernelGGL(bn_bwd_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, dy, x, y, mean, invstd, relu, M,
+                       C, G, partial);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final, dim3((unsigned)sp_cdiv(C, 128)), dim3(128), 0, s, partial, M, C, G, dgamma, dbeta,
+                       coef);
+    SP_LAUNCH_CHECK();
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, relu,
+                       training, n4, C, dx, dres);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int64_t sp_colsum_workspace(int64_t M, int C) { return (int64_t)pick_G(M, C) * C * (int64_t)sizeof(double); }
+
+extern "C" int sp_colsum(const float* x, int64_t M, int C, int ld, float* out, int beta, void* workspace, void* stream) {
+    if (!x || !out || !workspace) return SP_ENULL;
+    if (C % 4 || ld % 4 || M <= 0) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = pick_G(M, C);
+    hipLaunchKernelGGL(colsum_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, x, M, C, ld, G, (double*)workspace);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final, dim3((unsigned)sp_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, C, G, out,
+                       beta);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_rowsum(const float* x, int64_t M, int C, float scale, float* out, void* stream) {
+    if (!x || !out) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(M, 4), 4096));
+    hipLaunchKernelGGL(rowsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, M, C, scale, out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_rowsum_bwd(const float* dout, int64_t M, int C, float scale, float* dx, void* stream) {
+    if (!dout || !dx) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(rowsum_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, dout, n4, C, scale, dx);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int Ho, int Wo, void* stream) {
+    if (!x || !y) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, y, Ho, Wo);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_maxpool3s2_bwd(const float* dy, const float* x, const float* y, int N, int H, int W, int C, float* dx,
+                                 int Ho, int Wo, void* stream) {
+    if (!dy || !x || !y || !dx) return SP_ENULL;
+    const int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total) * 4), dim3(256), 0, (hipStream_t)stream, dy, x, y, N, H, W,
+                       C, dx, Ho, Wo);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_nchw_to_nhwc_pad(const float* x, int N, int C, int H, int W, int Cp, float* y, void* stream) {
+    if (!x || !y) return SP_ENULL;
+    if (Cp < C) return SP_EINVAL;
+    const int64_t total = (int64_t)N * H * W * Cp;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, Cp, y);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, void* stream) {
+    if (!x || !y) return SP_ENULL;
+    const int64_t total = rows * Cout;
+    hipLaunchKernelGGL(pad_lastdim_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, rows, Cin, Cout, y);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out) return SP_ENULL;
+    const int64_t n4 = n / 4;
+    if (n4 > 0) {
+        hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4);
+        SP_LAUNCH_CHECK();
+    }
+    if (n4 * 4 < n) {
+        hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, b, out, n4 * 4, n);
+        SP_LAUNCH_CHECK();
+    }
+    return SP_OK;
+}
+
+extern "C" int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream) {
+    if (!dy || !y || !dx) return SP_ENULL;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}

@@ -1,0 +1,507 @@
+// Small HBM-/latency-bound kernels of the attentive ConvLSTM decoder (AiR/models/baseline_attention.py).
+// Big contractions live in conv_igemm.hip / conv_wgrad.hip; this file holds the per-step pointwise cell,
+// the memory-list attention, the composed predict_head epilogue (with the wave-shuffle softmax) and glue.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n, 256), 2048)); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// ConvLSTM cell pointwise (:44-54): gates gate-major [i|f|o|g] x C.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xg, const float* hg, const float* c_prev,
+                                                       int64_t rows, int C, float* gates, float* c_out, float* h_out) {
+    const int C4 = C / 4;
+    const int64_t total = rows * C4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / C4;
+        const int c = (int)(idx - r * C4) * 4;
+        const float* px = xg + r * 4 * C + c;
+        float4 pi = *reinterpret_cast<const float4*>(px);
+        float4 pf = *reinterpret_cast<const float4*>(px + C);
+        float4 po = *reinterpret_cast<const float4*>(px + 2 * C);
+        float4 pg = *reinterpret_cast<const float4*>(px + 3 * C);
+        if (hg) {
+            const float* ph = hg + r * 4 * C + c;
+            const float4 a = *reinterpret_cast<const float4*>(ph), b = *reinterpret_cast<const float4*>(ph + C);
+            const float4 d = *reinterpret_cast<const float4*>(ph + 2 * C), e = *reinterpret_cast<const float4*>(ph + 3 * C);
+            pi.x += a.x; pi.y += a.y; pi.z += a.z; pi.w += a.w;
+            pf.x += b.x; pf.y += b.y; pf.z += b.z; pf.w += b.w;
+            po.x += d.x; po.y += d.y; po.z += d.z; po.w += d.w;
+            pg.x += e.x; pg.y += e.y; pg.z += e.z; pg.w += e.w;
+        }
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + r * C + c);
+        float4 gi, gf, go, gg, cn, hn;
+#define CELL(k)                                   \
+        gi.k = sigmoidf_(pi.k);                   \
+        gf.k = sigmoidf_(pf.k);                   \
+        go.k = sigmoidf_(po.k);                   \
+        gg.k = tanhf(pg.k);                       \
+        cn.k = gf.k * cp.k + gi.k * gg.k;         \
+        hn.k = go.k * cn.k;
+        CELL(x) CELL(y) CELL(z) CELL(w)
+#undef CELL
+        float* pgt = gates + r * 4 * C + c;
+        *reinterpret_cast<float4*>(pgt) = gi;
+        *reinterpret_cast<float4*>(pgt + C) = gf;
+        *reinterpret_cast<float4*>(pgt + 2 * C) = go;
+        *reinterpret_cast<float4*>(pgt + 3 * C) = gg;
+        *reinterpret_cast<float4*>(c_out + r * C + c) = cn;
+        *reinterpret_cast<float4*>(h_out + r * C + c) = hn;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const float* dc, const float* gates,
+                                                       const float* c_prev, const float* c_out, int64_t rows, int C,
+                                                       float* dpre, float* dc_prev) {
+    const int C4 = C / 4;
+    const int64_t total = rows * C4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / C4;
+        const int c = (int)(idx - r * C4) * 4;
+        const float* pgt = gates + r * 4 * C + c;
+        const float4 gi = *reinterpret_cast<const float4*>(pgt), gf = *reinterpret_cast<const float4*>(pgt + C);
+        const float4 go = *reinterpret_cast<const float4*>(pgt + 2 * C), gg = *reinterpret_cast<const float4*>(pgt + 3 * C);
+        const float4 cn = *reinterpret_cast<const float4*>(c_out + r * C + c);
+        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f), vdh = cp, vdc = cp;
+        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + r * C + c);
+        if (dh) vdh = *reinterpret_cast<const float4*>(dh + r * C + c);
+        if (dc) vdc = *reinterpret_cast<const float4*>(dc + r * C + c);
+        float4 di, df, dov, dg, dcp;
+#define CELLB(k)                                              \
+        {                                                     \
+            const float dct = vdc.k + vdh.k * go.k;           \
+            dov.k = vdh.k * cn.k * go.k * (1.f - go.k);       \
+            di.k = dct * gg.k * gi.k * (1.f - gi.k);          \
+            df.k = dct * cp.k * gf.k * (1.f - gf.k);          \
+            dg.k = dct * gi.k * (1.f - gg.k * gg.k);          \
+            dcp.k = dct * gf.k;                               \
+        }
+        CELLB(x) CELLB(y) CELLB(z) CELLB(w)
+#undef CELLB
+        float* pd = dpre + r * 4 * C + c;
+        *reinterpret_cast<float4*>(pd) = di;
+        *reinterpret_cast<float4*>(pd + C) = df;
+        *reinterpret_cast<float4*>(pd + 2 * C) = dov;
+        *reinterpret_cast<float4*>(pd + 3 * C) = dg;
+        *reinterpret_cast<float4*>(dc_prev + r * C + c) = dcp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 zero-padded im2col of 1-channel maps into columns [koff, koff+9) of col[r][p][ldk], and adjoint.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col1_kernel(const float* maps, int R, int H, int W, int koff, int ldk, float* col) {
+    const int64_t total = (int64_t)R * H * W * 9;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 9);
+        int64_t q = i / 9;
+        const int x = (int)(q % W); q /= W;
+        const int y = (int)(q % H);
+        const int r = (int)(q / H);
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        float v = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = maps[((int64_t)r * H + yy) * W + xx];
+        col[(((int64_t)r * H + y) * W + x) * ldk + koff + tap] = v;
+    }
+}
+__global__ __launch_bounds__(256) void col2im1_kernel(const float* dcol, int R, int H, int W, int koff, int ldk, float* dmaps) {
+    const int64_t total = (int64_t)R * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t q = i;
+        const int x = (int)(q % W); q /= W;
+        const int y = (int)(q % H);
+        const int r = (int)(q / H);
+        float s = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // col[(y0,x0)][tap] = map[y0+ky-1][x0+kx-1]  ->  (y0,x0) = (y-ky+1, x-kx+1)
+            const int y0 = y - (tap / 3 - 1), x0 = x - (tap % 3 - 1);
+            if ((unsigned)y0 < (unsigned)H && (unsigned)x0 < (unsigned)W)
+                s += dcol[(((int64_t)r * H + y0) * W + x0) * ldk + koff + tap];
+        }
+        dmaps[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention over a memory list: one block per row r.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXT = 40;
+
+__global__ __launch_bounds__(256) void listatt_fwd_kernel(const float* L, const float* u, int T, int R, int D, float* mem,
+                                                          float* alpha) {
+    __shared__ float sh4[4];
+    __shared__ float sc[MAXT];
+    const int r = blockIdx.x;
+    for (int t = 0; t < T; ++t) {
+        const float* row = L + ((int64_t)t * R + r) * D;
+        float s = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) s += row[d] * u[d];
+        s = block_sum_256(s, sh4);
+        if (threadIdx.x == 0) sc[t] = s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) den += expf(sc[t] - mx);
+    const float inv = 1.f / den;
+    if (threadIdx.x < T) alpha[(int64_t)threadIdx.x * R + r] = expf(sc[threadIdx.x] - mx) * inv;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += expf(sc[t] - mx) * inv * L[((int64_t)t * R + r) * D + d];
+        mem[(int64_t)r * D + d] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void listatt_bwd_kernel(const float* dmem, const float* L, const float* u,
+                                                          const float* alpha, int T, int R, int D, float* dL,
+                                                          float* du_partial) {
+    __shared__ float sh4[4];
+    __shared__ float gs[MAXT];
+    const int r = blockIdx.x;
+    const float* dm = dmem + (int64_t)r * D;
+    for (int t = 0; t < T; ++t) {
+        const float* row = L + ((int64_t)t * R + r) * D;
+        float s = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) s += row[d] * dm[d];
+        s = block_sum_256(s, sh4);
+        if (threadIdx.x == 0) gs[t] = s;
+    }
+    __syncthreads();
+    float mean = 0.f;
+    for (int t = 0; t < T; ++t) mean += alpha[(int64_t)t * R + r] * gs[t];
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float dmd = dm[d], ud = u[d];
+        float du = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float a = alpha[(int64_t)t * R + r];
+            const float ds = a * (gs[t] - mean);
+            const int64_t o = ((int64_t)t * R + r) * D + d;
+            du += ds * L[o];
+            dL[o] = a * dmd + ds * ud;
+        }
+        du_partial[(int64_t)r * D + d] = du;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = relu(a * b[i % nb])  (get_spatial_semantic with mean_c(vf) hoisted)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mulrelu_fwd_kernel(const float* a, const float* b, int64_t n, int64_t nb, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = fmaxf(a[i] * b[i % nb], 0.f);
+}
+__global__ __launch_bounds__(256) void mulrelu_bwd_kernel(const float* dout, const float* a, const float* b, const float* out,
+                                                          int64_t n, int64_t nb, float* da, float* db_partial) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = out[i] > 0.f ? dout[i] : 0.f;
+        da[i] = g * b[i % nb];
+        db_partial[i] = g * a[i];
+    }
+}
+
+// out[r][:] = sel[r] ? a[r][:] : b[r][:]   and its adjoint
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* a, const float* b, const unsigned char* sel, int64_t rows,
+                                                          int64_t len, float* out) {
+    const int64_t n = rows * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = sel[i / len] ? a[i] : b[i];
+}
+__global__ __launch_bounds__(256) void select_rows_bwd_kernel(const float* dout, const unsigned char* sel, int64_t rows,
+                                                              int64_t len, float* da, float* db) {
+    const int64_t n = rows * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool s = sel[i / len] != 0;
+        const float g = dout[i];
+        da[i] = s ? g : 0.f;
+        db[i] = s ? 0.f : g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// composed predict_head epilogue.  One block per (head, sample).
+//   Z row p holds at column base = hd*HC : [0] terminate map, [1] action map, [2+tap] the 49 taps of the
+//   7x7 stride-5 pad-2 duration conv composed with the 5x5 head conv; cb[hd][j] = composed biases,
+//   cb[hd][51] = drt_layer_1.bias.  Padding semantics of the ORIGINAL 7x7 conv are kept: taps that fall
+//   outside the (zero-padded) intermediate map contribute neither value nor composed bias.
+// ------------------------------------------------------------------------------------------------
+constexpr int NTAP = 49;
+constexpr int IDX_BD = 51;
+constexpr int MAXS = 256;   // dh*dw upper bound
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, int Hm, int Wm, int ldz, int HC,
+                                                       const float* cb, const float* w2, const float* b2, int softmax,
+                                                       float* logits, float* amap, float* mu, float* sigma2, float* drt,
+                                                       int dh, int dw) {
+    __shared__ float sh4[4];
+    __shared__ float sdrt[MAXS];
+    const int hd = blockIdx.y, b = blockIdx.x;
+    const int P = Hm * Wm, S = dh * dw;
+    const float* z = Z + (int64_t)b * P * ldz + hd * HC;
+    const float* c = cb + hd * HC;
+    float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
+    float* am = amap + ((int64_t)hd * B + b) * P;
+    // terminate logit + action map
+    float s0 = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        s0 += z[(int64_t)p * ldz];
+        const float v = fmaxf(z[(int64_t)p * ldz + 1] + c[1], 0.f);
+        lg[1 + p] = v;
+        am[p] = v;
+    }
+    s0 = block_sum_256(s0, sh4);
+    const float yterm = s0 / (float)P + c[0];
+    if (threadIdx.x == 0) lg[0] = yterm;
+    // duration branch
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int sy = s / dw, sx = s % dw;
+        float acc = c[IDX_BD];
+        for (int ky = 0; ky < 7; ++ky) {
+            const int py = 5 * sy - 2 + ky;
+            if ((unsigned)py >= (unsigned)Hm) continue;
+            for (int kx = 0; kx < 7; ++kx) {
+                const int px = 5 * sx - 2 + kx;
+                if ((unsigned)px >= (unsigned)Wm) continue;
+                const int tap = ky * 7 + kx;
+                acc += z[(int64_t)(py * Wm + px) * ldz + 2 + tap] + c[2 + tap];
+            }
+        }
+        acc = fmaxf(acc, 0.f);
+        sdrt[s] = acc;
+        drt[((int64_t)hd * B + b) * S + s] = acc;
+    }
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        t0 += w2[s] * sdrt[s];
+        t1 += w2[S + s] * sdrt[s];
+    }
+    t0 = block_sum_256(t0, sh4);
+    t1 = block_sum_256(t1, sh4);
+    if (threadIdx.x == 0) {
+        mu[hd * B + b] = t0 + b2[0];
+        sigma2[hd * B + b] = expf(t1 + b2[1]);
+    }
+    if (softmax) {
+        __syncthreads();   // lg[] written by this block is visible to it after the barrier
+        float mx = -INFINITY;
+        for (int a = threadIdx.x; a <= P; a += 256) mx = fmaxf(mx, lg[a]);
+        mx = block_max_256(mx, sh4);
+        float den = 0.f;
+        for (int a = threadIdx.x; a <= P; a += 256) den += expf(lg[a] - mx);
+        den = block_sum_256(den, sh4);
+        const float inv = 1.f / den;
+        for (int a = threadIdx.x; a <= P; a += 256) lg[a] = expf(lg[a] - mx) * inv;
+    }
+}
+
+// amap (pre-softmax action map) is needed in backward when softmax != 0; pass it as `amap` ([nh][B][P]).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, const float* damap, const float* dmu,
+                                                       const float* dsigma2, const float* logits, const float* amap,
+                                                       const float* sigma2,
+                                                       const float* drt, int B, int Hm, int Wm, int ldz, int HC,
+                                                       const float* w2, int softmax, float* dZ, float* dcb_partial,
+                                                       float* dw2_partial, float* db2_partial, int dh, int dw) {
+    __shared__ float sh4[4];
+    __shared__ float sdd[MAXS];
+    const int hd = blockIdx.y, b = blockIdx.x, nh = gridDim.y;
+    const int P = Hm * Wm, S = dh * dw;
+    const float* dl = dlogits + ((int64_t)hd * B + b) * (P + 1);
+    const float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
+    const float* am = amap + ((int64_t)hd * B + b) * P;
+    float* dz = dZ + (int64_t)b * P * ldz + hd * HC;
+    float* dcb = dcb_partial + ((int64_t)b * nh + hd) * HC;
+    float dot = 0.f;
+    if (softmax) {
+        for (int a = threadIdx.x; a <= P; a += 256) dot += lg[a] * dl[a];
+        dot = block_sum_256(dot, sh4);
+    }
+    const float d0 = softmax ? lg[0] * (dl[0] - dot) : dl[0];
+    // duration branch gradients
+    const float dt0 = dmu[hd * B + b];
+    const float dt1 = dsigma2[hd * B + b] * sigma2[hd * B + b];
+    float sumdd = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const float dv = drt[((int64_t)hd * B + b) * S + s];
+        const float dd = dv > 0.f ? dt0 * w2[s] + dt1 * w2[S + s] : 0.f;
+        sdd[s] = dd;
+        sumdd += dd;
+        float* pw = dw2_partial + (((int64_t)b * nh + hd) * 2) * S;
+        pw[s] = dt0 * dv;
+        pw[S + s] = dt1 * dv;
+    }
+    sumdd = block_sum_256(sumdd, sh4);   // also a barrier: sdd visible
+    if (threadIdx.x == 0) {
+        db2_partial[((int64_t)b * nh + hd) * 2 + 0] = dt0;
+        db2_partial[((int64_t)b * nh + hd) * 2 + 1] = dt1;
+        dcb[0] = d0;
+        dcb[IDX_BD] = sumdd;
+    }
+    // composed-bias gradient of the taps: sum over sites where the tap is in range
+    if (threadIdx.x < NTAP) {
+        const int ky = threadIdx.x / 7, kx = threadIdx.x % 7;
+        float s = 0.f;
+        for (int sy = 0; sy < dh; ++sy) {
+            if ((unsigned)(5 * sy - 2 + ky) >= (unsigned)Hm) continue;
+            for (int sx = 0; sx < dw; ++sx)
+                if ((unsigned)(5 * sx - 2 + kx) < (unsigned)Wm) s += sdd[sy * dw + sx];
+        }
+        dcb[2 + threadIdx.x] = s;
+    } else if (threadIdx.x > IDX_BD && threadIdx.x < HC) {
+        dcb[threadIdx.x] = 0.f;
+    }
+    // dZ, coalesced over the HC columns of this head
+    float s1 = 0.f;
+    const float invP = 1.f / (float)P;
+    for (int64_t i = threadIdx.x; i < (int64_t)P * HC; i += 256) {
+        const int p = (int)(i / HC), j = (int)(i % HC);
+        float v = 0.f;
+        if (j == 0) {
+            v = d0 * invP;
+        } else if (j == 1) {
+            float g = softmax ? lg[1 + p] * (dl[1 + p] - dot) : dl[1 + p];
+            if (damap) g += damap[((int64_t)hd * B + b) * P + p];
+            v = am[p] > 0.f ? g : 0.f;
+            s1 += v;
+        } else if (j < 2 + NTAP) {
+            const int tap = j - 2, ky = tap / 7, kx = tap % 7;
+            const int py = p / Wm, px = p % Wm;
+            const int ty = py + 2 - ky, tx = px + 2 - kx;
+            if (ty >= 0 && tx >= 0 && ty % 5 == 0 && tx % 5 == 0) {
+                const int sy = ty / 5, sx = tx / 5;
+                if (sy < dh && sx < dw) v = sdd[sy * dw + sx];
+            }
+        }
+        dz[(int64_t)p * ldz + j] = v;
+    }
+    s1 = block_sum_256(s1, sh4);
+    if (threadIdx.x == 0) dcb[1] = s1;
+}
+
+}  // namespace
+
+extern "C" int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const float* c_prev, int64_t rows, int C,
+                                     float* gates, float* c_out, float* h_out, void* stream) {
+    if (!xg || !gates || !c_out || !h_out) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, xg, hg, c_prev,
+                       rows, C, gates, c_out, h_out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                                     const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, void* stream) {
+    if (!gates || !c_out || !dpre || !dc_prev) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
+                       c_prev, c_out, rows, C, dpre, dc_prev);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_im2col3x3_1ch(const float* maps, int R, int H, int W, int koff, int ldk, float* col, void* stream) {
+    if (!maps || !col) return SP_ENULL;
+    if (koff + 9 > ldk) return SP_EINVAL;
+    hipLaunchKernelGGL(im2col1_kernel, dim3(ew_blocks((int64_t)R * H * W * 9)), dim3(256), 0, (hipStream_t)stream, maps, R, H,
+                       W, koff, ldk, col);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_col2im3x3_1ch(const float* dcol, int R, int H, int W, int koff, int ldk, float* dmaps, void* stream) {
+    if (!dcol || !dmaps) return SP_ENULL;
+    if (koff + 9 > ldk) return SP_EINVAL;
+    hipLaunchKernelGGL(col2im1_kernel, dim3(ew_blocks((int64_t)R * H * W)), dim3(256), 0, (hipStream_t)stream, dcol, R, H, W,
+                       koff, ldk, dmaps);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_listatt_fwd(const float* L, const float* u, int T, int R, int D, float* mem, float* alpha, void* stream) {
+    if (!L || !u || !mem || !alpha) return SP_ENULL;
+    if (T < 1 || T > MAXT) return SP_EINVAL;
+    hipLaunchKernelGGL(listatt_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, L, u, T, R, D, mem, alpha);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_listatt_bwd(const float* dmem, const float* L, const float* u, const float* alpha, int T, int R, int D,
+                              float* dL, float* du_partial, void* stream) {
+    if (!dmem || !L || !u || !alpha || !dL || !du_partial) return SP_ENULL;
+    if (T < 1 || T > MAXT) return SP_EINVAL;
+    hipLaunchKernelGGL(listatt_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, dmem, L, u, alpha, T, R, D, dL,
+                       du_partial);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_mulrelu_fwd(const float* a, const float* b, int64_t n, int64_t nb, float* out, void* stream) {
+    if (!a || !b || !out) return SP_ENULL;
+    hipLaunchKernelGGL(mulrelu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, nb, out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_mulrelu_bwd(const float* dout, const float* a, const float* b, const float* out, int64_t n, int64_t nb,
+                              float* da, float* db_partial, void* stream) {
+    if (!dout || !a || !b || !out || !da || !db_partial) return SP_ENULL;
+    hipLaunchKernelGGL(mulrelu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dout, a, b, out, n, nb, da,
+                       db_partial);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_select_rows(const float* a, const float* b, const unsigned char* sel, int64_t rows, int64_t len, float* out,
+                              void* stream) {
+    if (!a || !b || !sel || !out) return SP_ENULL;
+    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(rows * len)), dim3(256), 0, (hipStream_t)stream, a, b, sel, rows, len,
+                       out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_select_rows_bwd(const float* dout, const unsigned char* sel, int64_t rows, int64_t len, float* da, float* db,
+                                  void* stream) {
+    if (!dout || !sel || !da || !db) return SP_ENULL;
+    hipLaunchKernelGGL(select_rows_bwd_kernel, dim3(ew_blocks(rows * len)), dim3(256), 0, (hipStream_t)stream, dout, sel, rows,
+                       len, da, db);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
+                                  const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
+                                  float* sigma2, float* drt, void* stream) {
+    if (!Z || !cb || !w2 || !b2 || !logits || !amap || !mu || !sigma2 || !drt) return SP_ENULL;
+    const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
+    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1) return SP_EINVAL;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, Z, B, Hm, Wm, ldz, HC, cb, w2, b2,
+                       softmax, logits, amap, mu, sigma2, drt, dh, dw);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_head_finish_bwd(const float* dlogits, const float* damap, const float* dmu, const float* dsigma2,
+                                  const float* logits,
+                                  const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
+                                  int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
+                                  float* dw2_partial, float* db2_partial, void* stream) {
+    if (!dlogits || !dmu || !dsigma2 || !logits || !amap || !sigma2 || !drt || !w2 || !dZ || !dcb_partial || !dw2_partial ||
+        !db2_partial)
+        return SP_ENULL;
+    const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
+    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1) return SP_EINVAL;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, dlogits, damap, dmu, dsigma2, logits,
+                       amap,
+                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}

@@ -1,0 +1,687 @@
+"""torch.autograd.Function wrappers around the HIP kernels (scanpaths_amd/csrc via hip.py).
+
+Every arithmetic op of the hot path is a kernel launch through the C ABI; torch supplies device memory,
+the stream, and the autograd graph (plus pure data movement: cat / stack / views / copies).
+Activations are contiguous NHWC tensors ``[N, H, W, C]``; conv weights are nn.Parameters of logical shape
+OIHW in ``torch.channels_last`` memory format, i.e. physically ``[Co][KH][KW][Ci]`` -- the layout the
+implicit-GEMM kernels consume and the layout their weight gradients are produced in.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+from .hip import ConvDesc, WgradDesc, check, ptr
+
+
+# ----------------------------------------------------------------------------------------------------
+# raw launches
+# ----------------------------------------------------------------------------------------------------
+def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1,
+           mode=0, alpha=1.0, beta=0, relu=0, nbatch=1, sX=0, sW=0, sC=0):
+    d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
+                 int(relu), nbatch, sX, sW, sC)
+    check(hip.lib().sp_conv_igemm(C.byref(d), ptr(X), ptr(W), ptr(bias), ptr(out), hip.stream()), "sp_conv_igemm")
+
+
+def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0,
+           alpha=1.0, nbatch=1, sX=0, sY=0, sO=0):
+    d = WgradDesc(N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, KH, KW, stride, pad, dil, ldo, int(beta), float(alpha), nbatch,
+                  sX, sY, sO)
+    L = hip.lib()
+    ws = hip.workspace(L.sp_conv_wgrad_workspace(C.byref(d)), X.device, slot=0)
+    check(L.sp_conv_wgrad(C.byref(d), ptr(X), ptr(dY), ptr(dW), ptr(ws), hip.stream()), "sp_conv_wgrad")
+
+
+def colsum(x2d: torch.Tensor, C_: int, ld: int, M: int) -> torch.Tensor:
+    out = torch.empty(C_, dtype=torch.float32, device=x2d.device)
+    L = hip.lib()
+    ws = hip.workspace(L.sp_colsum_workspace(M, C_), x2d.device, slot=1)
+    check(L.sp_colsum(ptr(x2d), M, C_, ld, ptr(out), 0, ptr(ws), hip.stream()), "sp_colsum")
+    return out
+
+
+def _colsum_any(x: torch.Tensor, C_: int) -> torch.Tensor:
+    """sum over all leading dims of a contiguous [..., C_] tensor; pads C_ to a multiple of 4 when needed."""
+    M = x.numel() // C_
+    if C_ % 4 == 0:
+        return colsum(x, C_, C_, M)
+    Cp = (C_ + 3) // 4 * 4
+    xp = torch.empty((M, Cp), dtype=torch.float32, device=x.device)
+    check(hip.lib().sp_pad_lastdim(ptr(x), M, C_, Cp, ptr(xp), hip.stream()), "sp_pad_lastdim")
+    return colsum(xp, Cp, Cp, M)[:C_]
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(a)
+    check(hip.lib().sp_add(ptr(a), ptr(b), ptr(out), a.numel(), hip.stream()), "sp_add")
+    return out
+
+
+def _phys(w: torch.Tensor) -> torch.Tensor:
+    """[Co,KH,KW,Ci] contiguous view (or copy) of a logical OIHW weight."""
+    p = w.permute(0, 2, 3, 1)
+    return p if p.is_contiguous() else p.contiguous()
+
+
+def _out_hw(H, W, KH, KW, stride, pad, dil):
+    return (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+
+
+# ----------------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil, relu):
+        x = x.contiguous()
+        N, H, W_, Ci = x.shape
+        wp = _phys(w.detach())
+        Co, KH, KW, Ciw = wp.shape
+        assert Ciw == Ci, (wp.shape, x.shape)
+        Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
+        y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
+        _igemm(x, wp, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co, ldw=KH * KW * Ci,
+               KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
+        ctx.cfg = (stride, pad, dil, relu, bias is not None)
+        ctx.save_for_backward(x, wp, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, dil, relu, has_bias = ctx.cfg
+        x, wp, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, H, W_, Ci = x.shape
+        Co, KH, KW, _ = wp.shape
+        _, Ho, Wo, _ = dy.shape
+        if relu:
+            dyr = torch.empty_like(dy)
+            check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
+            dy = dyr
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
+                   KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty_like(wp)
+            _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci, KH=KH,
+                   KW=KW, stride=stride, pad=pad, dil=dil)
+            dw = dwp.permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum_any(dy, Co)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False):
+    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu)
+
+
+class _PadLast(Function):
+    """[..., Cin] -> [..., Cout] zero padded (stem weight 3->4 channels, K padding of tiny GEMM operands)."""
+    @staticmethod
+    def forward(ctx, x, cout):
+        x = x.contiguous()
+        cin = x.shape[-1]
+        rows = x.numel() // cin
+        y = torch.empty(x.shape[:-1] + (cout,), dtype=torch.float32, device=x.device)
+        check(hip.lib().sp_pad_lastdim(ptr(x), rows, cin, cout, ptr(y), hip.stream()), "sp_pad_lastdim")
+        ctx.cin = cin
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        cout = dy.shape[-1]
+        rows = dy.numel() // cout
+        dx = torch.empty(dy.shape[:-1] + (ctx.cin,), dtype=torch.float32, device=dy.device)
+        check(hip.lib().sp_pad_lastdim(ptr(dy), rows, cout, ctx.cin, ptr(dx), hip.stream()), "sp_pad_lastdim")
+        return dx, None
+
+
+def pad_last(x, cout):
+    return _PadLast.apply(x, cout)
+
+
+def nchw_to_nhwc(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    """images [N,C,H,W] -> [N,H,W,cpad]; inputs carry no gradient."""
+    x = x.contiguous()
+    N, Cc, H, W_ = x.shape
+    y = torch.empty((N, H, W_, cpad), dtype=torch.float32, device=x.device)
+    check(hip.lib().sp_nchw_to_nhwc_pad(ptr(x), N, Cc, H, W_, cpad, ptr(y), hip.stream()), "sp_nchw_to_nhwc_pad")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# dense / batched GEMM  (nn.Linear, weight composition, rank-1 contraction, pooled features)
+# ----------------------------------------------------------------------------------------------------
+def _rows(t):   # (nbatch, M, K, ld, batch_stride) of a 2-D / 3-D operand whose last dim is contiguous
+    assert t.stride(-1) == 1
+    if t.dim() == 2:
+        return 1, t.shape[0], t.shape[1], t.stride(0), 0
+    assert t.dim() == 3
+    return t.shape[0], t.shape[1], t.shape[2], t.stride(1), t.stride(0)
+
+
+class _Gemm(Function):
+    """C = relu?(alpha * A @ op(B) + bias).  layout 'nk': B is [N,K] (C = A B^T); 'kn': B is [K,N].
+    A: [M,K] or [Bt,M,K]; B 2-D (shared) or 3-D (batched)."""
+    @staticmethod
+    def forward(ctx, a, b, bias, layout, alpha, relu):
+        a = a if a.stride(-1) == 1 else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        nb, M, K, lda, sA = _rows(a)
+        bb = b.dim() == 3
+        if layout == "nk":
+            Nn, Kb = b.shape[-2], b.shape[-1]
+        else:
+            Kb, Nn = b.shape[-2], b.shape[-1]
+        assert Kb == K, (a.shape, b.shape, layout)
+        if bb:
+            assert b.shape[0] == nb
+        out_shape = (M, Nn) if a.dim() == 2 else (nb, M, Nn)
+        c = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+        sW = b.stride(0) if bb else 0
+        _igemm(a, b, bias, c, N_img=M, Hi=1, Wi=1, Kc=K, ldx=lda, Ho=1, Wo=1, Nout=Nn, ldc=Nn,
+               ldw=(K if layout == "nk" else Nn), mode=(0 if layout == "nk" else 1), alpha=alpha, relu=relu, nbatch=nb,
+               sX=sA, sW=sW, sC=M * Nn)
+        ctx.cfg = (layout, alpha, relu, bias is not None)
+        ctx.save_for_backward(a, b, c if relu else None)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        layout, alpha, relu, has_bias = ctx.cfg
+        a, b, c = ctx.saved_tensors
+        dc = dc.contiguous()
+        L = hip.lib()
+        if relu:
+            t = torch.empty_like(dc)
+            check(L.sp_relu_bwd(ptr(dc), ptr(c), dc.numel(), ptr(t), hip.stream()), "sp_relu_bwd")
+            dc = t
+        nb, M, K, lda, sA = _rows(a)
+        Nn = dc.shape[-1]
+        bb = b.dim() == 3
+        sW = b.stride(0) if bb else 0
+        da = db = dbias = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+            # dA[M,K] = alpha * dC[M,N] @ (B as [N,K] rows)   -> 'kn' on an [N][K] matrix, or 'nk' on a [K][N] one
+            if layout == "nk":
+                _igemm(dc, b, None, da, N_img=M, Hi=1, Wi=1, Kc=Nn, ldx=Nn, Ho=1, Wo=1, Nout=K, ldc=K, ldw=K, mode=1,
+                       alpha=alpha, nbatch=nb, sX=M * Nn, sW=sW, sC=M * K)
+            else:
+                _igemm(dc, b, None, da, N_img=M, Hi=1, Wi=1, Kc=Nn, ldx=Nn, Ho=1, Wo=1, Nout=K, ldc=K, ldw=Nn, mode=0,
+                       alpha=alpha, nbatch=nb, sX=M * Nn, sW=sW, sC=M * K)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty(b.shape, dtype=torch.float32, device=b.device)
+            if bb or nb == 1:
+                rows, nbt, sAa, sCc, sO = M, nb, sA, M * Nn, (b.stride(0) if bb else 0)
+            else:   # shared B, batched A: one reduction over all Bt*M rows (A must be densely stacked)
+                assert sA == M * lda, "batched A with shared B must be contiguous over the batch"
+                rows, nbt, sAa, sCc, sO = nb * M, 1, 0, 0, 0
+            if layout == "nk":    # dB[N,K] = alpha * dC^T A
+                _wgrad(a, dc, db, N_img=rows, Hi=1, Wi=1, Ci=K, ldx=lda, Ho=1, Wo=1, Co=Nn, ldy=Nn, ldo=K, alpha=alpha,
+                       nbatch=nbt, sX=sAa, sY=sCc, sO=sO)
+            else:                 # dB[K,N] = alpha * A^T dC
+                _wgrad(dc, a, db, N_img=rows, Hi=1, Wi=1, Ci=Nn, ldx=Nn, Ho=1, Wo=1, Co=K, ldy=lda, ldo=Nn, alpha=alpha,
+                       nbatch=nbt, sX=sCc, sY=sAa, sO=sO)
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = _colsum_any(dc, Nn)
+        return da, db, dbias, None, None, None
+
+
+def gemm(a, b, bias=None, layout="nk", alpha=1.0, relu=False):
+    return _Gemm.apply(a, b, bias, layout, alpha, relu)
+
+
+def linear(x, weight, bias):
+    """nn.Linear on the last dim (weight [out,in])."""
+    shp = x.shape
+    y = gemm(x.reshape(-1, shp[-1]), weight, bias, "nk")
+    return y.view(*shp[:-1], weight.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------------
+# BatchNorm (+residual, +ReLU), maxpool
+# ----------------------------------------------------------------------------------------------------
+class _BnAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, training, momentum, eps, relu):
+        x = x.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        L = hip.lib()
+        dev = x.device
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+        if training:
+            ws = hip.workspace(L.sp_bn_workspace(M, Cc), dev, slot=1)
+            check(L.sp_bn_stats(ptr(x), M, Cc, eps, momentum, ptr(mean), ptr(invstd), ptr(rmean), ptr(rvar), ptr(ws),
+                                hip.stream()), "sp_bn_stats")
+        else:
+            check(L.sp_bn_eval_stats(ptr(rmean), ptr(rvar), Cc, eps, ptr(mean), ptr(invstd), hip.stream()),
+                  "sp_bn_eval_stats")
+        y = torch.empty_like(x)
+        res = residual.contiguous() if residual is not None else None
+        check(L.sp_bn_apply(ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(res), int(relu), M, Cc, ptr(y),
+                            hip.stream()), "sp_bn_apply")
+        ctx.cfg = (training, relu, residual is not None)
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, relu, has_res = ctx.cfg
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        L = hip.lib()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        ws = hip.workspace(L.sp_bn_workspace(M, Cc), x.device, slot=1)
+        check(L.sp_bn_backward(ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), int(relu), int(training), M, Cc,
+                               ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), hip.stream()), "sp_bn_backward")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True):
+    return _BnAct.apply(x, gamma, beta, rmean, rvar, residual, training, momentum, eps, relu)
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        N, H, W_, Cc = x.shape
+        Ho = -(-(H - 3) // 2) + 1
+        Wo = -(-(W_ - 3) // 2) + 1
+        if (Ho - 1) * 2 >= H:
+            Ho -= 1
+        if (Wo - 1) * 2 >= W_:
+            Wo -= 1
+        y = torch.empty((N, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        check(hip.lib().sp_maxpool3s2_fwd(ptr(x), N, H, W_, Cc, ptr(y), Ho, Wo, hip.stream()), "sp_maxpool3s2_fwd")
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, H, W_, Cc = x.shape
+        _, Ho, Wo, _ = y.shape
+        dx = torch.empty_like(x)
+        check(hip.lib().sp_maxpool3s2_bwd(ptr(dy), ptr(x), ptr(y), N, H, W_, Cc, ptr(dx), Ho, Wo, hip.stream()),
+              "sp_maxpool3s2_bwd")
+        return dx
+
+
+def maxpool3s2(x):
+    return _MaxPool.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------
+# decoder
+# ----------------------------------------------------------------------------------------------------
+class _GateConv(Function):
+    """Hg = conv3x3(h, W_h[4C]) with the rank-1 gate terms accumulated into its first 3C columns:
+         Hg[b,p,n] += sum_k spcol[b,p,k] * wc[b,n,k]
+    (conv3x3(W, spatial (x) semantic) == a 9-tap single-channel conv with the per-sample contracted
+    filter W.s; baseline_attention.py:40-50).  h may be None (step 0: h == 0)."""
+    @staticmethod
+    def forward(ctx, h, w_h, spcol, wc, hw):
+        spcol = spcol.contiguous()
+        wc = wc.contiguous()
+        B, P, KP = spcol.shape
+        N3 = wc.shape[1]
+        wp = _phys(w_h.detach())
+        C4 = wp.shape[0]
+        if h is not None:
+            h = h.contiguous()
+            _, Hm, Wm, Cc = h.shape
+            hg = torch.empty((B, Hm, Wm, C4), dtype=torch.float32, device=spcol.device)
+            _igemm(h, wp, None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4, ldc=C4, ldw=9 * Cc, KH=3,
+                   KW=3, pad=1, mode=0)
+        else:
+            hg = torch.zeros((B, hw[0], hw[1], C4), dtype=torch.float32, device=spcol.device)
+        _igemm(spcol, wc, None, hg, N_img=P, Hi=1, Wi=1, Kc=KP, ldx=KP, Ho=1, Wo=1, Nout=N3, ldc=C4, ldw=KP, mode=0, beta=1,
+               nbatch=B, sX=P * KP, sW=N3 * KP, sC=P * C4)
+        ctx.has_h = h is not None
+        ctx.save_for_backward(h, wp, spcol, wc)
+        return hg
+
+    @staticmethod
+    def backward(ctx, dhg):
+        h, wp, spcol, wc = ctx.saved_tensors
+        dhg = dhg.contiguous()
+        B, P, KP = spcol.shape
+        N3 = wc.shape[1]
+        C4 = wp.shape[0]
+        dh = dw = dsp = dwc = None
+        if ctx.has_h:
+            _, Hm, Wm, Cc = h.shape
+            if ctx.needs_input_grad[0]:
+                dh = torch.empty_like(h)
+                _igemm(dhg, wp, None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm, Nout=Cc, ldc=Cc, ldw=Cc, KH=3,
+                       KW=3, pad=1, mode=1)
+            if ctx.needs_input_grad[1]:
+                dwp = torch.empty_like(wp)
+                _wgrad(h, dhg, dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Co=C4, ldy=C4, ldo=9 * Cc, KH=3,
+                       KW=3, pad=1)
+                dw = dwp.permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(wp).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[2]:
+            dsp = torch.empty_like(spcol)
+            _igemm(dhg, wc, None, dsp, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1,
+                   nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
+        if ctx.needs_input_grad[3]:
+            dwc = torch.empty_like(wc)
+            _wgrad(spcol, dhg, dwc, N_img=P, Hi=1, Wi=1, Ci=KP, ldx=KP, Ho=1, Wo=1, Co=N3, ldy=C4, ldo=KP, nbatch=B,
+                   sX=P * KP, sY=P * C4, sO=N3 * KP)
+        return dh, dw, dsp, dwc, None
+
+
+def gate_conv(h, w_h, spcol, wc, hw):
+    return _GateConv.apply(h, w_h, spcol, wc, hw)
+
+
+class _LstmCell(Function):
+    @staticmethod
+    def forward(ctx, xg, hg, c_prev):
+        xg = xg.contiguous()
+        hg = hg.contiguous() if hg is not None else None
+        c_prev = c_prev.contiguous() if c_prev is not None else None
+        C4 = xg.shape[-1]
+        Cc = C4 // 4
+        rows = xg.numel() // C4
+        shp = xg.shape[:-1] + (Cc,)
+        gates = torch.empty_like(xg)
+        c = torch.empty(shp, dtype=torch.float32, device=xg.device)
+        h = torch.empty(shp, dtype=torch.float32, device=xg.device)
+        check(hip.lib().sp_lstm_pointwise_fwd(ptr(xg), ptr(hg), ptr(c_prev), rows, Cc, ptr(gates), ptr(c), ptr(h),
+                                              hip.stream()), "sp_lstm_pointwise_fwd")
+        ctx.has = (hg is not None, c_prev is not None)
+        ctx.save_for_backward(gates, c_prev, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, c = ctx.saved_tensors
+        dh = dh.contiguous() if dh is not None else None
+        dc = dc.contiguous() if dc is not None else None
+        C4 = gates.shape[-1]
+        Cc = C4 // 4
+        rows = gates.numel() // C4
+        dpre = torch.empty_like(gates)
+        dcp = torch.empty_like(c)
+        check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
+                                              ptr(dcp), hip.stream()), "sp_lstm_pointwise_bwd")
+        has_hg, has_c = ctx.has
+        return dpre, (dpre if has_hg else None), (dcp if has_c else None)
+
+
+def lstm_cell(xg, hg, c_prev):
+    return _LstmCell.apply(xg, hg, c_prev)
+
+
+class _Im2col(Function):
+    """maps [S, R, H, W] -> col [R, H*W, KP]; stream s occupies columns [9s, 9s+9), the rest is zero."""
+    @staticmethod
+    def forward(ctx, maps, KP):
+        maps = maps.contiguous()
+        S, R, H, W_ = maps.shape
+        col = torch.zeros((R, H * W_, KP), dtype=torch.float32, device=maps.device)
+        for s in range(S):
+            check(hip.lib().sp_im2col3x3_1ch(ptr(maps[s]), R, H, W_, 9 * s, KP, ptr(col), hip.stream()), "sp_im2col3x3_1ch")
+        ctx.shape = (S, R, H, W_, KP)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        S, R, H, W_, KP = ctx.shape
+        dcol = dcol.contiguous()
+        dm = torch.empty((S, R, H, W_), dtype=torch.float32, device=dcol.device)
+        for s in range(S):
+            check(hip.lib().sp_col2im3x3_1ch(ptr(dcol), R, H, W_, 9 * s, KP, ptr(dm[s]), hip.stream()), "sp_col2im3x3_1ch")
+        return dm, None
+
+
+def im2col3x3(maps, KP):
+    return _Im2col.apply(maps, KP)
+
+
+class _ListAtt(Function):
+    """L [T,R,D], u [D] -> mem [R,D] = sum_t softmax_t(<L[t,r],u>) L[t,r]"""
+    @staticmethod
+    def forward(ctx, Lst, u):
+        Lst = Lst.contiguous()
+        u = u.contiguous()
+        T, R, D = Lst.shape
+        mem = torch.empty((R, D), dtype=torch.float32, device=Lst.device)
+        alpha = torch.empty((T, R), dtype=torch.float32, device=Lst.device)
+        check(hip.lib().sp_listatt_fwd(ptr(Lst), ptr(u), T, R, D, ptr(mem), ptr(alpha), hip.stream()), "sp_listatt_fwd")
+        ctx.save_for_backward(Lst, u, alpha)
+        return mem
+
+    @staticmethod
+    def backward(ctx, dmem):
+        Lst, u, alpha = ctx.saved_tensors
+        dmem = dmem.contiguous()
+        T, R, D = Lst.shape
+        dL = torch.empty_like(Lst)
+        dup = torch.empty((R, D), dtype=torch.float32, device=Lst.device)
+        check(hip.lib().sp_listatt_bwd(ptr(dmem), ptr(Lst), ptr(u), ptr(alpha), T, R, D, ptr(dL), ptr(dup), hip.stream()),
+              "sp_listatt_bwd")
+        du = _colsum_any(dup, D) if ctx.needs_input_grad[1] else None
+        return dL, du
+
+
+def list_attention(Lst, u):
+    return _ListAtt.apply(Lst, u)
+
+
+class _MulRelu(Function):
+    """a [S, n] (any trailing shape), b [n]  ->  relu(a * b)"""
+    @staticmethod
+    def forward(ctx, a, b):
+        a = a.contiguous()
+        b = b.contiguous()
+        out = torch.empty_like(a)
+        check(hip.lib().sp_mulrelu_fwd(ptr(a), ptr(b), a.numel(), b.numel(), ptr(out), hip.stream()), "sp_mulrelu_fwd")
+        ctx.save_for_backward(a, b, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, out = ctx.saved_tensors
+        dout = dout.contiguous()
+        da = torch.empty_like(a)
+        dbp = torch.empty_like(a)
+        check(hip.lib().sp_mulrelu_bwd(ptr(dout), ptr(a), ptr(b), ptr(out), a.numel(), b.numel(), ptr(da), ptr(dbp),
+                                       hip.stream()), "sp_mulrelu_bwd")
+        S = a.numel() // b.numel()
+        parts = dbp.view(S, -1)
+        db = parts[0]
+        for s in range(1, S):
+            db = add(db, parts[s])
+        return da, db.view(b.shape)
+
+
+def mul_relu(a, b):
+    return _MulRelu.apply(a, b)
+
+
+class _RowMean(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        check(hip.lib().sp_rowsum(ptr(x), M, Cc, 1.0 / Cc, ptr(out), hip.stream()), "sp_rowsum")
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        Cc = ctx.shape[-1]
+        dx = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        check(hip.lib().sp_rowsum_bwd(ptr(dout), dx.numel() // Cc, Cc, 1.0 / Cc, ptr(dx), hip.stream()), "sp_rowsum_bwd")
+        return dx
+
+
+def channel_mean(x):
+    return _RowMean.apply(x)
+
+
+class _SelectRows(Function):
+    @staticmethod
+    def forward(ctx, a, b, sel):
+        a = a.contiguous()
+        b = b.contiguous()
+        rows = a.shape[0]
+        ln = a.numel() // rows
+        out = torch.empty_like(a)
+        sel8 = sel.to(torch.uint8).contiguous()
+        check(hip.lib().sp_select_rows(ptr(a), ptr(b), ptr(sel8), rows, ln, ptr(out), hip.stream()), "sp_select_rows")
+        ctx.save_for_backward(sel8)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (sel8,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        rows = dout.shape[0]
+        ln = dout.numel() // rows
+        da = torch.empty_like(dout)
+        db = torch.empty_like(dout)
+        check(hip.lib().sp_select_rows_bwd(ptr(dout), ptr(sel8), rows, ln, ptr(da), ptr(db), hip.stream()),
+              "sp_select_rows_bwd")
+        return da, db, None
+
+
+def select_rows(a, b, sel):
+    return _SelectRows.apply(a, b, sel)
+
+
+class _HeadFinish(Function):
+    """Z [B,Hm,Wm,nh*HC] -> logits [nh,B,1+P], amap [nh,B,P], mu [nh,B], sigma2 [nh,B]"""
+    @staticmethod
+    def forward(ctx, Z, cb, w2, b2, nheads, HC, softmax):
+        Z = Z.contiguous()
+        cb = cb.contiguous()
+        w2c = w2.detach().contiguous()
+        b2 = b2.contiguous()
+        B, Hm, Wm, ldz = Z.shape
+        P = Hm * Wm
+        dev = Z.device
+        dh, dw = (Hm + 4 - 7) // 5 + 1, (Wm + 4 - 7) // 5 + 1
+        logits = torch.empty((nheads, B, P + 1), dtype=torch.float32, device=dev)
+        amap = torch.empty((nheads, B, P), dtype=torch.float32, device=dev)
+        mu = torch.empty((nheads, B), dtype=torch.float32, device=dev)
+        s2 = torch.empty((nheads, B), dtype=torch.float32, device=dev)
+        drt = torch.empty((nheads, B, dh * dw), dtype=torch.float32, device=dev)
+        check(hip.lib().sp_head_finish_fwd(ptr(Z), B, Hm, Wm, ldz, nheads, HC, ptr(cb), ptr(w2c), ptr(b2), int(softmax),
+                                           ptr(logits), ptr(amap), ptr(mu), ptr(s2), ptr(drt), hip.stream()),
+              "sp_head_finish_fwd")
+        ctx.cfg = (B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, tuple(w2.shape))
+        ctx.save_for_backward(logits, amap, s2, drt, w2c)
+        return logits, amap, mu, s2
+
+    @staticmethod
+    def backward(ctx, dlogits, damap, dmu, ds2):
+        B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, w2shape = ctx.cfg
+        logits, amap, s2, drt, w2c = ctx.saved_tensors
+        dev = logits.device
+        zf = lambda t, ref: (t.contiguous() if t is not None else torch.zeros_like(ref))
+        dlogits = zf(dlogits, logits)
+        dmu = zf(dmu, s2)
+        ds2 = zf(ds2, s2)
+        damap = damap.contiguous() if damap is not None else None
+        S = dh * dw
+        dZ = torch.empty((B, Hm, Wm, ldz), dtype=torch.float32, device=dev)
+        if ldz != nheads * HC:
+            dZ.zero_()
+        dcbp = torch.empty((B, nheads * HC), dtype=torch.float32, device=dev)
+        dw2p = torch.empty((B, nheads * 2 * S), dtype=torch.float32, device=dev)
+        db2p = torch.empty((B, nheads * 2), dtype=torch.float32, device=dev)
+        check(hip.lib().sp_head_finish_bwd(ptr(dlogits), ptr(damap), ptr(dmu), ptr(ds2), ptr(logits), ptr(amap), ptr(s2),
+                                           ptr(drt), B, Hm, Wm, ldz, nheads, HC, ptr(w2c), int(softmax), ptr(dZ), ptr(dcbp),
+                                           ptr(dw2p), ptr(db2p), hip.stream()), "sp_head_finish_bwd")
+        dcb = _colsum_any(dcbp, nheads * HC).view(nheads, HC)
+        dw2 = _colsum_any(dw2p, nheads * 2 * S).view(nheads, 2 * S)
+        db2 = _colsum_any(db2p, nheads * 2).view(nheads, 2)
+        dw2s, db2s = dw2[0], db2[0]
+        for k in range(1, nheads):          # drt_layer_2 is shared by the heads
+            dw2s = add(dw2s.contiguous(), dw2[k].contiguous())
+            db2s = add(db2s.contiguous(), db2[k].contiguous())
+        return dZ, dcb, dw2s.reshape(w2shape), db2s.reshape(2), None, None, None
+
+
+def head_finish(Z, cb, w2, b2, nheads, HC, softmax):
+    return _HeadFinish.apply(Z, cb, w2, b2, nheads, HC, softmax)
+
+
+# ----------------------------------------------------------------------------------------------------
+# loss
+# ----------------------------------------------------------------------------------------------------
+def device_sum(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L = hip.lib()
+    ws = hip.workspace(L.sp_sumsq_workspace(x.numel()), x.device, slot=1)
+    check(L.sp_sum(ptr(x), x.numel(), ptr(out), ptr(ws), hip.stream()), "sp_sum")
+    return out
+
+
+class _ScanpathLoss(Function):
+    @staticmethod
+    def forward(ctx, z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums):
+        z, mu, sigma2 = z.contiguous(), mu.contiguous(), sigma2.contiguous()
+        gt, amask, dur, dmask = gt.contiguous(), amask.contiguous(), dur.contiguous(), dmask.contiguous()
+        B, T, A = z.shape
+        dev = z.device
+        L = hip.lib()
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z)
+        dmu = torch.empty_like(mu)
+        ds2 = torch.empty_like(sigma2)
+        ws = hip.workspace(L.sp_scanpath_loss_workspace(B, T), dev, slot=1)
+        check(L.sp_scanpath_loss(ptr(z), ptr(gt), ptr(amask), ptr(mu), ptr(sigma2), ptr(dur), ptr(dmask), B, T, A,
+                                 float(lambda1), ptr(mask_sums), ptr(out3), ptr(dz), ptr(dmu), ptr(ds2), ptr(ws),
+                                 hip.stream()), "sp_scanpath_loss")
+        ctx.save_for_backward(dz, dmu, ds2)
+        loss, la, ld = out3[0].clone(), out3[1].clone(), out3[2].clone()
+        ctx.mark_non_differentiable(la, ld)
+        return loss, la, ld
+
+    @staticmethod
+    def backward(ctx, g, _ga, _gd):
+        dz, dmu, ds2 = ctx.saved_tensors
+        g = g.reshape(1).contiguous().to(torch.float32)
+        L = hip.lib()
+        outs = []
+        for t in (dz, dmu, ds2):
+            o = torch.empty_like(t)
+            check(L.sp_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), hip.stream()), "sp_scale_by")
+            outs.append(o)
+        return outs[0], outs[1], outs[2], None, None, None, None, None, None
+
+
+def scanpath_loss(z, mu, sigma2, gt, amask, dur, dmask, lambda1=1.0, mask_sums=None):
+    """loss, loss_actions, loss_duration (AiR/train.py:192-197).  mask_sums: device tensor
+    [sum(action_masks), sum(duration_masks)]; computed locally when None (single-process semantics)."""
+    if mask_sums is None:
+        mask_sums = torch.cat([device_sum(amask), device_sum(dmask)])
+    return _ScanpathLoss.apply(z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums)

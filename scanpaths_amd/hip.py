@@ -1,0 +1,136 @@
+"""ctypes binding of libscanpaths_amd.so (the C ABI declared in include/scanpaths_amd.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a tensor is not on a HIP
+device, the calls raise.  torch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscanpaths_amd.so")
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N_img", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Kc", C.c_int), ("ldx", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("Nout", C.c_int), ("ldc", C.c_int),
+                ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
+                ("mode", C.c_int), ("ldw", C.c_int),
+                ("alpha", C.c_float), ("beta", C.c_int), ("relu", C.c_int),
+                ("nbatch", C.c_int),
+                ("strideX", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("N_img", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ci", C.c_int), ("ldx", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("Co", C.c_int), ("ldy", C.c_int),
+                ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
+                ("ldo", C.c_int), ("beta", C.c_int), ("alpha", C.c_float), ("nbatch", C.c_int),
+                ("strideX", C.c_int64), ("strideY", C.c_int64), ("strideO", C.c_int64)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/scanpaths_amd.h declares
+SIGNATURES = {
+    "sp_abi_version": (_I, []),
+    "sp_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "sp_conv_wgrad_workspace": (_L, [C.POINTER(WgradDesc)]),
+    "sp_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),
+    "sp_colsum_workspace": (_L, [_L, _I]),
+    "sp_colsum": (_I, [_P, _L, _I, _I, _P, _I, _P, _P]),
+    "sp_rowsum": (_I, [_P, _L, _I, _F, _P, _P]),
+    "sp_rowsum_bwd": (_I, [_P, _L, _I, _F, _P, _P]),
+    "sp_bn_workspace": (_L, [_L, _I]),
+    "sp_bn_stats": (_I, [_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "sp_bn_eval_stats": (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    "sp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P]),
+    "sp_bn_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
+    "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "sp_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "sp_nchw_to_nhwc_pad": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_pad_lastdim": (_I, [_P, _L, _I, _I, _P, _P]),
+    "sp_add": (_I, [_P, _P, _P, _L, _P]),
+    "sp_lstm_pointwise_fwd": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "sp_im2col3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_col2im3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_listatt_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "sp_listatt_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "sp_mulrelu_fwd": (_I, [_P, _P, _L, _L, _P, _P]),
+    "sp_mulrelu_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P]),
+    "sp_select_rows": (_I, [_P, _P, _P, _L, _L, _P, _P]),
+    "sp_select_rows_bwd": (_I, [_P, _P, _L, _L, _P, _P, _P]),
+    "sp_head_finish_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "sp_head_finish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "sp_scanpath_loss_workspace": (_L, [_I, _I]),
+    "sp_scanpath_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_scale_by": (_I, [_P, _P, _L, _P, _P]),
+    "sp_sumsq_workspace": (_L, [_L]),
+    "sp_sum": (_I, [_P, _L, _P, _P, _P]),
+    "sp_sumsq": (_I, [_P, _L, _P, _P, _P]),
+    "sp_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises loudly when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  scanpaths_amd has no CPU or eager fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if _lib.sp_abi_version() != 1:
+            raise RuntimeError("libscanpaths_amd.so ABI version mismatch")
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "SP_EINVAL (unsupported shape/alignment)", -2: "SP_ENULL (null pointer)"}.get(rc, f"hipError {rc}")
+        raise HipError(f"{what} failed: {kind}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("scanpaths_amd kernels need tensors on a HIP device (no CPU path)")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws = {}
+
+
+def workspace(nbytes: int, device, slot: int = 0) -> Optional[torch.Tensor]:
+    """Grow-only scratch buffer per (device, slot); safe because every kernel of a process is enqueued in
+    stream order and a slot is consumed by the launch that requested it before the next request."""
+    if nbytes <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    cur = _ws.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = cur
+    return cur

@@ -1,0 +1,386 @@
+"""MI355X-native scanpath model: dilated ResNet encoder + attentive ConvLSTM decoder.
+
+Host-side mirror of the reference ``baseline`` modules
+  AiR            AiR/models/baseline_attention.py:187-504            forward(images, attention_maps, performances)
+  OSIE           OSIE/models/baseline_attention.py:179-414           forward(images)
+  COCO_Search18  COCO_Search18/models/baseline_attention_multihead.py:179-424   forward(images, attention_maps, tasks)
+with the same constructor arguments, ``self.training``-switched forward, output dict keys and
+state_dict key names / shapes (scanpaths_amd/spec.py), so the reference's train.py / test.py and its
+checkpoints work unchanged.  All arithmetic runs in hand-written HIP kernels (scanpaths_amd/functional.py).
+
+The decoder is evaluated in an algebraically reduced form (exact in real arithmetic,
+rounding-level differences in fp32):
+  * x-gate convolutions act on the step-invariant visual feature -> computed once as one 512->2048 conv
+    (reference recomputes 4 convs per step, :44-50,304);
+  * conv3x3(W, spatial (x) semantic) of a rank-1 tensor == 9-tap single-channel conv with the per-sample
+    contracted filter W.semantic -> two small GEMMs instead of six 512->512 convs per step (:40-50);
+  * 5x5 head conv followed by the linear 1x1 / 7x7-stride-5 predict_head convs (no non-linearity in
+    between, :306-309,152-158) -> weights composed once per forward: 5x5 512->51 per head instead of 512->512,
+    with the zero-padding semantics of the intermediate map preserved in the epilogue kernel;
+  * semantic_att / spatial_att: the "cur" branch and all biases are constant along the softmax axis and
+    cancel (:82-86,117-121) -> scores are <entry, u> with u composed from the "lists" and "attention"
+    weights; semantic_cur / spatial_cur / those biases receive exactly zero gradient (the reference
+    produces rounding-level noise there);
+  * get_spatial_semantic = a * mean_c(vf) (:240-244) -> mean_c(vf) computed once.
+Map size is derived from the input (Hm = H/8, Wm = W/8) instead of the hard-coded 30x40 (:105,142,145,208,279).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from ..spec import ARCHS, COCO_OBJECTS, drt_hw, encoder_channels
+
+HC = 64       # padded column count of one composed head (51 used)
+NTAP = 49
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter holders (give the state_dict the reference's key structure)
+# ----------------------------------------------------------------------------------------------------
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, kh, kw=None, bias=True):
+        super().__init__()
+        kw = kh if kw is None else kw
+        self.weight = nn.Parameter(torch.empty(cout, cin, kh, kw).contiguous(memory_format=torch.channels_last))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        if not bias:
+            self.register_parameter("bias", None)
+
+
+class _Linear(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _Block(nn.Module):
+    def __init__(self, kind, inpl, planes, exp, with_down):
+        super().__init__()
+        if kind == "bottleneck":
+            self.conv1 = _Conv(inpl, planes, 1, bias=False)
+            self.bn1 = _BN(planes)
+            self.conv2 = _Conv(planes, planes, 3, bias=False)
+            self.bn2 = _BN(planes)
+            self.conv3 = _Conv(planes, planes * 4, 1, bias=False)
+            self.bn3 = _BN(planes * 4)
+        else:
+            self.conv1 = _Conv(inpl, planes, 3, bias=False)
+            self.bn1 = _BN(planes)
+            self.conv2 = _Conv(planes, planes, 3, bias=False)
+            self.bn2 = _BN(planes)
+        if with_down:
+            self.downsample = nn.Sequential(_Conv(inpl, planes * exp, 1, bias=False), _BN(planes * exp))
+        else:
+            self.downsample = None
+
+
+def _make_encoder(arch):
+    kind, counts, exp = ARCHS[arch]
+    mods = [_Conv(3, 64, 7, bias=False), _BN(64), nn.Identity(), nn.Identity()]
+    inpl = 64
+    for li, n in enumerate(counts):
+        planes = 64 * 2 ** li
+        nominal_stride = 1 if li == 0 else 2
+        blocks = []
+        for bi in range(n):
+            down = bi == 0 and (nominal_stride != 1 or inpl != planes * exp)
+            blocks.append(_Block(kind, inpl, planes, exp, down))
+            inpl = planes * exp
+        mods.append(nn.Sequential(*blocks))
+    return nn.Sequential(*mods)
+
+
+class _LSTMParams(nn.Module):
+    def __init__(self, streams):
+        super().__init__()
+        for g in ("input", "forget", "output", "memory"):
+            setattr(self, g + "_x", _Conv(512, 512, 3))
+        for g in ("input", "forget", "output", "memory"):
+            setattr(self, g + "_h", _Conv(512, 512, 3))
+        for sfx in streams:
+            for g in ("input", "forget", "output"):
+                setattr(self, g + sfx, _Conv(512, 512, 3))
+
+
+class _SemAtt(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.semantic_lists = _Linear(512, 512)
+        self.semantic_cur = _Linear(512, 512)
+        self.semantic_attention = _Linear(512, 1)
+
+
+class _SpaAtt(nn.Module):
+    def __init__(self, Hm, Wm):
+        super().__init__()
+        self.spatial_lists = _Conv(1, 1, 3)
+        self.spatial_cur = _Conv(1, 1, 3)
+        self.spatial_attention = _Conv(1, 1, Hm, Wm)
+
+
+class _Head(nn.Module):
+    def __init__(self, Hm, Wm):
+        super().__init__()
+        dh, dw = drt_hw(Hm, Wm)
+        self.sal_layer_2 = _Conv(512, 1, 1)
+        self.sal_layer_3 = _Conv(512, 1, 1)
+        self.drt_layer_1 = _Conv(512, 1, 7)
+        self.drt_layer_2 = _Conv(1, 2, dh, dw)
+
+
+# ----------------------------------------------------------------------------------------------------
+class ScanpathModel(nn.Module):
+    """Generic over task ("AiR" | "OSIE" | "COCO_Search18"), encoder ("resnet50" | "resnet18") and map size."""
+
+    def __init__(self, task="AiR", embed_size=512, convLSTM_length=16, min_length=1, ratio=4, map_width=40, map_height=30,
+                 arch="resnet50"):
+        super().__init__()
+        assert task in ("AiR", "OSIE", "COCO_Search18")
+        self.task, self.arch = task, arch
+        self.embed_size, self.ratio = embed_size, ratio
+        self.convLSTM_length, self.min_length = convLSTM_length, min_length
+        self.downsampling_rate = 8
+        self.map_width, self.map_height = map_width, map_height
+        self.streams = ["_pos", "_neg"] if task == "AiR" else [""]
+        Hm, Wm = map_height, map_width
+        P = Hm * Wm
+        self.resnet = _make_encoder(arch)
+        self.sal_conv = _Conv(encoder_channels(arch), 512, 3)
+        self.lstm = _LSTMParams(self.streams)
+        self.semantic_embed = _Linear(512, 512)
+        self.spatial_embed = _Linear(P, P)
+        self.semantic_att = _SemAtt()
+        self.spatial_att = _SpaAtt(Hm, Wm)
+        if task == "AiR":
+            self.performance_situation = ["False", "True"]
+            self.performance_sal_layer = nn.ModuleDict({k: _Conv(512, 512, 5) for k in self.performance_situation})
+        elif task == "OSIE":
+            self.performance_sal_layer = _Conv(512, 512, 5)
+        else:
+            self.object_name = list(COCO_OBJECTS)
+            self.int2object = {i: n for i, n in enumerate(self.object_name)}
+            self.object_sal_layer = nn.ModuleDict({k: _Conv(512, 512, 5) for k in self.object_name})
+        self.object_head = _Head(Hm, Wm)
+        self.init_weights()
+
+    # ---- init: resnet.py:112-118 (He normal, BN 1/0); mmcv xavier_init (normal) for convs, normal_init(std=0.01) for
+    #      Linear (baseline_attention.py:58-65,90-97,126-133,176-185,495-504) ----
+    def init_weights(self):
+        for name, m in self.named_modules():
+            if isinstance(m, _Conv):
+                co, ci, kh, kw = m.weight.shape
+                if name.startswith("resnet."):
+                    nn.init.normal_(m.weight, 0.0, (2.0 / (kh * kw * co)) ** 0.5)
+                else:
+                    nn.init.xavier_normal_(m.weight)
+                    if m.bias is not None:
+                        nn.init.zeros_(m.bias)
+            elif isinstance(m, _Linear):
+                nn.init.normal_(m.weight, 0.0, 0.01)
+                nn.init.zeros_(m.bias)
+
+    # ------------------------------------------------------------------------------------------------
+    def _bn(self, bn: _BN, x, residual=None, relu=True):
+        y = F.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training=self.training, relu=relu)
+        if self.training:
+            bn.num_batches_tracked += 1
+        return y
+
+    def encode(self, images):
+        """models/resnet.py:96-152 + dilate_resnet (baseline_attention.py:226-238), NHWC."""
+        r = self.resnet
+        x = F.nchw_to_nhwc(images, 4)
+        w0 = F.pad_last(r[0].weight.permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)     # Cin 3 -> 4 (zero)
+        x = F.conv2d(x, w0, None, stride=2, pad=3)
+        x = self._bn(r[1], x)
+        x = F.maxpool3s2(x)
+        kind = ARCHS[self.arch][0]
+        for li in range(4):
+            first_stride = 2 if li == 2 else 1       # layer2[0], layer4[0] strides forced to 1
+            dil = {2: 2, 3: 4}.get(li, 1)
+            for bi, blk in enumerate(r[4 + li]):
+                s = first_stride if bi == 0 else 1
+                if kind == "bottleneck":
+                    o = self._bn(blk.bn1, F.conv2d(x, blk.conv1.weight, None, stride=s))
+                    o = self._bn(blk.bn2, F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil))
+                    o = F.conv2d(o, blk.conv3.weight, None)
+                    last = blk.bn3
+                else:
+                    o = self._bn(blk.bn1, F.conv2d(x, blk.conv1.weight, None, stride=s, pad=1))
+                    o = F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil)
+                    last = blk.bn2
+                idn = x
+                if blk.downsample is not None:
+                    idn = self._bn(blk.downsample[1], F.conv2d(x, blk.downsample[0].weight, None, stride=s), relu=False)
+                x = self._bn(last, o, residual=idn, relu=True)
+        return x
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _cat_phys(ws: List[torch.Tensor]) -> torch.Tensor:
+        """concatenate conv weights along Cout; returns the logical-OIHW view of a [sumCo,KH,KW,Ci] buffer."""
+        return torch.cat([w.permute(0, 2, 3, 1) for w in ws], 0).permute(0, 3, 1, 2)
+
+    def _sum_bias(self, names):
+        b = getattr(self.lstm, names[0]).bias
+        for n in names[1:]:
+            b = F.add(b, getattr(self.lstm, n).bias)
+        return b
+
+    def _compose_heads(self, convs: List[_Conv]):
+        """Compose each 5x5 head conv with sal_layer_2 / sal_layer_3 / drt_layer_1 (predict_head, :149-158)."""
+        oh = self.object_head
+        dev = oh.sal_layer_2.weight.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        wcomp = torch.cat([oh.sal_layer_2.weight.view(1, 512), oh.sal_layer_3.weight.view(1, 512),
+                           oh.drt_layer_1.weight.permute(0, 2, 3, 1).reshape(NTAP, 512), z(HC - 2 - NTAP, 512)], 0)
+        own = torch.cat([oh.sal_layer_2.bias, oh.sal_layer_3.bias, z(NTAP), oh.drt_layer_1.bias, z(HC - 3 - NTAP)])
+        Gs, cbs = [], []
+        for cv in convs:
+            w5 = cv.weight.permute(0, 2, 3, 1).reshape(512, 25 * 512)                 # [o][tap*ci]
+            Gs.append(F.gemm(wcomp, w5, None, "kn"))                                   # [HC, 25*512]
+            b4 = torch.cat([cv.bias.view(1, 512), z(3, 512)], 0)
+            cbs.append(F.add(F.gemm(wcomp, b4, None, "nk")[:, 0].contiguous(), own))   # [HC]
+        G = torch.cat(Gs, 0).view(len(convs) * HC, 5, 5, 512).permute(0, 3, 1, 2)
+        return G, torch.stack(cbs, 0)
+
+    def _attention_vectors(self):
+        sa, pa = self.semantic_att, self.spatial_att
+        dev = sa.semantic_lists.weight.device
+        u_sem = F.gemm(sa.semantic_attention.weight, sa.semantic_lists.weight, None, "kn").view(512)   # W_l^T w_a
+        Hm, Wm = self.map_height, self.map_width
+        acol = F.im2col3x3(pa.spatial_attention.weight.view(1, 1, Hm, Wm), 12).view(Hm * Wm, 12)
+        wl = torch.cat([pa.spatial_lists.weight.reshape(9).flip(0), torch.zeros(3, device=dev)]).view(1, 12)
+        wl4 = torch.cat([wl, torch.zeros(3, 12, device=dev)], 0)
+        u_spa = F.gemm(acol, wl4, None, "nk")[:, 0].contiguous()
+        return u_sem, u_spa
+
+    # ------------------------------------------------------------------------------------------------
+    def decode(self, enc, attention_maps, tasks=None):
+        """T steps of the attentive ConvLSTM; returns per-head stacks
+        logits [nh,B,T,A], mu [nh,B,T], sigma2 [nh,B,T], amap [nh,B,T,P]."""
+        T = self.convLSTM_length
+        S = len(self.streams)
+        vf = F.conv2d(enc, self.sal_conv.weight, self.sal_conv.bias, pad=1, relu=True)       # :270
+        B, Hm, Wm, Cc = vf.shape
+        assert (Hm, Wm) == (self.map_height, self.map_width), \
+            f"input gives a {Hm}x{Wm} map but the model was built for {self.map_height}x{self.map_width}"
+        P = Hm * Wm
+        dev = vf.device
+        L = self.lstm
+        # hoisted x-gates, all gate biases folded in
+        Wx = self._cat_phys([L.input_x.weight, L.forget_x.weight, L.output_x.weight, L.memory_x.weight])
+        bias = torch.cat([self._sum_bias([g + "_x", g + "_h"] + [g + s for s in self.streams])
+                          for g in ("input", "forget", "output")] + [self._sum_bias(["memory_x", "memory_h"])])
+        Xg = F.conv2d(vf, Wx, bias, pad=1)
+        Wh = self._cat_phys([L.input_h.weight, L.forget_h.weight, L.output_h.weight, L.memory_h.weight])
+        Wr = [torch.cat([getattr(L, g + s).weight.permute(0, 2, 3, 1) for g in ("input", "forget", "output")], 0)
+              .reshape(3 * 512 * 9, 512) for s in self.streams]
+        KP = (9 * S + 3) // 4 * 4
+        mvf = F.channel_mean(vf).view(B * P)
+        u_sem, u_spa = self._attention_vectors()
+        vf3 = vf.view(B, P, Cc)
+        # heads
+        if self.task == "AiR":
+            head_convs = [self.performance_sal_layer["True"], self.performance_sal_layer["False"]]   # good, poor
+        elif self.task == "OSIE":
+            head_convs = [self.performance_sal_layer]
+        else:
+            head_convs = None
+        nh = S
+        if head_convs is not None:
+            G, cb = self._compose_heads(head_convs)
+        else:
+            uniq = torch.unique(tasks).tolist()
+            Gt, cbt = self._compose_heads([self.object_sal_layer[self.int2object[int(t)]] for t in uniq])
+            sample_slot = torch.tensor([uniq.index(int(t)) for t in tasks.tolist()], device=dev)
+        w2, b2 = self.object_head.drt_layer_2.weight, self.object_head.drt_layer_2.bias
+        sp_list: List[torch.Tensor] = []
+        se_list: List[torch.Tensor] = []
+
+        def push(amaps):          # amaps [S,B,P]; memory update :277-296 / :317-336
+            spf = F.mul_relu(amaps, mvf)
+            sp_list.append(F.linear(spf.view(S * B, P), self.spatial_embed.weight, self.spatial_embed.bias))
+            pooled = F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)   # [B,S,C]
+            se_list.append(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), self.semantic_embed.weight,
+                                    self.semantic_embed.bias))
+            sp_mem = F.list_attention(torch.stack(sp_list, 0), u_spa)        # [S*B,P]
+            se_mem = F.list_attention(torch.stack(se_list, 0), u_sem)        # [S*B,C]
+            return sp_mem, se_mem
+
+        a0 = attention_maps.reshape(1, B, P).to(torch.float32)
+        sp_mem, se_mem = push(a0.expand(S, B, P).contiguous())
+        h = c = None
+        outs = {"logits": [], "amap": [], "mu": [], "s2": []}
+        zpad = torch.zeros(B, 3 * 512, KP - 9 * S, device=dev) if KP > 9 * S else None
+        for _ in range(T):
+            se = se_mem.view(S, B, Cc)
+            parts = [F.gemm(se[s], Wr[s], None, "nk").view(B, 3 * 512, 9) for s in range(S)]
+            wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
+            spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
+            hg = F.gate_conv(h, Wh, spcol, wc, (Hm, Wm))
+            h, c = F.lstm_cell(Xg, hg, c)
+            if head_convs is not None:
+                Z = F.conv2d(h, G, None, pad=2)
+                cbs = cb
+            else:      # COCO: per-sample head conv selected by task id (...multihead.py:285-288)
+                Zs = [F.conv2d(h, Gt[k * HC:(k + 1) * HC], None, pad=2) for k in range(len(uniq))]
+                Z = Zs[0]
+                for k in range(1, len(uniq)):
+                    Z = F.select_rows(Zs[k], Z, sample_slot == k)
+                cbs = None
+            if cbs is not None:
+                logits, amap, mu, s2 = F.head_finish(Z, cbs, w2, b2, nh, HC, not self.training)
+            else:
+                raise NotImplementedError
+            outs["logits"].append(logits)
+            outs["amap"].append(amap)
+            outs["mu"].append(mu)
+            outs["s2"].append(s2)
+            sp_mem, se_mem = push(amap)
+        return {k: torch.stack(v, 2) for k, v in outs.items()}
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, images, attention_maps=None, third=None):
+        if not images.is_cuda:
+            raise RuntimeError("scanpaths_amd runs on a HIP device only (no CPU path); move the model and inputs to cuda")
+        B = images.shape[0]
+        Hm, Wm = self.map_height, self.map_width
+        if self.task == "OSIE":
+            attention_maps = torch.zeros(B, 1, Hm, Wm, device=images.device)        # OSIE/...:261
+        enc = self.encode(images)
+        d = self.decode(enc, attention_maps, third if self.task == "COCO_Search18" else None)
+        T = self.convLSTM_length
+        if self.task == "AiR":
+            if self.training:                                   # :360-383
+                sel = third.to(images.device).to(torch.bool)
+                pick = lambda t: F.select_rows(t[0].reshape(B, -1), t[1].reshape(B, -1), sel)
+                return {"all_actions_prob": pick(d["logits"]).view(B, T, -1),
+                        "log_normal_mu": pick(d["mu"]).view(B, T),
+                        "log_normal_sigma2": pick(d["s2"]).view(B, T)}
+            res = {}
+            for i, name in enumerate(("good", "poor")):         # :471-491
+                res[name + "_all_actions_prob"] = d["logits"][i]
+                res[name + "_log_normal_mu"] = d["mu"][i]
+                res[name + "_log_normal_sigma2"] = d["s2"][i]
+                res[name + "_action_map"] = d["amap"][i].view(B, T, Hm, Wm)
+            return res
+        if self.task == "OSIE" and self.training:               # OSIE/...:316-320
+            return {"actions": d["logits"][0], "log_normal_mu": d["mu"][0], "log_normal_sigma2": d["s2"][0]}
+        return {"all_actions_prob": d["logits"][0], "log_normal_mu": d["mu"][0], "log_normal_sigma2": d["s2"][0],
+                "action_map": d["amap"][0].view(B, T, Hm, Wm)}

@@ -1,0 +1,207 @@
+"""Generate tests/golden/*.npz by importing the REAL reference (chenxy99/Scanpaths at /root/reference).
+
+Runs only in the survey/build container (the reference never travels to the GPU box).  Shims follow
+SURVEY.md §8(c): stub ``mmcv.cnn`` / ``torchvision`` / ``matplotlib``, construct ResNet with
+``pretrained=False``, put ``/root/reference/<task>`` on ``sys.path``.
+
+What is stored (data only -- seeds, and outputs of the reference; weights come from
+``scanpaths_amd.procedural`` and inputs from ``scanpaths_amd.synth``, both regenerated at test time):
+  <case>.npz : reference outputs in fp64 ("ref64/<key>") and fp32 ("ref32/<key>") + loss values,
+               gradient norms per parameter, a few full small gradient tensors, and post-Adam-step
+               parameter checksums for the train cases.
+
+Usage:  python tests/golden/make_golden.py            (writes next to this file)
+"""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from scanpaths_amd.procedural import fill_module  # noqa: E402
+from scanpaths_amd.synth import make_batch  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _install_shims():
+    mmcv = types.ModuleType("mmcv")
+    cnn = types.ModuleType("mmcv.cnn")
+
+    def xavier_init(m, gain=1, bias=0, distribution="normal"):
+        if distribution == "uniform":
+            torch.nn.init.xavier_uniform_(m.weight, gain=gain)
+        else:
+            torch.nn.init.xavier_normal_(m.weight, gain=gain)
+        if getattr(m, "bias", None) is not None:
+            torch.nn.init.constant_(m.bias, bias)
+
+    def normal_init(m, mean=0, std=1, bias=0):
+        torch.nn.init.normal_(m.weight, mean, std)
+        if getattr(m, "bias", None) is not None:
+            torch.nn.init.constant_(m.bias, bias)
+
+    def constant_init(m, val, bias=0):
+        torch.nn.init.constant_(m.weight, val)
+        if getattr(m, "bias", None) is not None:
+            torch.nn.init.constant_(m.bias, bias)
+
+    cnn.xavier_init, cnn.normal_init, cnn.constant_init, cnn.kaiming_init = xavier_init, normal_init, constant_init, None
+    mmcv.cnn = cnn
+    sys.modules.setdefault("mmcv", mmcv)
+    sys.modules.setdefault("mmcv.cnn", cnn)
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    mpl = types.ModuleType("matplotlib")
+    mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+    sys.modules.setdefault("matplotlib", mpl)
+    sys.modules.setdefault("matplotlib.pyplot", mpl.pyplot)
+
+
+def load_reference(task: str, arch: str = "resnet50", T: int = 16):
+    """Import ``models.*`` of one task dir and build its ``baseline`` with random (not downloaded) weights."""
+    _install_shims()
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    sys.path = [p for p in sys.path if not p.startswith(REF)]
+    sys.path.insert(0, os.path.join(REF, task))
+    modname = "models.baseline_attention_multihead" if task == "COCO_Search18" else "models.baseline_attention"
+    M = importlib.import_module(modname)
+    R = importlib.import_module("models.resnet")
+    ctor = getattr(R, arch)
+    M.resnet50 = lambda pretrained=False: ctor(False)
+    model = M.baseline(embed_size=512, convLSTM_length=T)
+    if arch == "resnet18":   # 512-channel trunk needs a 512-in sal_conv
+        model.sal_conv = torch.nn.Conv2d(512, 512, kernel_size=3, padding=1, stride=1, bias=True)
+    L = importlib.import_module("models.loss")
+    S = importlib.import_module("models.sampling")
+    return model, L, S
+
+
+def _np(d, prefix):
+    return {f"{prefix}/{k}": v.detach().cpu().clone().numpy() for k, v in d.items()}
+
+
+def run_case(name, task, arch, B, T, seed, mode, with_step):
+    H, W = 240, 320
+    batch = make_batch(task, B, H, W, T, seed=seed)
+    out = {}
+    meta = dict(task=task, arch=arch, B=B, T=T, H=H, W=W, seed=seed, mode=mode, weight_seed=seed)
+    for dt, tag in ((torch.float64, "ref64"), (torch.float32, "ref32")):
+        model, L, S = load_reference(task, arch, T)
+        fill_module(model, seed=seed)
+        model = model.to(dt)
+        model.train(mode == "train")
+        args = [batch["images"].to(dt)]
+        if task == "AiR":
+            args += [batch["attention_maps"].to(dt)] + ([batch["performances"]] if mode == "train" else [])
+        elif task == "COCO_Search18":
+            args += [batch["attention_maps"].to(dt), batch["tasks"]]
+        if mode == "eval":
+            with torch.no_grad():
+                pred = model(*args)
+            out.update(_np(pred, tag))
+            continue
+        pred = model(*args)
+        out.update(_np(pred, tag))
+        z = pred["actions"] if "actions" in pred else pred["all_actions_prob"]
+        la = L.CrossEntropyLoss(z, batch["scanpaths"].to(dt), batch["action_masks"].to(dt))
+        ld = L.MLPLogNormalDistribution(pred["log_normal_mu"], pred["log_normal_sigma2"],
+                                        batch["durations"].to(dt), batch["duration_masks"].to(dt))
+        loss = la + 1.0 * ld
+        out[f"{tag}/loss"] = np.array([loss.item(), la.item(), ld.item()])
+        if not with_step:
+            continue
+        loss.backward()
+        names = [k for k, _ in model.named_parameters()]
+        gn = np.array([p.grad.norm().item() if p.grad is not None else 0.0 for _, p in model.named_parameters()])
+        out[f"{tag}/grad_norms"] = gn
+        if tag == "ref64":
+            meta["param_names"] = names
+        for k, p in model.named_parameters():
+            if p.numel() <= 4608 and p.grad is not None:     # biases, BN affine, 1-ch convs, small heads
+                out[f"{tag}/grad/{k}"] = p.grad.detach().clone().numpy()   # copy: clip_grad_norm_ scales .grad in place
+        # a strided sample of every big gradient
+        for k, p in model.named_parameters():
+            if p.numel() > 4608 and p.grad is not None:
+                out[f"{tag}/gradsample/{k}"] = p.grad.detach().flatten()[::max(1, p.numel() // 512)][:512].clone().numpy()
+        tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 12.5)
+        out[f"{tag}/total_norm"] = np.array([float(tn)])
+        wd = 5e-5 if task == "AiR" else 5e-4
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+        opt.step()
+        out[f"{tag}/delta_l1"] = np.array([(p.detach() - before[k]).abs().sum().item()
+                                           for k, p in model.named_parameters()])
+        for k, p in model.named_parameters():
+            if p.numel() <= 4608:
+                out[f"{tag}/after/{k}"] = p.detach().clone().numpy()
+        # BN running stats after the train-mode forward (replica-0 stats are what gets checkpointed)
+        sd = model.state_dict()
+        for k in ("resnet.1.running_mean", "resnet.1.running_var", "resnet.7.0.bn2.running_mean",
+                  "resnet.7.0.bn2.running_var"):
+            if k in sd:
+                out[f"{tag}/bn/{k}"] = sd[k].clone().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", name, {k: v.shape for k, v in list(out.items())[:4]})
+
+
+def sampling_case():
+    """generate_scanpath / scanpath-length known answers for fixed selected actions (models/sampling.py:29-77)."""
+    _, _, S = load_reference("AiR", "resnet50", 16)
+    rng = np.random.Generator(np.random.PCG64(7))
+    n, T = 6, 16
+    acts = rng.integers(0, 1201, size=(n, T))
+    acts[0, 5] = 0
+    acts[1, 0] = 0          # terminate at t=0 quirk
+    acts[2, 15] = 0
+    acts[3, 3] = 0
+    acts[3, 9] = 0
+    durs = rng.uniform(0.1, 0.6, size=(n, T)).astype(np.float32)
+    samp = S.Sampling(convLSTM_length=T, min_length=1)
+    fix, am, dm = samp.generate_scanpath(torch.zeros(n, 3, 2, 2), torch.zeros(n, T), torch.from_numpy(durs),
+                                         torch.from_numpy(acts))
+    out = {"acts": acts, "durs": durs, "action_masks": am.numpy(), "duration_masks": dm.numpy()}
+    for b, f in enumerate(fix):
+        out[f"fix{b}"] = np.stack([f["start_x"], f["start_y"], f["duration"]], 1) if len(f) else np.zeros((0, 3))
+    # scanpath_length part of random_sample, replayed on fixed actions
+    length = torch.zeros(n)
+    sel = torch.from_numpy(acts)
+    for index in range(T):
+        length[torch.logical_and(length == 0, sel[:, index] == 0)] = index
+    length[length == 0] = T
+    out["scanpath_length"] = length.numpy()
+    np.savez_compressed(os.path.join(HERE, "sampling.npz"), **out)
+    print("wrote sampling")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["all"]
+    cases = [
+        # name, task, arch, B, T, seed, mode, with_step
+        ("air_train_T4", "AiR", "resnet50", 2, 4, 1, "train", True),
+        ("air_eval_T4", "AiR", "resnet50", 2, 4, 1, "eval", False),
+        ("air_train_T16", "AiR", "resnet50", 2, 16, 2, "train", False),
+        ("air_eval_T16", "AiR", "resnet50", 2, 16, 2, "eval", False),
+        ("osie_r18_train_T8", "OSIE", "resnet18", 2, 8, 3, "train", True),
+        ("osie_r18_eval_T8", "OSIE", "resnet18", 4, 8, 3, "eval", False),
+        ("osie_eval_T4", "OSIE", "resnet50", 2, 4, 4, "eval", False),
+        ("coco_train_T6", "COCO_Search18", "resnet50", 3, 6, 5, "train", True),
+        ("coco_eval_T6", "COCO_Search18", "resnet50", 3, 6, 5, "eval", False),
+    ]
+    for c in cases:
+        if "all" in which or c[0] in which:
+            run_case(*c)
+    if "all" in which or "sampling" in which:
+        sampling_case()

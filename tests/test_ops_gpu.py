@@ -1,0 +1,328 @@
+"""Kernel-level parity: every HIP op (through the C ABI / ctypes) against a plain PyTorch CPU reference of
+the same op in fp64, forward and backward.  Tolerances are fp32-rounding sized and written per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed + sum(shape)))
+    return torch.from_numpy(g.standard_normal(shape).astype(np.float32) * scale)
+
+
+def _close(a, b, tol, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3g}, tol {tol:g})"
+
+
+CONV_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, dil, bias, relu
+    (2, 13, 17, 64, 96, 3, 1, 1, 1, True, True),
+    (2, 15, 20, 32, 128, 3, 1, 2, 2, False, False),
+    (1, 30, 40, 64, 64, 3, 1, 4, 4, False, False),
+    (2, 16, 20, 64, 128, 1, 2, 0, 1, False, False),
+    (2, 9, 11, 96, 40, 1, 1, 0, 1, True, False),
+    (2, 12, 16, 32, 128, 5, 1, 2, 1, True, False),
+    (3, 10, 12, 160, 192, 3, 1, 1, 1, True, False),
+    (2, 17, 21, 32, 64, 3, 2, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case):
+    from scanpaths_amd import functional as F
+    N, H, W, Ci, Co, k, s, p, d, has_b, relu = case
+    x = _rand(N, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, k, k, seed=2, scale=1.0 / math.sqrt(Ci * k * k))
+    b = _rand(Co, seed=3) if has_b else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if has_b else None
+    yr = TF.conv2d(xr, wr, br, stride=s, padding=p, dilation=d)
+    if relu:
+        yr = TF.relu(yr)
+    gy = _rand(*yr.shape, seed=4)
+    yr.backward(gy.double())
+
+    dev = _dev()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    wg = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if has_b else None
+    y = F.conv2d(xg, wg, bg, stride=s, pad=p, dil=d, relu=relu)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    _close(y.permute(0, 3, 1, 2), yr, 2e-6, "y")
+    _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 2e-6, "dx")
+    _close(wg.grad, wr.grad, 3e-6, "dw")
+    if has_b:
+        _close(bg.grad, br.grad, 3e-6, "db")
+
+
+def test_stem_conv_7x7_s2_padded_channels():
+    from scanpaths_amd import functional as F
+    x = _rand(2, 3, 37, 45, seed=5)
+    w = _rand(64, 3, 7, 7, seed=6, scale=0.1)
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, stride=2, padding=3)
+    gy = _rand(*yr.shape, seed=7)
+    yr.backward(gy.double())
+    dev = _dev()
+    wg = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x4 = F.nchw_to_nhwc(x.to(dev), 4)
+    w4 = F.pad_last(wg.permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)
+    y = F.conv2d(x4, w4, None, stride=2, pad=3)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    _close(y.permute(0, 3, 1, 2), yr, 2e-6, "y")
+    _close(wg.grad, wr.grad, 3e-6, "dw")
+
+
+@pytest.mark.parametrize("layout", ["nk", "kn"])
+@pytest.mark.parametrize("shape", [(5, 1200, 1200), (64, 512, 512), (1, 512, 512), (130, 36, 260)])
+def test_gemm(layout, shape):
+    from scanpaths_amd import functional as F
+    M, K, N = shape
+    a = _rand(M, K, seed=8)
+    b = _rand(N, K, seed=9) if layout == "nk" else _rand(K, N, seed=9)
+    bias = _rand(N, seed=10)
+    ar, br, biasr = a.double().requires_grad_(True), b.double().requires_grad_(True), bias.double().requires_grad_(True)
+    cr = (ar @ (br.t() if layout == "nk" else br)) * 0.5 + biasr
+    gc = _rand(M, N, seed=11)
+    cr.backward(gc.double())
+    dev = _dev()
+    ag, bg, biasg = (t.to(dev).requires_grad_(True) for t in (a, b, bias))
+    c = F.gemm(ag, bg, biasg, layout, alpha=0.5)
+    c.backward(gc.to(dev))
+    tol = 3e-6 * math.sqrt(K / 32)
+    _close(c, cr, tol, "c")
+    _close(ag.grad, ar.grad, tol, "da")
+    _close(bg.grad, br.grad, tol, "db")
+    _close(biasg.grad, biasr.grad, tol, "dbias")
+
+
+def test_gemm_batched_kn_relu():
+    from scanpaths_amd import functional as F
+    Bt, M, K, N = 3, 2, 1200, 512
+    a, b = _rand(Bt, M, K, seed=12).abs(), _rand(Bt, K, N, seed=13)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    cr = TF.relu(torch.bmm(ar, br) / K)
+    gc = _rand(Bt, M, N, seed=14)
+    cr.backward(gc.double())
+    dev = _dev()
+    ag, bg = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    c = F.gemm(ag, bg, None, "kn", alpha=1.0 / K, relu=True)
+    c.backward(gc.to(dev))
+    _close(c, cr, 2e-6, "c")
+    _close(ag.grad, ar.grad, 2e-6, "da")
+    _close(bg.grad, br.grad, 2e-6, "db")
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_bn_act(training, with_res):
+    from scanpaths_amd import functional as F
+    N, C, H, W = 3, 64, 9, 11
+    x = _rand(N, C, H, W, seed=15) * 2 + 0.5
+    res = _rand(N, C, H, W, seed=16) if with_res else None
+    gamma, beta = _rand(C, seed=17).abs() + 0.5, _rand(C, seed=18)
+    rm, rv = _rand(C, seed=19) * 0.1, _rand(C, seed=20).abs() + 0.5
+    xr, gr, br = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    yr = TF.batch_norm(xr, rmr, rvr, gr, br, training, 0.1, 1e-5)
+    if with_res:
+        yr = yr + rr
+    yr = TF.relu(yr)
+    gy = _rand(N, C, H, W, seed=21)
+    yr.backward(gy.double())
+    dev = _dev()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    xg, gg, bg = nhwc(x).requires_grad_(True), gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rg = nhwc(res).requires_grad_(True) if with_res else None
+    rmg, rvg = rm.to(dev), rv.to(dev)
+    y = F.bn_act(xg, gg, bg, rmg, rvg, rg, training=training, relu=True)
+    y.backward(nhwc(gy))
+    _close(y.permute(0, 3, 1, 2), yr, 3e-6, "y")
+    _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-5, "dx")
+    _close(gg.grad, gr.grad, 1e-5, "dgamma")
+    _close(bg.grad, br.grad, 1e-5, "dbeta")
+    if with_res:
+        _close(rg.grad.permute(0, 3, 1, 2), rr.grad, 3e-6, "dres")
+    _close(rmg, rmr, 2e-6, "running_mean")
+    _close(rvg, rvr, 2e-6, "running_var")
+
+
+@pytest.mark.parametrize("hw", [(120, 160), (17, 23), (16, 20)])
+def test_maxpool_ceil_with_ties(hw):
+    from scanpaths_amd import functional as F
+    H, W = hw
+    x = TF.relu(_rand(2, 8, H, W, seed=22))        # many exact-zero ties, like the post-ReLU stem
+    xr = x.double().requires_grad_(True)
+    yr = TF.max_pool2d(xr, 3, 2, 0, ceil_mode=True)
+    gy = _rand(*yr.shape, seed=23)
+    yr.backward(gy.double())
+    dev = _dev()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    y = F.maxpool3s2(xg)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert torch.equal(y.permute(0, 3, 1, 2).cpu().double(), yr.detach())
+    _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-6, "dx")
+
+
+def test_lstm_cell_and_gate_conv():
+    from scanpaths_amd import functional as F
+    B, Hm, Wm, C, S = 2, 6, 8, 32, 2
+    KP = 20
+    h, c = _rand(B, C, Hm, Wm, seed=24), _rand(B, C, Hm, Wm, seed=25)
+    xg = _rand(B, 4 * C, Hm, Wm, seed=26)
+    wh = _rand(4 * C, C, 3, 3, seed=27, scale=0.1)
+    sp = _rand(S, B, Hm, Wm, seed=28)
+    wr = [_rand(3 * C, C, 3, 3, seed=29 + s, scale=0.1) for s in range(S)]     # rank-1 conv weights (i,f,o)
+    se = _rand(S, B, C, seed=33)
+    dbl = lambda t: t.double().requires_grad_(True)
+    hr, cr, xgr, whr, spr, ser = dbl(h), dbl(c), dbl(xg), dbl(wh), dbl(sp), dbl(se)
+    wrr = [dbl(t) for t in wr]
+    pre = xgr + TF.conv2d(hr, whr, padding=1)
+    extra = 0
+    for s in range(S):
+        ss = spr[s].unsqueeze(1) * ser[s].unsqueeze(-1).unsqueeze(-1)
+        extra = extra + TF.conv2d(ss, wrr[s], padding=1)
+    pre = pre + torch.cat([extra, torch.zeros_like(extra[:, :C])], 1)
+    i, f, o, g = pre[:, :C].sigmoid(), pre[:, C:2 * C].sigmoid(), pre[:, 2 * C:3 * C].sigmoid(), pre[:, 3 * C:].tanh()
+    c2 = f * cr + i * g
+    h2 = o * c2
+    gh, gc = _rand(*h2.shape, seed=40), _rand(*c2.shape, seed=41)
+    (h2 * gh.double()).sum().add((c2 * gc.double()).sum()).backward()
+
+    dev = _dev()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    hg_, cg_, xgg = nhwc(h), nhwc(c), nhwc(xg)
+    whg = wh.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    spg, seg = sp.to(dev).requires_grad_(True), se.to(dev).requires_grad_(True)
+    wrg = [t.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in wr]
+    parts = []
+    for s in range(S):
+        wflat = wrg[s].permute(0, 2, 3, 1).reshape(3 * C * 9, C)
+        parts.append(F.gemm(seg[s], wflat, None, "nk").view(B, 3 * C, 9))
+    wc = torch.cat(parts + [torch.zeros(B, 3 * C, KP - 9 * S, device=dev)], 2)
+    spcol = F.im2col3x3(spg, KP)
+    hgate = F.gate_conv(hg_, whg, spcol, wc, (Hm, Wm))
+    hn, cn = F.lstm_cell(xgg, hgate, cg_)
+    (hn * nhwc(gh).detach()).sum().add((cn * nhwc(gc).detach()).sum()).backward()
+    back = lambda t: t.permute(0, 3, 1, 2)
+    _close(back(hn), h2, 3e-6, "h")
+    _close(back(cn), c2, 3e-6, "c")
+    _close(back(hg_.grad), hr.grad, 1e-5, "dh")
+    _close(back(cg_.grad), cr.grad, 1e-5, "dc")
+    _close(back(xgg.grad), xgr.grad, 1e-5, "dxg")
+    _close(whg.grad, whr.grad, 1e-5, "dwh")
+    _close(spg.grad, spr.grad, 1e-5, "dspatial")
+    _close(seg.grad, ser.grad, 1e-5, "dsemantic")
+    for s in range(S):
+        _close(wrg[s].grad, wrr[s].grad, 1e-5, f"dwr{s}")
+
+
+def test_list_attention_and_small_ops():
+    from scanpaths_amd import functional as F
+    T, R, D = 5, 6, 1200
+    Lst, u = _rand(T, R, D, seed=42), _rand(D, seed=43, scale=0.05)
+    Lr, ur = Lst.double().requires_grad_(True), u.double().requires_grad_(True)
+    sc = (Lr * ur).sum(-1)
+    memr = (Lr * sc.softmax(0).unsqueeze(-1)).sum(0)
+    gm = _rand(R, D, seed=44)
+    memr.backward(gm.double())
+    dev = _dev()
+    Lg, ug = Lst.to(dev).requires_grad_(True), u.to(dev).requires_grad_(True)
+    mem = F.list_attention(Lg, ug)
+    mem.backward(gm.to(dev))
+    _close(mem, memr, 3e-6, "mem")
+    _close(Lg.grad, Lr.grad, 1e-5, "dL")
+    _close(ug.grad, ur.grad, 1e-5, "du")
+
+    a, b = _rand(2, 3, 50, seed=45), _rand(3, 50, seed=46)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    outr = TF.relu(ar * br)
+    go = _rand(2, 3, 50, seed=47)
+    outr.backward(go.double())
+    ag, bg = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = F.mul_relu(ag, bg)
+    out.backward(go.to(dev))
+    _close(out, outr, 1e-6)
+    _close(ag.grad, ar.grad, 1e-6)
+    _close(bg.grad, br.grad, 1e-6)
+
+    x = _rand(2, 5, 7, 512, seed=48)
+    xr = x.double().requires_grad_(True)
+    mr = xr.mean(-1)
+    gmm = _rand(2, 5, 7, seed=49)
+    mr.backward(gmm.double())
+    xg = x.to(dev).requires_grad_(True)
+    m = F.channel_mean(xg)
+    m.backward(gmm.to(dev))
+    _close(m, mr, 1e-6)
+    _close(xg.grad, xr.grad, 1e-6)
+
+    a2, b2 = _rand(4, 33, seed=50), _rand(4, 33, seed=51)
+    sel = torch.tensor([True, False, False, True])
+    ag, bg = a2.to(dev).requires_grad_(True), b2.to(dev).requires_grad_(True)
+    o = F.select_rows(ag, bg, sel.to(dev))
+    o.backward(torch.ones_like(o))
+    assert torch.equal(o.cpu(), torch.where(sel[:, None], a2, b2))
+    assert torch.equal(ag.grad.cpu(), sel[:, None].float().expand_as(a2))
+    assert torch.equal(bg.grad.cpu(), (~sel)[:, None].float().expand_as(a2))
+
+
+def test_loss_and_clip_adam_vs_oracle():
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.optim import FlatAdam  # noqa: F401  (import check)
+    from scanpaths_amd.synth import make_batch
+    B, T, A = 3, 5, 1201
+    batch = make_batch("AiR", B, 240, 320, T, seed=9)
+    z, mu = _rand(B, T, A, seed=52) * 2, _rand(B, T, seed=53)
+    s2 = _rand(B, T, seed=54).abs() + 0.3
+    zr, mur, s2r = z.double().requires_grad_(True), mu.double().requires_grad_(True), s2.double().requires_grad_(True)
+    bd = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    lossr, lar, ldr = O.supervised_loss({"all_actions_prob": zr, "log_normal_mu": mur, "log_normal_sigma2": s2r}, bd)
+    (lossr * 1.7).backward()
+    dev = _dev()
+    zg, mug, s2g = (t.to(dev).requires_grad_(True) for t in (z, mu, s2))
+    loss, la, ld = F.scanpath_loss(zg, mug, s2g, batch["scanpaths"].to(dev), batch["action_masks"].to(dev),
+                                   batch["durations"].to(dev), batch["duration_masks"].to(dev), 1.0)
+    (loss * 1.7).backward()
+    _close(torch.stack([loss, la, ld]), torch.stack([lossr, lar, ldr]), 2e-6, "loss")
+    _close(zg.grad, zr.grad, 2e-6, "dz")
+    _close(mug.grad, mur.grad, 2e-6, "dmu")
+    _close(s2g.grad, s2r.grad, 2e-6, "dsigma2")
+
+
+def test_flat_adam_matches_oracle():
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.optim import FlatAdam
+    shapes = {"a.weight": (64, 32, 3, 3), "a.bias": (64,), "b.weight": (7, 5), "c.bias": (1,)}
+    params = {k: _rand(*s, seed=60 + i) for i, (k, s) in enumerate(shapes.items())}
+    grads = {k: _rand(*s, seed=70 + i) * 3 for i, (k, s) in enumerate(shapes.items())}
+    ref = {k: v.double().clone() for k, v in params.items()}
+    state = {}
+    dev = _dev()
+    plist = [torch.nn.Parameter(v.to(dev)) for v in params.values()]
+    opt = FlatAdam(plist, lr=1e-3, weight_decay=5e-5, clip=12.5)
+    for step in range(3):
+        gstep = {k: g.double() * (step + 1) for k, g in grads.items()}
+        tn_ref = O.clip_and_adam(ref, gstep, state, lr=1e-3, clip=12.5, weight_decay=5e-5)
+        for p, g in zip(plist, grads.values()):
+            p.grad = (g * (step + 1)).to(dev)
+        tn = opt.step()
+        assert abs(float(tn) - tn_ref) <= 1e-5 * tn_ref
+    for p, k in zip(plist, params):
+        _close(p, ref[k], 2e-6, k)
