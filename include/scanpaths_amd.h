@@ -160,7 +160,7 @@ int sp_select_rows_bwd(const float* dout, const unsigned char* sel, int64_t rows
  * Outputs per head: logits [nheads][B][1+P] (col 0 = terminate; probabilities when softmax != 0, i.e. eval mode :161-162),
  * amap [nheads][B][P] (relu action map, always pre-softmax), mu/sigma2 [nheads][B], drt [nheads][B][dh*dw] (post-relu). */
 int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
-                       const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
+                       int cb_per_sample /* 1: cb is [B][nheads][HC] (COCO per-task heads) */, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
                        float* sigma2, float* drt, void* stream);
 /* dlogits is the gradient w.r.t. the `logits` output (probabilities if softmax).  dZ is fully written for the nheads*HC
  * columns.  Partials are per sample: dcb [B][nheads][HC], dw2 [B][nheads][2][dh*dw], db2 [B][nheads][2]. */

@@ -34,7 +34,7 @@ struct WgradArgs {
 
 constexpr int BM = 128, BN = 128, BKP = 32, LDS_LD = 132;
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages x (A,B) x [32][132]
     constexpr int TILE = BKP * LDS_LD;
     const int t = threadIdx.x;
@@ -97,13 +97,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         }
     };
 
-    f32x16 acc[2][2];
+    // two-level accumulation (see conv_igemm.hip): fold the running chunk into `tot` every 8 K-tiles (256 pixels)
+    constexpr int CHUNK = 8;
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                tot[i][j][r] = 0.f;
+            }
 
     if (nkt > 0) {
         load_tile(0);
@@ -130,12 +135,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
+        if ((kt & (CHUNK - 1)) == CHUNK - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
         if (more) {
             float* nA = smem + ((kt + 1) & 1) * 2 * TILE;
             store_tile(nA, nA + TILE);
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
 
     float* out = p.out + (int64_t)bz * p.strideO + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
@@ -151,11 +170,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
                 if (co < p.Co) {
                     float* dst = out + (int64_t)co * p.ldo + n;
                     if (direct) {
-                        float v = p.alpha * acc[i][j][r];
+                        float v = p.alpha * tot[i][j][r];
                         if (p.beta) v += *dst;
                         *dst = v;
                     } else {
-                        *dst = acc[i][j][r];
+                        *dst = tot[i][j][r];
                     }
                 }
             }

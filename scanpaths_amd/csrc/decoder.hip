@@ -237,15 +237,15 @@ constexpr int IDX_BD = 51;
 constexpr int MAXS = 256;   // dh*dw upper bound
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, int Hm, int Wm, int ldz, int HC,
-                                                       const float* cb, const float* w2, const float* b2, int softmax,
-                                                       float* logits, float* amap, float* mu, float* sigma2, float* drt,
+                                                       const float* cb, int cb_per_sample, const float* w2,
+                                                       const float* b2, int softmax, float* logits, float* amap, float* mu, float* sigma2, float* drt,
                                                        int dh, int dw) {
     __shared__ float sh4[4];
     __shared__ float sdrt[MAXS];
     const int hd = blockIdx.y, b = blockIdx.x;
     const int P = Hm * Wm, S = dh * dw;
     const float* z = Z + (int64_t)b * P * ldz + hd * HC;
-    const float* c = cb + hd * HC;
+    const float* c = cb + (cb_per_sample ? ((int64_t)b * gridDim.y + hd) : (int64_t)hd) * HC;
     float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
     float* am = amap + ((int64_t)hd * B + b) * P;
     // terminate logit + action map
@@ -478,12 +478,13 @@ extern "C" int sp_select_rows_bwd(const float* dout, const unsigned char* sel, i
 }
 
 extern "C" int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
-                                  const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
+                                  int cb_per_sample, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
                                   float* sigma2, float* drt, void* stream) {
     if (!Z || !cb || !w2 || !b2 || !logits || !amap || !mu || !sigma2 || !drt) return SP_ENULL;
     const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
     if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1) return SP_EINVAL;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, Z, B, Hm, Wm, ldz, HC, cb, w2, b2,
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, Z, B, Hm, Wm, ldz, HC, cb,
+                       cb_per_sample, w2, b2,
                        softmax, logits, amap, mu, sigma2, drt, dh, dw);
     SP_LAUNCH_CHECK();
     return SP_OK;

@@ -56,10 +56,46 @@ def _colsum_any(x: torch.Tensor, C_: int) -> torch.Tensor:
     return colsum(xp, Cp, Cp, M)[:C_]
 
 
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def _add_raw(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a, b = a.contiguous(), b.contiguous()
     out = torch.empty_like(a)
     check(hip.lib().sp_add(ptr(a), ptr(b), ptr(out), a.numel(), hip.stream()), "sp_add")
     return out
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _add_raw(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class _ZeroGradTouch(Function):
+    """Identity on ``t`` that makes ``params`` part of the graph with an exactly-zero gradient.
+    Used for parameters whose contribution cancels analytically (the attention "cur" branches and biases,
+    baseline_attention.py:82-86,117-121): the reference gives them a ~1e-17 gradient, hence weight decay and an
+    Adam step; a zero gradient (instead of None) reproduces that with any optimizer."""
+    @staticmethod
+    def forward(ctx, t, *params):
+        ctx.shapes = [(p.shape, p.stride(), p.device) for p in params]
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        zeros = tuple(torch.zeros(sh, dtype=torch.float32, device=dev) for sh, _, dev in ctx.shapes)
+        return (g,) + zeros
+
+
+def touch_zero_grad(t, params):
+    return _ZeroGradTouch.apply(t, *params)
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a + b (same shape) as a differentiable HIP op."""
+    return _Add.apply(a, b)
 
 
 def _phys(w: torch.Tensor) -> torch.Tensor:
@@ -513,7 +549,7 @@ class _MulRelu(Function):
         parts = dbp.view(S, -1)
         db = parts[0]
         for s in range(1, S):
-            db = add(db, parts[s])
+            db = _add_raw(db, parts[s])
         return da, db.view(b.shape)
 
 
@@ -578,7 +614,7 @@ def select_rows(a, b, sel):
 class _HeadFinish(Function):
     """Z [B,Hm,Wm,nh*HC] -> logits [nh,B,1+P], amap [nh,B,P], mu [nh,B], sigma2 [nh,B]"""
     @staticmethod
-    def forward(ctx, Z, cb, w2, b2, nheads, HC, softmax):
+    def forward(ctx, Z, cb, w2, b2, nheads, HC, softmax, per_sample):
         Z = Z.contiguous()
         cb = cb.contiguous()
         w2c = w2.detach().contiguous()
@@ -592,16 +628,17 @@ class _HeadFinish(Function):
         mu = torch.empty((nheads, B), dtype=torch.float32, device=dev)
         s2 = torch.empty((nheads, B), dtype=torch.float32, device=dev)
         drt = torch.empty((nheads, B, dh * dw), dtype=torch.float32, device=dev)
-        check(hip.lib().sp_head_finish_fwd(ptr(Z), B, Hm, Wm, ldz, nheads, HC, ptr(cb), ptr(w2c), ptr(b2), int(softmax),
+        check(hip.lib().sp_head_finish_fwd(ptr(Z), B, Hm, Wm, ldz, nheads, HC, ptr(cb), int(per_sample), ptr(w2c), ptr(b2),
+                                           int(softmax),
                                            ptr(logits), ptr(amap), ptr(mu), ptr(s2), ptr(drt), hip.stream()),
               "sp_head_finish_fwd")
-        ctx.cfg = (B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, tuple(w2.shape))
+        ctx.cfg = (B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, tuple(w2.shape), per_sample, tuple(cb.shape))
         ctx.save_for_backward(logits, amap, s2, drt, w2c)
         return logits, amap, mu, s2
 
     @staticmethod
     def backward(ctx, dlogits, damap, dmu, ds2):
-        B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, w2shape = ctx.cfg
+        B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, w2shape, per_sample, cbshape = ctx.cfg
         logits, amap, s2, drt, w2c = ctx.saved_tensors
         dev = logits.device
         zf = lambda t, ref: (t.contiguous() if t is not None else torch.zeros_like(ref))
@@ -619,18 +656,18 @@ class _HeadFinish(Function):
         check(hip.lib().sp_head_finish_bwd(ptr(dlogits), ptr(damap), ptr(dmu), ptr(ds2), ptr(logits), ptr(amap), ptr(s2),
                                            ptr(drt), B, Hm, Wm, ldz, nheads, HC, ptr(w2c), int(softmax), ptr(dZ), ptr(dcbp),
                                            ptr(dw2p), ptr(db2p), hip.stream()), "sp_head_finish_bwd")
-        dcb = _colsum_any(dcbp, nheads * HC).view(nheads, HC)
+        dcb = dcbp.view(cbshape) if per_sample else _colsum_any(dcbp, nheads * HC).view(nheads, HC)
         dw2 = _colsum_any(dw2p, nheads * 2 * S).view(nheads, 2 * S)
         db2 = _colsum_any(db2p, nheads * 2).view(nheads, 2)
         dw2s, db2s = dw2[0], db2[0]
         for k in range(1, nheads):          # drt_layer_2 is shared by the heads
-            dw2s = add(dw2s.contiguous(), dw2[k].contiguous())
-            db2s = add(db2s.contiguous(), db2[k].contiguous())
-        return dZ, dcb, dw2s.reshape(w2shape), db2s.reshape(2), None, None, None
+            dw2s = _add_raw(dw2s, dw2[k])
+            db2s = _add_raw(db2s, db2[k])
+        return dZ, dcb, dw2s.reshape(w2shape), db2s.reshape(2), None, None, None, None
 
 
-def head_finish(Z, cb, w2, b2, nheads, HC, softmax):
-    return _HeadFinish.apply(Z, cb, w2, b2, nheads, HC, softmax)
+def head_finish(Z, cb, w2, b2, nheads, HC, softmax, per_sample=False):
+    return _HeadFinish.apply(Z, cb, w2, b2, nheads, HC, softmax, per_sample)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -46,8 +46,9 @@ class _Conv(nn.Module):
         super().__init__()
         kw = kh if kw is None else kw
         self.weight = nn.Parameter(torch.empty(cout, cin, kh, kw).contiguous(memory_format=torch.channels_last))
-        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
-        if not bias:
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+        else:
             self.register_parameter("bias", None)
 
 
@@ -268,6 +269,11 @@ class ScanpathModel(nn.Module):
         wl = torch.cat([pa.spatial_lists.weight.reshape(9).flip(0), torch.zeros(3, device=dev)]).view(1, 12)
         wl4 = torch.cat([wl, torch.zeros(3, 12, device=dev)], 0)
         u_spa = F.gemm(acol, wl4, None, "nk")[:, 0].contiguous()
+        # parameters that cancel along the softmax axis: exact zero gradient, but still decayed / stepped like the reference
+        u_sem = F.touch_zero_grad(u_sem, [sa.semantic_lists.bias, sa.semantic_cur.weight, sa.semantic_cur.bias,
+                                          sa.semantic_attention.bias])
+        u_spa = F.touch_zero_grad(u_spa, [pa.spatial_lists.bias, pa.spatial_cur.weight, pa.spatial_cur.bias,
+                                          pa.spatial_attention.bias])
         return u_sem, u_spa
 
     # ------------------------------------------------------------------------------------------------
@@ -306,9 +312,14 @@ class ScanpathModel(nn.Module):
         if head_convs is not None:
             G, cb = self._compose_heads(head_convs)
         else:
-            uniq = torch.unique(tasks).tolist()
-            Gt, cbt = self._compose_heads([self.object_sal_layer[self.int2object[int(t)]] for t in uniq])
-            sample_slot = torch.tensor([uniq.index(int(t)) for t in tasks.tolist()], device=dev)
+            tl = [int(t) for t in tasks.tolist()]            # host sync, as the reference's int(tasks[index])
+            uniq = sorted(set(tl))
+            Gt, cbt = self._compose_heads([self.object_sal_layer[self.int2object[t]] for t in uniq])
+            slot = torch.tensor([uniq.index(t) for t in tl], device=dev)
+            order = torch.argsort(slot, stable=True)
+            inv_order = torch.argsort(order)
+            groups = [(k, torch.nonzero(slot == k).flatten()) for k in range(len(uniq))]
+            cb_samples = cbt.index_select(0, slot).view(B, 1, HC)
         w2, b2 = self.object_head.drt_layer_2.weight, self.object_head.drt_layer_2.bias
         sp_list: List[torch.Tensor] = []
         se_list: List[torch.Tensor] = []
@@ -337,17 +348,11 @@ class ScanpathModel(nn.Module):
             h, c = F.lstm_cell(Xg, hg, c)
             if head_convs is not None:
                 Z = F.conv2d(h, G, None, pad=2)
-                cbs = cb
-            else:      # COCO: per-sample head conv selected by task id (...multihead.py:285-288)
-                Zs = [F.conv2d(h, Gt[k * HC:(k + 1) * HC], None, pad=2) for k in range(len(uniq))]
-                Z = Zs[0]
-                for k in range(1, len(uniq)):
-                    Z = F.select_rows(Zs[k], Z, sample_slot == k)
-                cbs = None
-            if cbs is not None:
-                logits, amap, mu, s2 = F.head_finish(Z, cbs, w2, b2, nh, HC, not self.training)
-            else:
-                raise NotImplementedError
+                logits, amap, mu, s2 = F.head_finish(Z, cb, w2, b2, nh, HC, not self.training)
+            else:      # COCO: per-sample head conv selected by task id (...multihead.py:285-288), grouped by task
+                Zp = [F.conv2d(h.index_select(0, idx), Gt[k * HC:(k + 1) * HC], None, pad=2) for k, idx in groups]
+                Z = torch.cat(Zp, 0).index_select(0, inv_order)
+                logits, amap, mu, s2 = F.head_finish(Z, cb_samples, w2, b2, nh, HC, not self.training, per_sample=True)
             outs["logits"].append(logits)
             outs["amap"].append(amap)
             outs["mu"].append(mu)

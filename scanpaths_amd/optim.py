@@ -45,7 +45,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._t = 0
+        self._steps = [0] * len(params)          # per-parameter Adam step (torch.optim.Adam keeps it per parameter)
+        self._touched = [False] * len(params)    # did this backward produce a gradient for the parameter?
         self.process_group = process_group
         with torch.no_grad():
             for p, o in zip(params, offs):
@@ -57,6 +58,8 @@ class FlatAdam(torch.optim.Optimizer):
                 self.state[p] = {"step": torch.zeros((), dtype=torch.float32),
                                  "exp_avg": torch.as_strided(self.flat_m, p.shape, st, o),
                                  "exp_avg_sq": torch.as_strided(self.flat_v, p.shape, st, o)}
+        for i, p in enumerate(params):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touched.__setitem__(i, True))
 
     @staticmethod
     def _dense_strides(p):
@@ -67,19 +70,22 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):   # noqa: D401  (views must survive)
         self.flat_g.zero_()
+        self._touched = [False] * len(self._params)
         for p, o in zip(self._params, self._offs):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = torch.as_strided(self.flat_g, p.shape, self._dense_strides(p), o)
 
     def _gather_foreign_grads(self):
         """If a caller replaced p.grad (e.g. the reference's optimizer.zero_grad(set_to_none=True)), copy it back."""
-        for p, o in zip(self._params, self._offs):
+        for i, (p, o) in enumerate(zip(self._params, self._offs)):
             g = p.grad
             view = torch.as_strided(self.flat_g, p.shape, self._dense_strides(p), o)
             if g is None:
                 view.zero_()
+                self._touched[i] = False
             elif g.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 view.copy_(g)
+                self._touched[i] = True
             p.grad = view
 
     @torch.no_grad()
@@ -94,14 +100,29 @@ class FlatAdam(torch.optim.Optimizer):
         L = hip.lib()
         ws = hip.workspace(L.sp_sumsq_workspace(self.numel), self.flat_g.device, slot=1)
         check(L.sp_sumsq(ptr(self.flat_g), self.numel, ptr(self._sumsq), ptr(ws), hip.stream()), "sp_sumsq")
-        self._t += 1
         b1, b2 = g["betas"]
-        check(L.sp_clip_adam(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), self.numel,
-                             ptr(self._sumsq), 1.0 / world, float(g["clip"]), float(g["lr"]), b1, b2, float(g["eps"]),
-                             float(g["weight_decay"]), 1.0 - b1 ** self._t, 1.0 - b2 ** self._t, hip.stream()),
-              "sp_clip_adam")
-        for p in self._params:
-            self.state[p]["step"] += 1
+        # torch.optim.Adam skips parameters whose .grad is None (no decay, no moment update, no step increment), e.g.
+        # the COCO per-category heads of categories absent from the batch: run the fused kernel per maximal run of
+        # consecutive touched parameters that share a step count (one launch for AiR / OSIE).
+        n = len(self._params)
+        i = 0
+        while i < n:
+            if not self._touched[i]:
+                i += 1
+                continue
+            j, t = i, self._steps[i] + 1
+            while j + 1 < n and self._touched[j + 1] and self._steps[j + 1] + 1 == t:
+                j += 1
+            lo = self._offs[i]
+            hi = self._offs[j + 1] if j + 1 < n else self.numel
+            check(L.sp_clip_adam(ptr(self.flat_p) + 4 * lo, ptr(self.flat_g) + 4 * lo, ptr(self.flat_m) + 4 * lo,
+                                 ptr(self.flat_v) + 4 * lo, hi - lo, ptr(self._sumsq), 1.0 / world, float(g["clip"]),
+                                 float(g["lr"]), b1, b2, float(g["eps"]), float(g["weight_decay"]), 1.0 - b1 ** t,
+                                 1.0 - b2 ** t, hip.stream()), "sp_clip_adam")
+            for k in range(i, j + 1):
+                self._steps[k] = t
+                self.state[self._params[k]]["step"] += 1
+            i = j + 1
         return self._sumsq.sqrt() / world      # total gradient norm before clipping (device scalar, no sync)
 
     def load_state_dict(self, state_dict):
@@ -113,7 +134,7 @@ class FlatAdam(torch.optim.Optimizer):
                     self.state[p]["exp_avg"].copy_(st["exp_avg"])
                     self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
                     self.state[p]["step"].fill_(float(st["step"]))
-                    self._t = int(float(st["step"]))
+                    self._steps[i] = int(float(st["step"]))
         for k, v in state_dict["param_groups"][0].items():
             if k != "params":
                 self.param_groups[0][k] = v

@@ -29,6 +29,8 @@ def case_inputs(meta, dtype=torch.float64):
 
 
 def max_err(a, b):
-    a = torch.as_tensor(a, dtype=torch.float64)
-    b = torch.as_tensor(b, dtype=torch.float64)
+    if a is None:
+        a = torch.zeros_like(torch.as_tensor(b))
+    a = torch.as_tensor(a).detach().cpu().to(torch.float64)
+    b = torch.as_tensor(b).detach().cpu().to(torch.float64)
     return (a - b).abs().max().item()

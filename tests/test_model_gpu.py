@@ -1,0 +1,211 @@
+"""Model-level parity of the HIP path (through the C ABI) on a real MI355X.
+
+  * against the committed golden outputs of the REAL reference (tests/golden, fp64 run) -- forward (eval and train
+    mode), loss, gradients, one clip+Adam step, BN running statistics, for AiR / OSIE(ResNet-18 and -50) / COCO;
+  * against the oracle (oracle/scanpath_oracle.py, fp64 on the host CPU) at 320x512, the size BASELINE.json names and
+    the reference itself cannot run (map size hard-coded).
+
+Tolerance (north_star: 1e-4 fp32 on logits, bit-exact argmax): the reference's OWN fp32 run differs from its fp64
+run by the "noise floor" stored beside each golden (up to 8e-4 on train-mode logits, SURVEY.md §7 hard part 2), so
+the bar is, per decode step,   err(hip32, ref64) <= max(1e-4 * scale, 10 * err(ref32, ref64))
+(the recurrence amplifies rounding noise: with random weights the reference's fp32 run drifts from its fp64 run by
+O(1) after ~10 eval-mode steps, so only the early steps carry a tight bar -- that is the reference's property).
+Argmax must match wherever the fp64 top-2 margin exceeds that error bar."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_inputs, load_golden, max_err, oracle_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(meta, Hm=30, Wm=40):
+    from scanpaths_amd.models.scanpath_model import ScanpathModel
+    from scanpaths_amd.procedural import fill_module
+    m = ScanpathModel(meta["task"], convLSTM_length=meta["T"], map_width=Wm, map_height=Hm, arch=meta["arch"])
+    fill_module(m, seed=meta["weight_seed"])
+    return m.to(DEV)
+
+
+def _call(model, meta, b):
+    img = b["images"].to(DEV)
+    if meta["task"] == "AiR":
+        return model(img, b["attention_maps"].to(DEV), b["performances"].to(DEV) if model.training else None)
+    if meta["task"] == "OSIE":
+        return model(img)
+    return model(img, b["attention_maps"].to(DEV), b["tasks"].to(DEV))
+
+
+def _check(name, key, got, g, report, T=None):
+    """err(hip, ref64) <= max(1e-4*scale, 10 * running-max of the reference's own fp32-vs-fp64 error), per decode step.
+    Returns {step: bar} for the steps that were compared."""
+    ref = torch.as_tensor(g["ref64/" + key])
+    r32 = torch.as_tensor(g["ref32/" + key])
+    got = got.detach().cpu().double()
+    is_prob = key.endswith("all_actions_prob") and float(ref.max()) <= 1.0 and float(ref.min()) >= 0.0 \
+        and abs(float(ref[0, 0].sum()) - 1.0) < 1e-6
+    scale = float(ref.abs().max()) if is_prob else max(1.0, float(ref.abs().max()))
+    steps = range(ref.shape[1]) if (T is not None and ref.dim() >= 2 and ref.shape[1] == T) else [None]
+    floor_run, bars = 0.0, {}
+    for t in steps:
+        sl = (slice(None), t) if t is not None else (Ellipsis,)
+        floor_run = max(floor_run, max_err(r32[sl], ref[sl]))
+        if floor_run > 1e-2 * scale:
+            # the reference's own fp32 run is no longer within 1% of its fp64 run here (chaotic recurrence with random
+            # weights): later steps carry no information about correctness
+            report.append(f"{name}:{key}[t={t}]: reference fp32 noise {floor_run:.2e} > 1% of scale -- later steps not compared")
+            break
+        err = max_err(got[sl], ref[sl])
+        bar = max(1e-4 * scale, 10 * floor_run)
+        line = f"{name}:{key}[t={t}]: hip-ref64 {err:.2e}  ref32-ref64(run max) {floor_run:.2e}  scale {scale:.2e}  bar {bar:.2e}"
+        report.append(line)
+        assert err <= bar, line
+        bars[t] = bar
+    return bars
+
+
+def _check_argmax(got, ref, bars):
+    """bit-exact argmax fixation index wherever the fp64 top-2 margin exceeds twice that step's error bar"""
+    ref = torch.as_tensor(ref)
+    n = tot = 0
+    for t, bar in bars.items():
+        r, gt = ref[:, t], got[:, t].cpu()
+        top2 = r.topk(2, -1).values
+        decisive = (top2[..., 0] - top2[..., 1]) > 2 * bar
+        assert torch.equal(gt.argmax(-1)[decisive], r.argmax(-1)[decisive]), t
+        n += int(decisive.sum())
+        tot += decisive.numel()
+    return n, tot
+
+
+@pytest.mark.parametrize("name", ["air_eval_T4", "air_eval_T16", "osie_r18_eval_T8", "osie_eval_T4", "coco_eval_T6"])
+def test_eval_forward_matches_reference(name):
+    meta, g = load_golden(name)
+    b = case_inputs(meta, torch.float32)
+    model = _build(meta).eval()
+    with torch.no_grad():
+        pred = _call(model, meta, b)
+    report = []
+    for k, v in pred.items():
+        bars = _check(name, k, v, g, report, meta["T"])
+        if k.endswith("all_actions_prob"):
+            n, tot = _check_argmax(v, g["ref64/" + k], bars)
+            report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
+    print("\n".join(report))
+
+
+@pytest.mark.parametrize("name", ["air_train_T4", "osie_r18_train_T8", "coco_train_T6"])
+def test_train_step_matches_reference(name):
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.optim import FlatAdam
+    meta, g = load_golden(name)
+    b = case_inputs(meta, torch.float32)
+    model = _build(meta).train()
+    wd = 5e-5 if meta["task"] == "AiR" else 5e-4
+    opt = FlatAdam(model.parameters(), lr=1e-4, weight_decay=wd, clip=12.5)
+    opt.zero_grad()
+    pred = _call(model, meta, b)
+    report = []
+    for k, v in pred.items():
+        bars = _check(name, k, v, g, report, meta["T"])
+        if k in ("all_actions_prob", "actions"):
+            n, tot = _check_argmax(v, g["ref64/" + k], bars)
+            report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
+    p0 = {k: v.detach().cpu().double().clone() for k, v in model.named_parameters()}
+    loss, la, ld = supervised_loss(pred, b["scanpaths"].to(DEV), b["durations"].to(DEV), b["action_masks"].to(DEV),
+                                   b["duration_masks"].to(DEV), 1.0)
+    got = np.array([loss.item(), la.item(), ld.item()])
+    floor = np.abs(g["ref32/loss"] - g["ref64/loss"]).max()
+    assert np.abs(got - g["ref64/loss"]).max() <= max(1e-4, 10 * floor), (got, g["ref64/loss"])
+    loss.backward()
+    names = meta["param_names"]
+    params = dict(model.named_parameters())
+    gn = np.array([params[k].grad.norm().item() for k in names])
+    gref, g32 = g["ref64/grad_norms"], g["ref32/grad_norms"]
+    # gradient norms: relative to the largest norm; "cur"-branch params are exactly 0 here and ~1e-9 in the reference
+    tot = np.sqrt((gref ** 2).sum())
+    nfloor = np.abs(g32 - gref).max()
+    nerr = np.abs(gn - gref).max()
+    report.append(f"{name}: grad-norm err {nerr:.2e} (ref32 floor {nfloor:.2e}, total norm {tot:.2f})")
+    assert nerr <= max(1e-4 * tot, 10 * nfloor), report[-1]
+    for k in g:
+        if k.startswith("ref64/grad/") or k.startswith("ref64/gradsample/"):
+            full = k.startswith("ref64/grad/")
+            pname = k.split("/", 2)[2]
+            gg = params[pname].grad
+            if gg is None:
+                gg = torch.zeros_like(params[pname])
+            if not full:
+                gg = gg.flatten()[::max(1, gg.numel() // 512)][:512]
+            ref = g[k]
+            f32 = max_err(g[k.replace("ref64", "ref32")], ref)
+            e = max_err(gg, ref)
+            assert e <= max(1e-4 * max(1.0, float(np.abs(ref).max())), 10 * f32, 1e-5 * tot), (pname, e, f32)
+    tn = opt.step()
+    checked_after = total_after = 0
+    assert abs(float(tn) - g["ref64/total_norm"][0]) <= max(1e-4 * tot, 10 * abs(g["ref32/total_norm"][0] - g["ref64/total_norm"][0]))
+    for k in g:
+        if k.startswith("ref64/after/"):
+            # First Adam step moves every element by ~lr*sign(g): where the reference's own fp32 gradient noise can flip
+            # the sign (|g| small) the update is noise in the reference too -> compare where the gradient is decisive.
+            pname = k[len("ref64/after/"):]
+            if ("ref64/grad/" + pname) not in g:      # parameter unused in this batch (COCO heads of absent tasks)
+                assert max_err(params[pname], g[k]) <= 1e-7, pname
+                continue
+            g64, g32_ = torch.as_tensor(g["ref64/grad/" + pname]), torch.as_tensor(g["ref32/grad/" + pname])
+            coef = min(1.0, 12.5 / (float(g["ref64/total_norm"][0]) + 1e-6))
+            geff = g64 * coef + wd * p0[pname]                    # clip, then L2 folded into the gradient
+            noise = float((g32_ - g64).abs().max()) * coef
+            decisive = geff.abs() > 30 * noise + 1e-10
+            expect = p0[pname] - 1e-4 * geff / (geff.abs() + 1e-8)   # first Adam step: m_hat = g, v_hat = g^2
+            ref_p = torch.as_tensor(g[k])
+            got_p = params[pname].detach().cpu().double()
+            if decisive.any():
+                assert (expect - ref_p).abs()[decisive].max().item() <= 1e-9, ("golden self-check", pname)
+                assert (got_p - ref_p).abs()[decisive].max().item() <= 5e-6, pname
+            checked_after += int(decisive.sum())
+            total_after += decisive.numel()
+        if k.startswith("ref64/bn/"):
+            bname = k[len("ref64/bn/"):]
+            f32 = max_err(g["ref32/bn/" + bname], g[k])
+            assert max_err(model.state_dict()[bname], g[k]) <= max(1e-5, 10 * f32), bname
+    assert checked_after > 0.05 * total_after, (checked_after, total_after)
+    report.append(f"{name}: post-Adam parameters equal (5e-6) on {checked_after}/{total_after} gradient-decisive elements")
+    print("\n".join(report))
+
+
+def test_air_320x512_matches_oracle():
+    """BASELINE.json's image size; reference cannot run it -> HIP vs the (golden-pinned) fp64 oracle."""
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.synth import make_batch
+    meta = dict(task="AiR", arch="resnet50", T=2, weight_seed=11)
+    Hm, Wm = 40, 64
+    b = make_batch("AiR", 1, 320, 512, 2, seed=11)
+    sd = oracle_state("AiR", "resnet50", 11, Hm, Wm)
+    with torch.no_grad():
+        ref = O.forward(sd, "AiR", b["images"].double(), b["attention_maps"].double(), training=False, T=2)
+        sd32 = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+        ref32 = O.forward(sd32, "AiR", b["images"], b["attention_maps"], training=False, T=2)
+    model = _build(meta, Hm, Wm).eval()
+    with torch.no_grad():
+        pred = model(b["images"].to(DEV), b["attention_maps"].to(DEV))
+    for k, v in pred.items():
+        scale = max(1.0, ref[k].abs().max().item())
+        floor = max_err(ref32[k], ref[k])
+        err = max_err(v, ref[k])
+        print(f"320x512:{k}: hip-oracle64 {err:.2e}  oracle32-oracle64 {floor:.2e}  scale {scale:.2f}")
+        assert err <= max(1e-4 * scale, 10 * floor), k
+
+
+def test_state_dict_roundtrip_and_no_cpu_path():
+    from scanpaths_amd.models.baseline_attention import baseline
+    m = baseline(convLSTM_length=2)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 240, 320), torch.zeros(1, 1, 30, 40), torch.ones(1, dtype=torch.bool))
+    sd = m.state_dict()
+    m2 = baseline(convLSTM_length=2).to(DEV)
+    m2.load_state_dict(sd)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k])
