@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- AiR supervised train step (fwd + loss + bwd + clip + Adam [+ RCCL grad all-reduce]) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: AiR, ResNet-50 encoder, 16-step decode, bs=32 per GPU, synthetic 320x512 images
+(attention map 40x64 instead of the reference's hard-coded 30x40; "14-token questions" reach the model only as the
+attention map).  A "step" is one pass of the hot path over one synthetic batch already resident in HBM.
+Weak scaling: every rank processes its own bs=32 shard; the only exchange is the gradient all-reduce of ONE flat
+buffer inside FlatAdam.step().  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--T", type=int, default=16)
+    ap.add_argument("--arch", type=str, default="resnet50")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (literal CPU restatement of the reference, kind "port") timed on the host cores on a bounded sample:
+    one image, T in {1, 2} decode steps, full train step (fwd + loss + bwd + clip + Adam); the cost is affine in T
+    (encoder + T identical decoder steps), so it is extrapolated to T=16."""
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.procedural import procedural_state_dict
+    from scanpaths_amd.spec import model_spec, is_buffer
+    from scanpaths_amd.synth import make_batch
+    cores = args.cpu_threads or os.cpu_count()
+    torch.set_num_threads(cores)
+    Hm, Wm = args.height // 8, args.width // 8
+    sd = procedural_state_dict(model_spec("AiR", args.arch, Hm, Wm), seed=0)
+    times = {}
+    for T in (1, 2):
+        batch = make_batch("AiR", 1, args.height, args.width, T, seed=0)
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not is_buffer(k)}
+        full = dict(sd)
+        full.update(params)
+        t0 = time.perf_counter()
+        pred = O.forward(full, "AiR", batch["images"], batch["attention_maps"], batch["performances"], training=True, T=T,
+                         arch=args.arch)
+        loss, _, _ = O.supervised_loss(pred, batch)
+        loss.backward()
+        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+        with torch.no_grad():
+            O.clip_and_adam({k: p.data for k, p in params.items()}, grads, {}, lr=1e-4, clip=12.5, weight_decay=5e-5)
+        times[T] = time.perf_counter() - t0
+    per_step = max(times[2] - times[1], 1e-9)
+    t16 = times[1] + (args.T - 1) * per_step
+    return {"value": 1.0 / t16, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle train step, 1 image {args.height}x{args.width}, T=1 ({times[1]:.1f}s) and T=2 ({times[2]:.1f}s), "
+                      f"extrapolated affinely to T={args.T} ({t16:.1f}s/img)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from scanpaths_amd import hip
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+
+    Hm, Wm = args.height // 8, args.width // 8
+    model = baseline(convLSTM_length=args.T, map_width=Wm, map_height=Hm, arch=args.arch)
+    fill_module(model, seed=0)                     # identical replicas on every rank
+    model = model.to(dev).train()
+    opt = FlatAdam(model.parameters(), lr=1e-4, weight_decay=5e-5, clip=12.5)
+    b = {k: v.to(dev) for k, v in make_batch("AiR", args.batch, args.height, args.width, args.T, seed=0, rank=rank).items()}
+
+    def step():
+        opt.zero_grad()
+        pred = model(b["images"], b["attention_maps"], b["performances"])
+        mask_sums = None
+        if world > 1:   # loss normalised by the GLOBAL mask sums, as DataParallel's gathered loss (AiR/train.py:190-197)
+            from scanpaths_amd import functional as F
+            mask_sums = torch.cat([F.device_sum(b["action_masks"]), F.device_sum(b["duration_masks"])])
+            torch.distributed.all_reduce(mask_sums)
+            mask_sums = mask_sums / world       # grads are averaged over ranks in FlatAdam -> keep the global normaliser
+        loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0,
+                                     mask_sums)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    hip.TIMER = hip.KernelTimer(min_flops=2e11 * args.batch / 32)    # bracket only the dominant GEMM launches with HIP events
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    timer, hip.TIMER = hip.TIMER, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+    summ = timer.summary()
+    # dominant kernel = the per-step h-gate conv: implicit GEMM  M = B*P, N = 2048, K = 9*512 (forward flavour)
+    P = Hm * Wm
+    dom_key = ("igemm_fwd", args.batch * P, 2048, 9 * 512, "3x3", 1)
+    dom = summ.get(dom_key) or max(summ.values(), key=lambda d: d["ms"])
+    total_timed_ms = sum(d["ms"] for d in summ.values()) / args.steps
+    roofline = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "igemm_kernel<128,128,2,2,fwd> h-gate conv3x3 512->2048",
+                "flops_per_launch": dom["flops_per_launch"], "avg_launch_ms": round(dom["avg_ms"], 4),
+                "launches_timed": dom["launches"],
+                "all_big_gemms_ms_per_step": round(total_timed_ms, 2),
+                "all_big_gemms_tflops": round(sum(d["flops_per_launch"] * d["launches"] for d in summ.values())
+                                              / max(sum(d["ms"] for d in summ.values()), 1e-9) / 1e9, 2)}
+    out = {"metric": "images/sec/GPU (AiR train step, bs=32, 320x512) at 1/2/4/8 MI355X", "value": round(value, 3),
+           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "value_per_gpu": round(value / world, 3),
+           "config": {"workload": f"AiR supervised train step (fwd+loss+bwd+clip+Adam), {args.arch}, T={args.T}, "
+                                  f"{args.height}x{args.width}, per-GPU batch {args.batch}",
+                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss), 5)},
+           "roofline": roofline}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

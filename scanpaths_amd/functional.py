@@ -25,7 +25,14 @@ def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, K
            mode=0, alpha=1.0, beta=0, relu=0, nbatch=1, sX=0, sW=0, sC=0):
     d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
                  int(relu), nbatch, sX, sW, sC)
-    check(hip.lib().sp_conv_igemm(C.byref(d), ptr(X), ptr(W), ptr(bias), ptr(out), hip.stream()), "sp_conv_igemm")
+    def launch():
+        check(hip.lib().sp_conv_igemm(C.byref(d), ptr(X), ptr(W), ptr(bias), ptr(out), hip.stream()), "sp_conv_igemm")
+    if hip.TIMER is None:
+        return launch()
+    M = N_img * Ho * Wo
+    K = KH * KW * Kc
+    key = ("igemm_fwd" if mode == 0 else "igemm_dgrad", M, Nout, K, f"{KH}x{KW}", nbatch)
+    hip.TIMER.bracket(key, 2.0 * M * Nout * K * nbatch, launch)
 
 
 def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0,
@@ -34,7 +41,13 @@ def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=
                   sX, sY, sO)
     L = hip.lib()
     ws = hip.workspace(L.sp_conv_wgrad_workspace(C.byref(d)), X.device, slot=0)
-    check(L.sp_conv_wgrad(C.byref(d), ptr(X), ptr(dY), ptr(dW), ptr(ws), hip.stream()), "sp_conv_wgrad")
+    def launch():
+        check(L.sp_conv_wgrad(C.byref(d), ptr(X), ptr(dY), ptr(dW), ptr(ws), hip.stream()), "sp_conv_wgrad")
+    if hip.TIMER is None:
+        return launch()
+    M = N_img * Ho * Wo
+    key = ("wgrad", M, Co, KH * KW * Ci, f"{KH}x{KW}", nbatch)
+    hip.TIMER.bracket(key, 2.0 * M * Co * KH * KW * Ci * nbatch, launch)
 
 
 def colsum(x2d: torch.Tensor, C_: int, ld: int, M: int) -> torch.Tensor:

@@ -134,3 +134,38 @@ def workspace(nbytes: int, device, slot: int = 0) -> Optional[torch.Tensor]:
         cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = cur
     return cur
+
+
+class KernelTimer:
+    """HIP-event timing of individual GEMM launches on the launch stream (bench.py roofline leg).
+    Only launches with at least ``min_flops`` algorithmic FLOPs are bracketed, so the timed region is not perturbed
+    by ~2000 extra event records per step."""
+
+    def __init__(self, min_flops: float = 1e11):
+        self.min_flops = min_flops
+        self.pending = []          # (key, flops, start_event, end_event)
+
+    def bracket(self, key, flops, launch):
+        if flops < self.min_flops:
+            return launch()
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.pending.append((key, flops, s, e))
+
+    def summary(self):
+        """key -> dict(launches, flops_per_launch, avg_ms, tflops); call after a device synchronise."""
+        out = {}
+        for key, flops, s, e in self.pending:
+            d = out.setdefault(key, {"launches": 0, "flops_per_launch": flops, "ms": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+        for d in out.values():
+            d["avg_ms"] = d["ms"] / d["launches"]
+            d["tflops"] = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
