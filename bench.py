@@ -104,9 +104,9 @@ def main():
         mask_sums = None
         if world > 1:   # loss normalised by the GLOBAL mask sums, as DataParallel's gathered loss (AiR/train.py:190-197)
             from scanpaths_amd import functional as F
-            mask_sums = torch.cat([F.device_sum(b["action_masks"]), F.device_sum(b["duration_masks"])])
-            torch.distributed.all_reduce(mask_sums)
-            mask_sums = mask_sums / world       # grads are averaged over ranks in FlatAdam -> keep the global normaliser
+            from scanpaths_amd.ddp import global_mask_normaliser
+            mask_sums = global_mask_normaliser(torch.cat([F.device_sum(b["action_masks"]),
+                                                          F.device_sum(b["duration_masks"])]))
         loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0,
                                      mask_sums)
         loss.backward()
@@ -162,7 +162,7 @@ def main():
            "value_per_gpu": round(value / world, 3),
            "config": {"workload": f"AiR supervised train step (fwd+loss+bwd+clip+Adam), {args.arch}, T={args.T}, "
                                   f"{args.height}x{args.width}, per-GPU batch {args.batch}",
-                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss), 5)},
+                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 5)},
            "roofline": roofline}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

@@ -265,12 +265,14 @@ def clip_and_adam(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor
                   betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-5) -> float:
     """clip_grad_norm_(12.5) then torch.optim.Adam (L2 folded into the gradient; not AdamW).
     AiR/train.py:116-117,200-202; opts.py:15,25.  In-place on ``params``; returns the total norm."""
-    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values() if g is not None)).item()
     scale = min(1.0, clip / (total + 1e-6)) if clip > 0 else 1.0
     state["step"] = state.get("step", 0) + 1
     t = state["step"]
     b1, b2 = betas
     for k, p in params.items():
+        if grads.get(k) is None:        # torch.optim.Adam skips parameters without a gradient (unused COCO heads)
+            continue
         g = grads[k] * scale + weight_decay * p
         m = state.setdefault("m." + k, torch.zeros_like(p))
         v = state.setdefault("v." + k, torch.zeros_like(p))

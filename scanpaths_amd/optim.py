@@ -93,10 +93,9 @@ class FlatAdam(torch.optim.Optimizer):
         self._gather_foreign_grads()
         g = self.param_groups[0]
         world = 1
-        if self.process_group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(self.process_group)
-            if world > 1:   # RCCL sum over xGMI of ONE flat buffer; averaged inside the Adam kernel (gscale)
-                torch.distributed.all_reduce(self.flat_g, group=self.process_group)
+        if self.process_group is not False:   # RCCL sum over xGMI of ONE flat buffer; averaged inside the Adam kernel
+            from .ddp import allreduce_sum_
+            world = allreduce_sum_(self.flat_g, self.process_group)
         L = hip.lib()
         ws = hip.workspace(L.sp_sumsq_workspace(self.numel), self.flat_g.device, slot=1)
         check(L.sp_sumsq(ptr(self.flat_g), self.numel, ptr(self._sumsq), ptr(ws), hip.stream()), "sp_sumsq")

@@ -1,0 +1,116 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares, the host-side mirror of the
+reference surface (state_dict keys, CLI flags, sampling index arithmetic), the synthetic generators, and the refusal
+to run without a HIP device."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "scanpaths_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from scanpaths_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/scanpaths_amd.h but not exported"
+    assert sorted(hip.SIGNATURES) == syms, set(hip.SIGNATURES) ^ set(syms)
+    assert lib.sp_abi_version() == 1          # pure host call, no GPU needed
+
+
+@pytest.mark.parametrize("case,task", [("air_train_T4", "AiR"), ("osie_r18_train_T8", "OSIE"), ("coco_train_T6", "COCO_Search18")])
+def test_state_dict_keys_and_parameter_order_match_reference(case, task):
+    """parameter registration order == the reference's model.named_parameters() (stored with the goldens): optimizer
+    state in reference checkpoints is indexed by that order (utils/checkpointing.py:93-110)."""
+    from scanpaths_amd.models.scanpath_model import ScanpathModel
+    from scanpaths_amd.spec import is_buffer, model_spec
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", case + ".json")))
+    m = ScanpathModel(task, convLSTM_length=2, arch=meta["arch"])
+    assert [k for k, _ in m.named_parameters()] == meta["param_names"]
+    spec = model_spec(task, meta["arch"])
+    sd = m.state_dict()
+    assert list(sd) == list(spec) and all(tuple(sd[k].shape) == tuple(spec[k]) for k in spec)
+    assert [k for k in spec if not is_buffer(k)] == meta["param_names"]
+    w = sd["lstm.input_x.weight"]
+    assert w.permute(0, 2, 3, 1).is_contiguous()       # [Co][KH][KW][Ci] physical layout the kernels consume
+
+
+def test_map_size_generic_spec():
+    from scanpaths_amd.spec import drt_hw, model_spec
+    assert drt_hw(30, 40) == (6, 8)                     # reference's hard-coded (6,8), baseline_attention.py:145
+    s = model_spec("AiR", "resnet50", 40, 64)
+    assert s["spatial_embed.weight"] == (2560, 2560) and s["object_head.drt_layer_2.weight"] == (2, 1, 8, 13)
+    assert s["spatial_att.spatial_attention.weight"] == (1, 1, 40, 64)
+
+
+def test_no_cpu_path():
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd import functional as F, hip
+    m = baseline(convLSTM_length=1)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 240, 320), torch.zeros(1, 1, 30, 40), torch.ones(1, dtype=torch.bool))
+    with pytest.raises(hip.HipError):
+        F.conv2d(torch.zeros(1, 4, 4, 32), torch.zeros(32, 32, 3, 3), None, pad=1)
+
+
+def test_opts_flag_surface():
+    from scanpaths_amd.opts import parse_opt
+    a = parse_opt("AiR", [])
+    assert (a.width, a.height, a.map_width, a.map_height) == (320, 240, 40, 30)
+    assert (a.clip, a.batch, a.lr, a.weight_decay, a.lambda_1, a.lambda_5, a.max_length) == (12.5, 16, 1e-4, 5e-5, 1, -2.0, 16)
+    assert parse_opt("OSIE", []).weight_decay == 5e-4 and not hasattr(parse_opt("OSIE", []), "lambda_5")
+    c = parse_opt("COCO_Search18", ["--detector_threshold", "0.5", "--batch", "64"])
+    assert c.detector_threshold == 0.5 and c.batch == 64 and not hasattr(c, "att_dir")
+    assert parse_opt("AiR", ["--ablate_attention_info", "False"]).ablate_attention_info is True   # type=bool quirk kept
+    assert parse_opt("AiR", ["--set_cfgs", "lr", "0.01"]).lr == 0.01                              # set_cfgs > defaults
+    assert parse_opt("AiR", ["--set_cfgs", "lr", "0.01", "--lr", "0.5"]).lr == 0.5                 # explicit CLI > set_cfgs (:70)
+
+
+def test_sampling_host_logic_matches_reference_known_answers():
+    from scanpaths_amd.models.sampling import Sampling
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "sampling.npz")))
+    acts, durs = torch.from_numpy(g["acts"]), torch.from_numpy(g["durs"])
+    s = Sampling(convLSTM_length=16, min_length=1)
+    fix, am, dm = s.generate_scanpath(torch.zeros(6, 3, 2, 2), torch.zeros(6, 16), durs, acts)
+    assert np.array_equal(am.numpy(), g["action_masks"]) and np.array_equal(dm.numpy(), g["duration_masks"])
+    for b, f in enumerate(fix):
+        ref = g[f"fix{b}"]
+        assert len(f) == len(ref)
+        if len(f):
+            assert np.allclose(np.stack([f["start_x"], f["start_y"], f["duration"]], 1), ref, atol=1e-6)
+    # first-terminate scan inside random_sample (incl. the "terminate at t=0 -> T" quirk), replayed on fixed actions
+    is_term = acts == 0
+    first = torch.where(is_term.any(1), is_term.float().argmax(1), torch.zeros(6, dtype=torch.long)).float()
+    first[first == 0] = 16
+    assert np.array_equal(first.numpy(), g["scanpath_length"])
+
+
+def test_synth_and_procedural_are_deterministic():
+    from scanpaths_amd.procedural import procedural_state_dict
+    from scanpaths_amd.spec import model_spec
+    from scanpaths_amd.synth import make_batch
+    a, b = make_batch("AiR", 3, 240, 320, 16, seed=5), make_batch("AiR", 3, 240, 320, 16, seed=5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert a["scanpaths"].shape == (3, 16, 1201) and torch.all(a["scanpaths"].sum(-1) == 1)
+    assert torch.all(a["attention_maps"].flatten(1).max(1).values == 1)
+    assert torch.all(a["action_masks"].sum(1) >= a["duration_masks"].sum(1))
+    r1 = make_batch("AiR", 3, 240, 320, 16, seed=5, rank=1)
+    assert not torch.equal(a["images"], r1["images"])
+    spec = {k: v for k, v in list(model_spec("OSIE", "resnet18").items())[:40]}
+    s1, s2 = procedural_state_dict(spec, 3), procedural_state_dict(dict(reversed(list(spec.items()))), 3)
+    assert all(torch.equal(s1[k], s2[k]) for k in spec)          # value depends on key/shape/seed, not on order
