@@ -146,12 +146,19 @@ def main():
     summ = timer.summary()
     # dominant kernel = the per-step h-gate conv: implicit GEMM  M = B*P, N = 2048, K = 9*512 (forward flavour)
     P = Hm * Wm
-    dom_key = ("igemm_fwd", args.batch * P, 2048, 9 * 512, "3x3", 1)
-    dom = summ.get(dom_key) or max(summ.values(), key=lambda d: d["ms"])
+    dom = None
+    for kind in ("b3_fwd", "igemm_fwd"):
+        dom = dom or summ.get((kind, args.batch * P, 2048, 9 * 512, "3x3", 1))
+    dom_kernel = "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)" if ("b3_fwd", args.batch * P, 2048, 9 * 512, "3x3", 1) in summ \
+        else "igemm_kernel<128,128,2,2,fwd> (fp32 MFMA)"
+    if dom is None:
+        dom = max(summ.values(), key=lambda d: d["ms"])
     total_timed_ms = sum(d["ms"] for d in summ.values()) / args.steps
     roofline = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "igemm_kernel<128,128,2,2,fwd> h-gate conv3x3 512->2048",
+                "kernel": dom_kernel + ": h-gate conv3x3 512->2048, implicit GEMM M=B*P N=2048 K=4608",
+                "peak_note": "fp32-faithful arithmetic; priced against the fp32 matrix peak (157.3 TFLOP/s). The 3xbf16-split "
+                             "kernel issues 6 bf16 MFMAs per product: its bf16 issue rate is 6x `achieved` (bf16 dense peak 2500)",
                 "flops_per_launch": dom["flops_per_launch"], "avg_launch_ms": round(dom["avg_ms"], 4),
                 "launches_timed": dom["launches"],
                 "all_big_gemms_ms_per_step": round(total_timed_ms, 2),

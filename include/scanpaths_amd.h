@@ -58,6 +58,19 @@ typedef struct sp_conv_desc {
 
 int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float* W, const float* bias, float* out, void* stream);
 
+/* fp32-faithful variant on the bf16 matrix pipe: every operand pre-split into three bf16 planes x = x1+x2+x3
+ * (sp_split3_bf16), six v_mfma_f32_32x32x16_bf16 products per fragment pair, hi/lo fp32 accumulators -> ~2^-24 relative
+ * product error at 2.67x the fp32 MFMA rate.  Same descriptor as sp_conv_igemm (nbatch must be 1, Kc % 32 == 0); the
+ * weight operand is ALWAYS [Nout][K] rows (K contiguous): for mode 1 pass the operand made by sp_split3_bf16_wT.
+ * ldx must equal Kc (dense NHWC source). */
+/* "split-3 interleaved" operand: x fp32 [rows][K] (K % 16 == 0) -> bf16 [rows][K/16][3][16] (96 contiguous bytes per row
+ * per 16-k group; 6 bytes per element) */
+int sp_split3_bf16(const float* x, int64_t n, void* out, void* stream);
+/* w [Co][taps][Ci] fp32 -> rows ci, k = (tap, co):  bf16 [Ci][taps*Co/16][3][16]  (K-contiguous B operand of dgrad) */
+int sp_split3_bf16_wT(const float* w, int Co, int taps, int Ci, void* out, void* stream);
+int sp_conv_igemm_bf16x3(const sp_conv_desc* d, const void* Xsplit, const void* Wsplit, const float* bias, float* out,
+                         void* stream);
+
 /* Weight gradient (TN GEMM, reduction over output pixels), deterministic split over pixel ranges.
  *   dW[co][tap][ci] (+)= sum_m dY[m][co] * X[pix(m,tap)][ci]
  * Replaces the wgrad half of conv2d/linear backward (autograd of the modules above).

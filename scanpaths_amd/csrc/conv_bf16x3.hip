@@ -1,0 +1,374 @@
+// fp32-faithful implicit-GEMM convolution on the bf16 matrix pipe ("3xbf16 split, 6 products").
+//
+// gfx950 has no TF32/xf32 path and its fp32 MFMA runs at 1/16 of the bf16 rate (157 TFLOP/s peak).  Every fp32
+// operand x is therefore pre-split into three bf16 planes  x = x1 + x2 + x3  (each the round-to-nearest bf16 of the
+// running residual, |x - x1 - x2 - x3| <= 2^-27 |x|; the residuals are exact in fp32), and
+//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1)  + O(2^-26 |ab|)
+// is evaluated with six v_mfma_f32_32x32x16_bf16 per fragment pair.  bf16 x bf16 products are exact in fp32; the
+// six products are issued smallest-first into one accumulator that is folded into a total every 256 k (two-level
+// accumulation as in the fp32 kernel).  Six bf16 MFMAs cost 192 cycles per 16 k against 512 for v_mfma_f32_32x32x2_f32: 2.67x the fp32 matrix rate at
+// fp32-level accuracy (checked against fp64 in tests/test_ops_gpu.py with the same 2e-6 bar as the fp32 kernel).
+//
+// The split is a separate HBM-bound pass (sp_split3_bf16: 4 B read + 6 B written per element), amortised because each
+// activation / gradient / weight tensor feeds GEMMs with thousands of FLOPs per element; planes are ordinary NHWC /
+// [N][K] bf16 tensors.  With six MFMAs per fragment pair the kernel is MFMA-paced by construction (0.5 ds_read_b128 per
+// MFMA); what limits it is operand delivery (per-CU L2/Infinity-Cache rate and the LDS store path), hence the tall
+// 256x128x16 block tile, LDS-DMA staging and the source-side swizzle described at b3_kernel.
+#include "common.h"
+#include <algorithm>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// Operand storage ("split-3 interleaved"): for every row (pixel / output channel) and every group of 16 consecutive k
+// the three planes lie next to each other:  [row][k/16][plane 0..2][16 bf16]  = 96 contiguous bytes per (row, K-tile),
+// so one K-tile of a block row is fetched as six consecutive 16-byte chunks (coalesced, L2-line friendly).
+struct B3Args {
+    const uint16_t* X;    // [pixels][Kc/16][3][16]
+    const uint16_t* W;    // [Nout][K/16][3][16], row stride ldw3 elements (= 3*K)
+    const float* bias;
+    float* C;
+    int64_t M;
+    int Hi, Wi, Kc, ldx3;          // ldx3 = elements per pixel row of X (= 3*Kc)
+    int Ho, Wo, Nout, ldc;
+    int KH, KW, stride, pad, dil;
+    int64_t ldw3;
+    int ncblk, nkt, tiles_n;
+    float alpha;
+    int beta, relu;
+};
+
+// Block tile 256 x 128 x 16, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64 = 2x2 MFMA tiles), 2 waves per
+// SIMD, 1 workgroup per CU.  Why this shape and this staging:
+//  * with six bf16 MFMAs per fragment pair a 128x128 tile needs ~64 GB/s of operand traffic per CU, more than
+//    L2/Infinity Cache deliver per CU (v1 measured 30 GB/s = the Infinity-Cache rate, 32 % MFMA issue).  A 256-row tile halves
+//    the weight traffic (the operand that streams from Infinity Cache) and keeps the activation panel in the XCD's L2 (the
+//    N-tiles of one M-tile are adjacent in the XCD-remapped block order);
+//  * register staging + ds_write_b128 (v2) spent ~700 LDS cycles per K-tile on the 79 B/clk VGPR->LDS store path next to
+//    1536 MFMA cycles.  v3 stages with LDS-DMA (global_load_lds_dwordx4): no VGPRs, no ds_write, loads stay in flight
+//    across the barrier behind a counted s_waitcnt vmcnt(N) in a 3-stage ring;
+//  * LDS-DMA writes lane-linear (base + lane*16), so the LDS image is the linear [row][6 chunks] image of the operand and
+//    bank conflicts are removed on the SOURCE side: chunk c of row r is stored at position (c + ((r>>3)&1)) mod 6 of its
+//    row, which makes the 16 rows of every ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) hit 16
+//    distinct 16-byte slots of the 256-byte bank row (checked exhaustively in DESIGN.md) -- the same rotation is applied
+//    to the fragment read address.
+constexpr int BM = 256, BN = 128, BK = 16;
+constexpr int A_BYTES = BM * 96;                 // 24576: [row][6 x 16 B]
+constexpr int B_BYTES = BN * 96;                 // 12288
+constexpr int STAGE_B = A_BYTES + B_BYTES;       // 36864
+constexpr int NSTAGE = 3;
+constexpr int CHUNK_KT = 16;                     // fold acc into tot every 16 K-tiles (256 k)
+
+__device__ uint4 g_zero_page[4];                 // masked (zero-padding / out-of-range) lanes fetch from here
+
+#define SP_GLDS16(src, dst)                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
+    const int64_t m0 = (int64_t)tmi * BM;
+    const int n0 = tn * BN;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+
+    // ---- loader mapping: LDS chunk g = t + 512 j  ->  row g/6, position g%6; source chunk = position un-rotated ----
+    const int HoWo = p.Ho * p.Wo;
+    int a_c[3], a_py[3], a_px[3];
+    int64_t a_boff[3];
+    bool a_ok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int idx = t + 512 * j;
+        const int row = idx / 6, pos = idx - row * 6;
+        a_c[j] = (pos + 6 - ((row >> 3) & 1)) % 6;
+        const int64_t m = m0 + row;
+        a_ok[j] = m < p.M;
+        const int64_t mm = a_ok[j] ? m : 0;
+        const int b = (int)(mm / HoWo);
+        const int rem = (int)(mm - (int64_t)b * HoWo);
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        a_boff[j] = (int64_t)b * p.Hi * p.Wi;
+        if (MODE == 0) {
+            a_py[j] = yo * p.stride - p.pad;
+            a_px[j] = xo * p.stride - p.pad;
+        } else {
+            a_py[j] = yo + p.pad;
+            a_px[j] = xo + p.pad;
+        }
+    }
+    const uint16_t* b_src[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = t + 512 * j;
+        const int row = idx / 6, pos = idx - row * 6;
+        const int c = (pos + 6 - ((row >> 3) & 1)) % 6;
+        b_ok[j] = idx < BN * 6 && (n0 + row) < p.Nout;
+        b_src[j] = p.W + (b_ok[j] ? (int64_t)(n0 + row) * p.ldw3 + c * 8 : 0);
+    }
+    const int nb_loads = (wave < 4) ? 5 : 4;      // wave-uniform: A 3 + B (2 for waves 0-3, 1 for waves 4-7)
+    int ld_ky = 0, ld_kx = 0, ld_cblk = 0, ld_kt = 0;
+
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bool ok = a_ok[j];
+            int iy = 0, ix = 0;
+            if (MODE == 0) {
+                iy = a_py[j] + ld_ky * p.dil;
+                ix = a_px[j] + ld_kx * p.dil;
+                ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            } else {
+                const int ty = a_py[j] - ld_ky * p.dil, tx = a_px[j] - ld_kx * p.dil;
+                ok = ok && ty >= 0 && tx >= 0;
+                if (p.stride == 1) {
+                    iy = ty;
+                    ix = tx;
+                } else {
+                    iy = ty / p.stride;
+                    ix = tx / p.stride;
+                    ok = ok && (iy * p.stride == ty) && (ix * p.stride == tx);
+                }
+                ok = ok && iy < p.Hi && ix < p.Wi;
+            }
+            const uint16_t* src = ok ? p.X + (a_boff[j] + (int64_t)iy * p.Wi + ix) * p.ldx3 + ld_cblk * 48 + a_c[j] * 8 : zero;
+            SP_GLDS16(src, st + (wave + 8 * j) * 1024);
+        }
+        {
+            const uint16_t* src = b_ok[0] ? b_src[0] + (int64_t)ld_kt * 48 : zero;
+            SP_GLDS16(src, st + A_BYTES + wave * 1024);
+        }
+        if (wave < 4) {
+            const uint16_t* src = b_ok[1] ? b_src[1] + (int64_t)ld_kt * 48 : zero;
+            SP_GLDS16(src, st + A_BYTES + (wave + 8) * 1024);
+        }
+        ++ld_kt;
+        if (++ld_cblk == p.ncblk) {
+            ld_cblk = 0;
+            if (++ld_kx == p.KW) {
+                ld_kx = 0;
+                ++ld_ky;
+            }
+        }
+    };
+
+    // fragment read offsets: row r, chunk c = 2*plane + h stored at position (c + ((r>>3)&1)) % 6
+    const int rot = (l32 >> 3) & 1;
+    int offA[3], offB[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pos = (2 * q + h + rot) % 6;
+        offA[q] = (wm * 64 + l32) * 96 + pos * 16;
+        offB[q] = A_BYTES + (wn * 64 + l32) * 96 + pos * 16;
+    }
+
+    f32x16 tot[2][2], acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tot[i][j][r] = 0.f;
+                acc[i][j][r] = 0.f;
+            }
+
+    // prologue: tiles 0 and 1 in flight, tile 0 landed
+    issue_tile(0);
+    if (p.nkt > 1) issue_tile(1);
+    if (p.nkt > 1) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        // prefetch tile kt+2 into the stage that was read in iteration kt-1 (all waves passed the barrier since)
+        const bool pre = kt + 2 < p.nkt;
+        if (pre) issue_tile(stage == 0 ? 2 : stage - 1);
+        const unsigned char* st = smem + stage * STAGE_B;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                af[i][q] = *reinterpret_cast<const bf16x8*>(st + offA[q] + i * 32 * 96);
+                bf[i][q] = *reinterpret_cast<const bf16x8*>(st + offB[q] + i * 32 * 96);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // six products, smallest magnitude first (a1b3, a3b1, a2b2 ~2^-18; a1b2, a2b1 ~2^-9; a1b1)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+        if ((kt & (CHUNK_KT - 1)) == CHUNK_KT - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+        // tile kt+1 must have landed (everything but the loads just issued for kt+2), then all waves rendezvous
+        if (pre) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = (stage == NSTAGE - 1) ? 0 : stage + 1;
+    }
+    (void)nb_loads;
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l32;
+        if (n >= p.Nout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M) {
+                    float* dst = p.C + m * p.ldc + n;
+                    float v = p.alpha * (tot[i][j][r] + acc[i][j][r]) + bv;
+                    if (p.beta) v += *dst;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- split kernels ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float v, uint16_t& a, uint16_t& b, uint16_t& c) {
+    const __bf16 x1 = (__bf16)v;
+    const float r1 = v - (float)x1;
+    const __bf16 x2 = (__bf16)r1;
+    const float r2 = r1 - (float)x2;
+    const __bf16 x3 = (__bf16)r2;
+    a = __builtin_bit_cast(uint16_t, x1);
+    b = __builtin_bit_cast(uint16_t, x2);
+    c = __builtin_bit_cast(uint16_t, x3);
+}
+
+// x fp32 [rows][K] (K % 16 == 0)  ->  [rows][K/16][3][16] bf16.  One thread per 4 consecutive k.
+__global__ __launch_bounds__(256) void split3_kernel(const float* x, int64_t n4, uint16_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        ushort4 a, b, c;
+        split3(v.x, a.x, b.x, c.x);
+        split3(v.y, a.y, b.y, c.y);
+        split3(v.z, a.z, b.z, c.z);
+        split3(v.w, a.w, b.w, c.w);
+        const int64_t g = i >> 2;            // 16-k group (global, rows are multiples of 16 long)
+        const int sub = (int)(i & 3) * 4;    // offset inside the group
+        uint16_t* o = out + g * 48 + sub;
+        *reinterpret_cast<ushort4*>(o) = a;
+        *reinterpret_cast<ushort4*>(o + 16) = b;
+        *reinterpret_cast<ushort4*>(o + 32) = c;
+    }
+}
+
+// w [Co][taps][Ci] fp32 -> rows n = ci, k = (tap, co):  [Ci][taps*Co/16][3][16]  (the K-contiguous B operand of dgrad)
+__global__ __launch_bounds__(256) void split3_wT_kernel(const float* w, int Co, int taps, int Ci, uint16_t* out) {
+    const int64_t total = (int64_t)Co * taps * Ci;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co);
+        int64_t r = i / Co;
+        const int tap = (int)(r % taps);
+        const int ci = (int)(r / taps);
+        uint16_t a, b, c;
+        split3(w[((int64_t)co * taps + tap) * Ci + ci], a, b, c);
+        const int64_t k = (int64_t)tap * Co + co;                      // k index inside row ci
+        uint16_t* o = out + ((int64_t)ci * ((int64_t)taps * Co / 16) + (k >> 4)) * 48 + (k & 15);
+        o[0] = a;
+        o[16] = b;
+        o[32] = c;
+    }
+}
+
+template <int MODE>
+int launch_b3(const B3Args& a, hipStream_t s) {
+    auto kern = b3_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B);
+        attr_set = true;
+    }
+    const int64_t grid = sp_cdiv(a.M, BM) * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), NSTAGE * STAGE_B, s, a);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+}  // namespace
+
+extern "C" int sp_split3_bf16(const float* x, int64_t n, void* out, void* stream) {
+    if (!x || !out) return SP_ENULL;
+    if (n % 16) return SP_EINVAL;            // every row must be a multiple of 16 long
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256), 4096));
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, (uint16_t*)out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_split3_bf16_wT(const float* w, int Co, int taps, int Ci, void* out, void* stream) {
+    if (!w || !out) return SP_ENULL;
+    if (((int64_t)taps * Co) % 16) return SP_EINVAL;
+    const int64_t total = (int64_t)Co * taps * Ci;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(total, 256), 4096));
+    hipLaunchKernelGGL(split3_wT_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Co, taps, Ci, (uint16_t*)out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_conv_igemm_bf16x3(const sp_conv_desc* d, const void* Xs, const void* Ws, const float* bias, float* out,
+                                    void* stream) {
+    if (!d || !Xs || !Ws || !out) return SP_ENULL;
+    if (d->mode != 0 && d->mode != 1) return SP_EINVAL;
+    if (d->Kc % 16 || d->ldx != d->Kc) return SP_EINVAL;
+    if (((uintptr_t)Xs | (uintptr_t)Ws) & 15) return SP_EINVAL;
+    if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
+    B3Args a;
+    a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
+    a.M = (int64_t)d->N_img * d->Ho * d->Wo;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx3 = 3 * d->Kc;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->ldc;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.ldw3 = 3 * (int64_t)d->KH * d->KW * d->Kc;
+    a.ncblk = d->Kc / 16;
+    a.nkt = d->KH * d->KW * a.ncblk;
+    a.tiles_n = (int)sp_cdiv(d->Nout, BN);
+    a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
+    if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
+    return d->mode == 0 ? launch_b3<0>(a, (hipStream_t)stream) : launch_b3<1>(a, (hipStream_t)stream);
+}

@@ -50,6 +50,52 @@ def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=
     hip.TIMER.bracket(key, 2.0 * M * Co * KH * KW * Ci * nbatch, launch)
 
 
+# ---- fp32-faithful GEMM on the bf16 pipe (csrc/conv_bf16x3.hip) -----------------------------------------------
+USE_BF16X3 = True          # False -> every GEMM on the fp32 MFMA kernel (parity triage / A-B timing)
+
+
+def split3(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [..., K] (K % 16 == 0) -> "split-3 interleaved" bf16 operand [..., K/16, 3, 16] with x = p0+p1+p2 to ~2^-27."""
+    x = x.contiguous()
+    n = x.numel()
+    out = torch.empty(3 * n, dtype=torch.bfloat16, device=x.device)
+    check(hip.lib().sp_split3_bf16(ptr(x), n, ptr(out), hip.stream()), "sp_split3_bf16")
+    return out
+
+
+def split3_wT(wp: torch.Tensor) -> torch.Tensor:
+    """physical weight [Co,KH,KW,Ci] -> split-3 operand with rows ci and k = (tap, co)  (dgrad B operand)."""
+    Co, KH, KW, Ci = wp.shape
+    out = torch.empty(3 * wp.numel(), dtype=torch.bfloat16, device=wp.device)
+    check(hip.lib().sp_split3_bf16_wT(ptr(wp), Co, KH * KW, Ci, ptr(out), hip.stream()), "sp_split3_bf16_wT")
+    return out
+
+
+def _b3_pays(M, N, K, Kc, nbatch=1):
+    """cost model: split pass (10 B per operand element at ~4 TB/s) + GEMM at ~2.3x the fp32 rate < fp32 GEMM"""
+    if not USE_BF16X3 or nbatch != 1 or Kc % 16 or N < 64:
+        return False
+    flops = 2.0 * M * N * K
+    split_bytes = 10.0 * (M * Kc + N * K)
+    return flops * (1 / 1.1e14 - 1 / 2.5e14) > split_bytes / 4e12 and flops > 2e9
+
+
+def _igemm_b3(Xp, Wp, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
+              alpha=1.0, beta=0, relu=0):
+    d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
+                 int(relu), 1, 0, 0, 0)
+
+    def launch():
+        check(hip.lib().sp_conv_igemm_bf16x3(C.byref(d), ptr(Xp), ptr(Wp), ptr(bias), ptr(out), hip.stream()),
+              "sp_conv_igemm_bf16x3")
+    if hip.TIMER is None:
+        return launch()
+    M = N_img * Ho * Wo
+    K = KH * KW * Kc
+    key = ("b3_fwd" if mode == 0 else "b3_dgrad", M, Nout, K, f"{KH}x{KW}", 1)
+    hip.TIMER.bracket(key, 2.0 * M * Nout * K, launch)
+
+
 def colsum(x2d: torch.Tensor, C_: int, ld: int, M: int) -> torch.Tensor:
     out = torch.empty(C_, dtype=torch.float32, device=x2d.device)
     L = hip.lib()
@@ -134,8 +180,12 @@ class _Conv2d(Function):
         assert Ciw == Ci, (wp.shape, x.shape)
         Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
-        _igemm(x, wp, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co, ldw=KH * KW * Ci,
-               KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
+        if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
+            _igemm_b3(split3(x), split3(wp), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
+                      ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
+        else:
+            _igemm(x, wp, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co, ldw=KH * KW * Ci,
+                   KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
         ctx.save_for_backward(x, wp, y if relu else None)
         return y
@@ -155,8 +205,12 @@ class _Conv2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
-                   KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+            if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co):
+                _igemm_b3(split3(dy), split3_wT(wp), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
+                          ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+            else:
+                _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
+                       KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
         if ctx.needs_input_grad[1]:
             dwp = torch.empty_like(wp)
             _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci, KH=KH,
@@ -398,8 +452,12 @@ class _GateConv(Function):
             h = h.contiguous()
             _, Hm, Wm, Cc = h.shape
             hg = torch.empty((B, Hm, Wm, C4), dtype=torch.float32, device=spcol.device)
-            _igemm(h, wp, None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4, ldc=C4, ldw=9 * Cc, KH=3,
-                   KW=3, pad=1, mode=0)
+            if _b3_pays(B * Hm * Wm, C4, 9 * Cc, Cc):
+                _igemm_b3(split3(h), split3(wp), None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4,
+                          ldc=C4, ldw=9 * Cc, KH=3, KW=3, pad=1, mode=0)
+            else:
+                _igemm(h, wp, None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4, ldc=C4, ldw=9 * Cc,
+                       KH=3, KW=3, pad=1, mode=0)
         else:
             hg = torch.zeros((B, hw[0], hw[1], C4), dtype=torch.float32, device=spcol.device)
         _igemm(spcol, wc, None, hg, N_img=P, Hi=1, Wi=1, Kc=KP, ldx=KP, Ho=1, Wo=1, Nout=N3, ldc=C4, ldw=KP, mode=0, beta=1,
@@ -420,8 +478,12 @@ class _GateConv(Function):
             _, Hm, Wm, Cc = h.shape
             if ctx.needs_input_grad[0]:
                 dh = torch.empty_like(h)
-                _igemm(dhg, wp, None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm, Nout=Cc, ldc=Cc, ldw=Cc, KH=3,
-                       KW=3, pad=1, mode=1)
+                if _b3_pays(B * Hm * Wm, Cc, 9 * C4, C4):
+                    _igemm_b3(split3(dhg), split3_wT(wp), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
+                              Nout=Cc, ldc=Cc, ldw=9 * C4, KH=3, KW=3, pad=1, mode=1)
+                else:
+                    _igemm(dhg, wp, None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm, Nout=Cc, ldc=Cc, ldw=Cc,
+                           KH=3, KW=3, pad=1, mode=1)
             if ctx.needs_input_grad[1]:
                 dwp = torch.empty_like(wp)
                 _wgrad(h, dhg, dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Co=C4, ldy=C4, ldo=9 * Cc, KH=3,

@@ -38,7 +38,24 @@ def _call(model, meta, b):
     return model(img, b["attention_maps"].to(DEV), b["tasks"].to(DEV))
 
 
-def _check(name, key, got, g, report, T=None):
+def _informative_steps(g, keys, T):
+    """Number of leading decode steps worth comparing: the recurrent state is shared by all outputs, so once ANY output
+    of the reference's own fp32 run has drifted more than 1 % (of its scale) from its fp64 run, later steps of EVERY
+    output only measure chaotic amplification of rounding noise (random weights), not correctness."""
+    tmax = T
+    for key in keys:
+        ref, r32 = torch.as_tensor(g["ref64/" + key]), torch.as_tensor(g["ref32/" + key])
+        if ref.dim() < 2 or ref.shape[1] != T:
+            continue
+        scale = max(float(ref.abs().max()), 1e-30)
+        for t in range(T):
+            if max_err(r32[:, t], ref[:, t]) > 1e-2 * scale:
+                tmax = min(tmax, t + 1)      # step t itself is still compared (with its own, already loose, bar)
+                break
+    return tmax
+
+
+def _check(name, key, got, g, report, T=None, tmax=None):
     """err(hip, ref64) <= max(1e-4*scale, 10 * running-max of the reference's own fp32-vs-fp64 error), per decode step.
     Returns {step: bar} for the steps that were compared."""
     ref = torch.as_tensor(g["ref64/" + key])
@@ -48,6 +65,8 @@ def _check(name, key, got, g, report, T=None):
         and abs(float(ref[0, 0].sum()) - 1.0) < 1e-6
     scale = float(ref.abs().max()) if is_prob else max(1.0, float(ref.abs().max()))
     steps = range(ref.shape[1]) if (T is not None and ref.dim() >= 2 and ref.shape[1] == T) else [None]
+    if tmax is not None and steps != [None]:
+        steps = range(min(tmax, ref.shape[1]))
     floor_run, bars = 0.0, {}
     for t in steps:
         sl = (slice(None), t) if t is not None else (Ellipsis,)
@@ -88,8 +107,10 @@ def test_eval_forward_matches_reference(name):
     with torch.no_grad():
         pred = _call(model, meta, b)
     report = []
+    tmax = _informative_steps(g, list(pred.keys()), meta["T"])
+    report.append(f"{name}: comparing the first {tmax} of {meta['T']} decode steps")
     for k, v in pred.items():
-        bars = _check(name, k, v, g, report, meta["T"])
+        bars = _check(name, k, v, g, report, meta["T"], tmax)
         if k.endswith("all_actions_prob"):
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
@@ -108,8 +129,9 @@ def test_train_step_matches_reference(name):
     opt.zero_grad()
     pred = _call(model, meta, b)
     report = []
+    tmax = _informative_steps(g, list(pred.keys()), meta["T"])
     for k, v in pred.items():
-        bars = _check(name, k, v, g, report, meta["T"])
+        bars = _check(name, k, v, g, report, meta["T"], tmax)
         if k in ("all_actions_prob", "actions"):
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")

@@ -41,9 +41,14 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_fwd_bwd(case):
+def test_conv2d_fwd_bwd(case, path, monkeypatch):
+    """both GEMM back-ends against fp64 with the SAME fp32-rounding-sized bar (the 3xbf16-split kernel is fp32-faithful)"""
     from scanpaths_amd import functional as F
+    monkeypatch.setattr(F, "USE_BF16X3", path == "bf16x3")
+    if path == "bf16x3":       # force the split kernel even where the cost model would not pick it
+        monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1: nbatch == 1 and Kc % 16 == 0)
     N, H, W, Ci, Co, k, s, p, d, has_b, relu = case
     x = _rand(N, Ci, H, W, seed=1)
     w = _rand(Co, Ci, k, k, seed=2, scale=1.0 / math.sqrt(Ci * k * k))
