@@ -89,6 +89,13 @@ typedef struct sp_wgrad_desc {
 int64_t sp_conv_wgrad_workspace(const sp_wgrad_desc* d);
 int sp_conv_wgrad(const sp_wgrad_desc* d, const float* X, const float* dY, float* dW, void* workspace, void* stream);
 
+/* weight gradient on the same 3xbf16-split scheme (K = pixels; fragments by ds_read_b64_tr_b16).  X / dY are split-3
+ * operands of the dense NHWC tensors; needs Ci % 128 == 0, Co % 16 == 0, nbatch == 1, ldx == Ci, ldy == Co. */
+int64_t sp_conv_wgrad_bf16x3_workspace(const sp_wgrad_desc* d);
+int sp_conv_wgrad_bf16x3(const sp_wgrad_desc* d, const void* Xsplit, const void* dYsplit, float* dW, void* workspace,
+                         void* stream);
+
+
 /* column sums of a row-major [M][C] matrix (ld = row stride): out[c] = beta*out[c] + sum_m x[m][c]
  * (bias gradients).  workspace >= sp_colsum_workspace(M, C) bytes. */
 int64_t sp_colsum_workspace(int64_t M, int C);

@@ -266,6 +266,251 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
     }
 }
 
+// ================================================================================================================
+// Weight gradient on the same scheme:  dW[co][tap][ci] = sum_m dY[m][co] * X[pix(m,tap)][ci]   (K = pixels).
+// Both operands are pixel-major in HBM, so a K-tile (16 pixels) is staged as [pixel][channel chunks] rows by LDS-DMA and
+// the K-major MFMA fragments are produced by ds_read_b64_tr_b16 (hardware transpose read: a 16-lane group reads a
+// 4-pixel x 16-channel block and each lane receives one channel's 4 consecutive pixels; verified lane map in
+// tools/probes/tr_probe.hip).  A pixel row is 1536 B (A: 256 co) / 768 B (B: 128 ci), both = 0 mod 256, so the four
+// pixel rows of a block would collide on the same banks; the loader therefore stores row r rotated by 4*(r&3) chunks
+// (64 B), which spreads the 4 rows x 2 channel groups of every 32-lane half over all 64 banks -> conflict-free.
+// Block tile 256 (co) x 128 (tap,ci) x 16 pixels, 8 waves, 3-stage ring, counted vmcnt -- as the forward kernel.
+// The pixel reduction is split over blockIdx.y into partial slabs (summed in a fixed order by wgrad3_reduce_kernel).
+struct W3Args {
+    const uint16_t* X;     // split-3 [pixels_in][Ci/16][3][16]
+    const uint16_t* dY;    // split-3 [pixels_out][Co/16][3][16]
+    float* out;            // dW [Co][ldo] or slabs
+    int64_t M;             // output pixels
+    int Hi, Wi, Ci, Ho, Wo, Co;
+    int KH, KW, stride, pad, dil;
+    int Ntot, ldo, tiles_n, splits;
+    int64_t rows_per_split, slab_stride;
+    float alpha;
+    int beta;
+};
+
+constexpr int WA_BYTES = 16 * 1536;              // 24576
+constexpr int WB_BYTES = 16 * 768;               // 12288
+constexpr int WSTAGE_B = WA_BYTES + WB_BYTES;    // 36864
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, int off1) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + off0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + off1));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
+    const int co0 = tmi * 256, n0 = tn * 128;
+    const int tap = n0 / p.Ci, ci0 = n0 - tap * p.Ci;           // Ci % 128 == 0: a column tile lies inside one tap
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int split = blockIdx.y;
+    const int64_t m_begin = (int64_t)split * p.rows_per_split;
+    const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nkt = (int)((m_end - m_begin + 15) / 16);
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- loader mapping ---------------------------------------------------------------------------------------
+    int a_r[3], a_src[3];          // pixel row inside the K-tile, element offset inside the pixel's channel run
+    bool a_cok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int g = t + 512 * j;
+        const int r = g / 96, pos = g - r * 96;
+        const int js = (pos + 96 - 4 * (r & 3)) % 96;            // un-rotate: which source chunk lands here
+        a_r[j] = r;
+        a_src[j] = co0 * 3 + js * 8;
+        a_cok[j] = co0 + (js / 6) * 16 < p.Co;
+    }
+    int b_r[2], b_src[2];
+    bool b_live[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = t + 512 * j;
+        const int r = g / 48, pos = g - r * 48;
+        const int js = (pos + 48 - 4 * (r & 3)) % 48;
+        b_r[j] = r & 15;
+        b_src[j] = ci0 * 3 + js * 8;
+        b_live[j] = g < 768 && n0 + (js / 6) * 16 < p.Ntot;
+    }
+    int ld_kt = 0;
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * WSTAGE_B;
+        const int64_t mt = m_begin + (int64_t)ld_kt * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int64_t m = mt + a_r[j];
+            const bool ok = a_cok[j] && m < m_end;
+            const uint16_t* src = ok ? p.dY + m * (3 * (int64_t)p.Co) + a_src[j] : zero;
+            SP_GLDS16(src, st + (wave + 8 * j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && wave >= 4) break;
+            const int64_t m = mt + b_r[j];
+            bool ok = b_live[j] && m < m_end;
+            const uint16_t* src = zero;
+            if (ok) {
+                const int b = (int)(m / HoWo);
+                const int rem = (int)(m - (int64_t)b * HoWo);
+                const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+                const int iy = yo * p.stride - p.pad + ky * p.dil, ix = xo * p.stride - p.pad + kx * p.dil;
+                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                    src = p.X + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * (3 * (int64_t)p.Ci) + b_src[j];
+            }
+            SP_GLDS16(src, st + WA_BYTES + (wave + 8 * j) * 1024);
+        }
+        ++ld_kt;
+    };
+
+    // ---- transposed-read offsets: lane (group g4 = lane>>4, q = (lane>>2)&3, pp = lane&3) addresses pixel row
+    //      8h + 4s + q, channels cbase + 16*(g4&1) + 4pp .. +3 of plane pl ------------------------------------------------
+    const int g4 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    int offA[2][3][2], offB[2][3][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int row = 8 * h + 4 * s2 + q;
+                const int ja = (wm * 4 + i * 2 + g4) * 6 + pl * 2 + (pp >> 1);
+                offA[i][pl][s2] = row * 1536 + ((ja + 4 * q) % 96) * 16 + (pp & 1) * 8;
+                const int jb = (wn * 4 + i * 2 + g4) * 6 + pl * 2 + (pp >> 1);
+                offB[i][pl][s2] = WA_BYTES + row * 768 + ((jb + 4 * q) % 48) * 16 + (pp & 1) * 8;
+            }
+
+    f32x16 tot[2][2], acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tot[i][j][r] = 0.f;
+                acc[i][j][r] = 0.f;
+            }
+
+    if (nkt > 0) {
+        issue_tile(0);
+        if (nkt > 1) issue_tile(1);
+        if (nkt > 1) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool pre = kt + 2 < nkt;
+        if (pre) issue_tile(stage == 0 ? 2 : stage - 1);
+        const unsigned char* st = smem + stage * WSTAGE_B;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[i][pl] = tr_pair(st, offA[i][pl][0], offA[i][pl][1]);
+                bf[i][pl] = tr_pair(st, offB[i][pl][0], offB[i][pl][1]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+        if ((kt & (CHUNK_KT - 1)) == CHUNK_KT - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+        if (pre) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = (stage == NSTAGE - 1) ? 0 : stage + 1;
+    }
+
+    float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
+    const bool direct = p.splits == 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l32;
+        if (n >= p.Ntot) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) {
+                    float* dst = out + (int64_t)co * p.ldo + n;
+                    const float v = tot[i][j][r] + acc[i][j][r];
+                    if (direct) {
+                        float w = p.alpha * v;
+                        if (p.beta) w += *dst;
+                        *dst = w;
+                    } else {
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void wgrad3_reduce_kernel(const float* slab, float* out, int Co, int Ntot, int ldo, int splits, int64_t slab_stride,
+                                     float alpha, int beta) {
+    const int64_t total = (int64_t)Co * Ntot;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Ntot), n = (int)(i - (int64_t)co * Ntot);
+        const int64_t off = (int64_t)co * ldo + n;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * slab_stride + off];
+        s *= alpha;
+        if (beta) s += out[off];
+        out[off] = s;
+    }
+}
+
+int w3_splits(const sp_wgrad_desc* d) {
+    const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
+    const int64_t tiles = sp_cdiv(d->Co, 256) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, 128);
+    int64_t want = sp_cdiv(2048, tiles);                          // 1 workgroup per CU: aim for >= 8 rounds of 256
+    want = std::min<int64_t>(want, std::max<int64_t>(1, M / 512));  // >= 32 K-tiles per split
+    want = std::min<int64_t>(want, 64);
+    return (int)std::max<int64_t>(1, want);
+}
+
 // ---- split kernels ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split3(float v, uint16_t& a, uint16_t& b, uint16_t& c) {
     const __bf16 x1 = (__bf16)v;
@@ -371,4 +616,50 @@ extern "C" int sp_conv_igemm_bf16x3(const sp_conv_desc* d, const void* Xs, const
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
     return d->mode == 0 ? launch_b3<0>(a, (hipStream_t)stream) : launch_b3<1>(a, (hipStream_t)stream);
+}
+
+extern "C" int64_t sp_conv_wgrad_bf16x3_workspace(const sp_wgrad_desc* d) {
+    if (!d) return 0;
+    const int sp = w3_splits(d);
+    return sp <= 1 ? 0 : (int64_t)sp * d->Co * d->ldo * (int64_t)sizeof(float);
+}
+
+extern "C" int sp_conv_wgrad_bf16x3(const sp_wgrad_desc* d, const void* Xsplit, const void* dYsplit, float* dW, void* workspace,
+                                    void* stream) {
+    if (!d || !Xsplit || !dYsplit || !dW) return SP_ENULL;
+    if (d->Ci % 128 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
+    if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
+    W3Args a;
+    a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;
+    a.M = (int64_t)d->N_img * d->Ho * d->Wo;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.Ntot = d->KH * d->KW * d->Ci;
+    a.ldo = d->ldo;
+    a.tiles_n = (int)sp_cdiv(a.Ntot, 128);
+    a.splits = w3_splits(d);
+    if (a.splits > 1 && !workspace) return SP_ENULL;
+    a.rows_per_split = sp_cdiv(sp_cdiv(a.M, a.splits), 16) * 16;
+    a.slab_stride = (int64_t)d->Co * d->ldo;
+    a.out = a.splits > 1 ? (float*)workspace : dW;
+    a.alpha = d->alpha; a.beta = d->beta;
+    if (a.M <= 0) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  NSTAGE * WSTAGE_B);
+        attr_set = true;
+    }
+    const int64_t grid = sp_cdiv(d->Co, 256) * a.tiles_n;
+    hipLaunchKernelGGL(w3_kernel, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), NSTAGE * WSTAGE_B, s, a);
+    SP_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        const int64_t total = (int64_t)d->Co * a.Ntot;
+        const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);
+        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot,
+                           d->ldo, a.splits, a.slab_stride, d->alpha, d->beta);
+        SP_LAUNCH_CHECK();
+    }
+    return SP_OK;
 }

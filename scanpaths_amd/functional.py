@@ -96,6 +96,27 @@ def _igemm_b3(Xp, Wp, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, l
     hip.TIMER.bracket(key, 2.0 * M * Nout * K, launch)
 
 
+def _w3_pays(M, Co, K, Ci, nbatch=1):
+    if not USE_BF16X3 or nbatch != 1 or Ci % 128 or Co % 16 or Co < 128:
+        return False
+    flops = 2.0 * M * Co * K
+    split_bytes = 10.0 * M * (Ci + Co)
+    return flops * (1 / 1.0e14 - 1 / 1.6e14) > split_bytes / 4e12 and flops > 2e9
+
+
+def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0, alpha=1.0):
+    d = WgradDesc(N_img, Hi, Wi, Ci, Ci, Ho, Wo, Co, Co, KH, KW, stride, pad, dil, ldo, int(beta), float(alpha), 1, 0, 0, 0)
+    L = hip.lib()
+    ws = hip.workspace(L.sp_conv_wgrad_bf16x3_workspace(C.byref(d)), dW.device, slot=0)
+
+    def launch():
+        check(L.sp_conv_wgrad_bf16x3(C.byref(d), ptr(Xs), ptr(dYs), ptr(dW), ptr(ws), hip.stream()), "sp_conv_wgrad_bf16x3")
+    if hip.TIMER is None:
+        return launch()
+    M = N_img * Ho * Wo
+    hip.TIMER.bracket(("b3_wgrad", M, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * M * Co * KH * KW * Ci, launch)
+
+
 def colsum(x2d: torch.Tensor, C_: int, ld: int, M: int) -> torch.Tensor:
     out = torch.empty(C_, dtype=torch.float32, device=x2d.device)
     L = hip.lib()
@@ -203,18 +224,24 @@ class _Conv2d(Function):
             check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
             dy = dyr
         dx = dw = db = None
+        dys = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co):
-                _igemm_b3(split3(dy), split3_wT(wp), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
+                dys = split3(dy)
+                _igemm_b3(dys, split3_wT(wp), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
                           ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
             else:
                 _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
                        KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
         if ctx.needs_input_grad[1]:
             dwp = torch.empty_like(wp)
-            _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci, KH=KH,
-                   KW=KW, stride=stride, pad=pad, dil=dil)
+            if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
+                _wgrad_b3(split3(x), dys if dys is not None else split3(dy), dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo,
+                          Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
+            else:
+                _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
+                       KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
             dw = dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum_any(dy, Co)
@@ -476,18 +503,24 @@ class _GateConv(Function):
         dh = dw = dsp = dwc = None
         if ctx.has_h:
             _, Hm, Wm, Cc = h.shape
+            dys = None
             if ctx.needs_input_grad[0]:
                 dh = torch.empty_like(h)
                 if _b3_pays(B * Hm * Wm, Cc, 9 * C4, C4):
-                    _igemm_b3(split3(dhg), split3_wT(wp), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
+                    dys = split3(dhg)
+                    _igemm_b3(dys, split3_wT(wp), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
                               Nout=Cc, ldc=Cc, ldw=9 * C4, KH=3, KW=3, pad=1, mode=1)
                 else:
                     _igemm(dhg, wp, None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm, Nout=Cc, ldc=Cc, ldw=Cc,
                            KH=3, KW=3, pad=1, mode=1)
             if ctx.needs_input_grad[1]:
                 dwp = torch.empty_like(wp)
-                _wgrad(h, dhg, dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Co=C4, ldy=C4, ldo=9 * Cc, KH=3,
-                       KW=3, pad=1)
+                if _w3_pays(B * Hm * Wm, C4, 9 * Cc, Cc):
+                    _wgrad_b3(split3(h), dys if dys is not None else split3(dhg), dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, Ho=Hm,
+                              Wo=Wm, Co=C4, ldo=9 * Cc, KH=3, KW=3, pad=1)
+                else:
+                    _wgrad(h, dhg, dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Co=C4, ldy=C4, ldo=9 * Cc,
+                           KH=3, KW=3, pad=1)
                 dw = dwp.permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(wp).permute(0, 3, 1, 2)

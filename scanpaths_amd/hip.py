@@ -42,6 +42,8 @@ SIGNATURES = {
     "sp_split3_bf16": (_I, [_P, _L, _P, _P]),
     "sp_split3_bf16_wT": (_I, [_P, _I, _I, _I, _P, _P]),
     "sp_conv_igemm_bf16x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "sp_conv_wgrad_bf16x3_workspace": (_L, [C.POINTER(WgradDesc)]),
+    "sp_conv_wgrad_bf16x3": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_workspace": (_L, [C.POINTER(WgradDesc)]),
     "sp_conv_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),
     "sp_colsum_workspace": (_L, [_L, _I]),

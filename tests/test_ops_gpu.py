@@ -38,6 +38,9 @@ CONV_CASES = [
     (2, 12, 16, 32, 128, 5, 1, 2, 1, True, False),
     (3, 10, 12, 160, 192, 3, 1, 1, 1, True, False),
     (2, 17, 21, 32, 64, 3, 2, 1, 1, False, False),
+    (2, 14, 18, 128, 288, 3, 1, 1, 1, True, False),      # Ci % 128 == 0: exercises the split-scheme wgrad (tr reads)
+    (3, 9, 13, 256, 64, 3, 1, 2, 2, False, False),
+    (2, 16, 20, 128, 256, 1, 2, 0, 1, False, False),
 ]
 
 
@@ -49,6 +52,7 @@ def test_conv2d_fwd_bwd(case, path, monkeypatch):
     monkeypatch.setattr(F, "USE_BF16X3", path == "bf16x3")
     if path == "bf16x3":       # force the split kernel even where the cost model would not pick it
         monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1: nbatch == 1 and Kc % 16 == 0)
+        monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1: nbatch == 1 and Ci % 128 == 0 and Co % 16 == 0)
     N, H, W, Ci, Co, k, s, p, d, has_b, relu = case
     x = _rand(N, Ci, H, W, seed=1)
     w = _rand(Co, Ci, k, k, seed=2, scale=1.0 / math.sqrt(Ci * k * k))
