@@ -64,7 +64,7 @@ int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float* W, const f
  * weight operand is ALWAYS [Nout][K] rows (K contiguous): for mode 1 pass the operand made by sp_split3_bf16_wT.
  * ldx must equal Kc (dense NHWC source). */
 /* "split-3 interleaved" operand: x fp32 [rows][K] (K % 16 == 0) -> bf16 [rows][K/16][3][16] (96 contiguous bytes per row
- * per 16-k group; 6 bytes per element) */
+ * per 16-k group; 6 bytes per element) followed by a 64-byte zero block (out must hold 6*n + 64 bytes) */
 int sp_split3_bf16(const float* x, int64_t n, void* out, void* stream);
 /* w [Co][taps][Ci] fp32 -> rows ci, k = (tap, co):  bf16 [Ci][taps*Co/16][3][16]  (K-contiguous B operand of dgrad) */
 int sp_split3_bf16_wT(const float* w, int Co, int taps, int Ci, void* out, void* stream);

@@ -16,6 +16,7 @@
 // 256x128x16 block tile, LDS-DMA staging and the source-side swizzle described at b3_kernel.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -37,6 +38,8 @@ struct B3Args {
     int ncblk, nkt, tiles_n;
     float alpha;
     int beta, relu;
+    int dbg;              // timing experiments only (env SP_B3_DBG): 1 = no global loads, 2 = no MFMAs
+    uint32_t x_bytes, w_bytes;   // data bytes of the split operands; a 64-byte zero block follows each (masked lanes)
 };
 
 // Block tile 256 x 128 x 16, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64 = 2x2 MFMA tiles), 2 waves per
@@ -57,7 +60,7 @@ constexpr int BM = 256, BN = 128, BK = 16;
 constexpr int A_BYTES = BM * 96;                 // 24576: [row][6 x 16 B]
 constexpr int B_BYTES = BN * 96;                 // 12288
 constexpr int STAGE_B = A_BYTES + B_BYTES;       // 36864
-constexpr int NSTAGE = 3;
+constexpr int NSTAGE = 4;                        // ring depth: NSTAGE-1 K-tiles in flight (147 KB LDS)
 constexpr int CHUNK_KT = 16;                     // fold acc into tot every 16 K-tiles (256 k)
 
 __device__ uint4 g_zero_page[4];                 // masked (zero-padding / out-of-range) lanes fetch from here
@@ -66,7 +69,7 @@ __device__ uint4 g_zero_page[4];                 // masked (zero-padding / out-o
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int MODE>
+template <int MODE, int DBG>
 __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -79,25 +82,26 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
     const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
     const int64_t m0 = (int64_t)tmi * BM;
     const int n0 = tn * BN;
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-
-    // ---- loader mapping: LDS chunk g = t + 512 j  ->  row g/6, position g%6; source chunk = position un-rotated ----
+    // ---- loader mapping: LDS chunk g = t + 512 j  ->  row g/6, position g%6; source chunk = position un-rotated.
+    // Address generation is kept off the per-K-tile path: a lane's byte offset (32 bit) and its validity depend only on
+    // the filter tap and are recomputed when the tap changes (every Kc/16 K-tiles); per K-tile the wave adds a SCALAR
+    // channel-block / k offset to the base, and masked lanes (zero padding, tile tails) are redirected to the 64-byte
+    // zero block that follows the operand, so every lane uses the same scalar-base + 32-bit-offset addressing. ----
     const int HoWo = p.Ho * p.Wo;
-    int a_c[3], a_py[3], a_px[3];
-    int64_t a_boff[3];
-    bool a_ok[3];
+    int a_c8[3], a_py[3], a_px[3], a_boff[3];
+    bool a_rowok[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int idx = t + 512 * j;
         const int row = idx / 6, pos = idx - row * 6;
-        a_c[j] = (pos + 6 - ((row >> 3) & 1)) % 6;
+        a_c8[j] = ((pos + 6 - ((row >> 3) & 1)) % 6) * 16;            // byte offset of the source chunk in its 96-B group
         const int64_t m = m0 + row;
-        a_ok[j] = m < p.M;
-        const int64_t mm = a_ok[j] ? m : 0;
+        a_rowok[j] = m < p.M;
+        const int64_t mm = a_rowok[j] ? m : 0;
         const int b = (int)(mm / HoWo);
         const int rem = (int)(mm - (int64_t)b * HoWo);
         const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
-        a_boff[j] = (int64_t)b * p.Hi * p.Wi;
+        a_boff[j] = b * p.Hi * p.Wi;
         if (MODE == 0) {
             a_py[j] = yo * p.stride - p.pad;
             a_px[j] = xo * p.stride - p.pad;
@@ -106,25 +110,26 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
             a_px[j] = xo + p.pad;
         }
     }
-    const uint16_t* b_src[2];
+    uint32_t b_voff[2];
     bool b_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int idx = t + 512 * j;
         const int row = idx / 6, pos = idx - row * 6;
-        const int c = (pos + 6 - ((row >> 3) & 1)) % 6;
+        const int c8 = ((pos + 6 - ((row >> 3) & 1)) % 6) * 16;
         b_ok[j] = idx < BN * 6 && (n0 + row) < p.Nout;
-        b_src[j] = p.W + (b_ok[j] ? (int64_t)(n0 + row) * p.ldw3 + c * 8 : 0);
+        b_voff[j] = b_ok[j] ? (uint32_t)((int64_t)(n0 + row) * p.ldw3 * 2 + c8) : 0u;
     }
-    const int nb_loads = (wave < 4) ? 5 : 4;      // wave-uniform: A 3 + B (2 for waves 0-3, 1 for waves 4-7)
     int ld_ky = 0, ld_kx = 0, ld_cblk = 0, ld_kt = 0;
+    uint32_t a_voff[3];
+    bool a_ok[3];
+    const int rowbytes = p.ldx3 * 2;
 
-    auto issue_tile = [&](int stage) {
-        unsigned char* st = smem + stage * STAGE_B;
+    auto tap_update = [&]() {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            bool ok = a_ok[j];
-            int iy = 0, ix = 0;
+            bool ok = a_rowok[j];
+            int iy, ix;
             if (MODE == 0) {
                 iy = a_py[j] + ld_ky * p.dil;
                 ix = a_px[j] + ld_kx * p.dil;
@@ -142,16 +147,32 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
                 }
                 ok = ok && iy < p.Hi && ix < p.Wi;
             }
-            const uint16_t* src = ok ? p.X + (a_boff[j] + (int64_t)iy * p.Wi + ix) * p.ldx3 + ld_cblk * 48 + a_c[j] * 8 : zero;
-            SP_GLDS16(src, st + (wave + 8 * j) * 1024);
+            a_ok[j] = ok;
+            a_voff[j] = ok ? (uint32_t)(a_boff[j] + iy * p.Wi + ix) * (uint32_t)rowbytes + (uint32_t)a_c8[j] : 0u;
         }
+    };
+
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * STAGE_B;
+        if (ld_cblk == 0) tap_update();
+        const uint32_t koffA = (uint32_t)ld_cblk * 96u;                  // scalar: channel block inside the pixel row
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
+        const uint32_t zrelA = p.x_bytes - koffA;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t off = a_ok[j] ? a_voff[j] : zrelA;
+            SP_GLDS16(baseA + off, st + (wave + 8 * j) * 1024);
+        }
+        const uint32_t koffB = (uint32_t)ld_kt * 96u;
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
+        const uint32_t zrelB = p.w_bytes - koffB;
         {
-            const uint16_t* src = b_ok[0] ? b_src[0] + (int64_t)ld_kt * 48 : zero;
-            SP_GLDS16(src, st + A_BYTES + wave * 1024);
+            const uint32_t off = b_ok[0] ? b_voff[0] : zrelB;
+            SP_GLDS16(baseB + off, st + A_BYTES + wave * 1024);
         }
         if (wave < 4) {
-            const uint16_t* src = b_ok[1] ? b_src[1] + (int64_t)ld_kt * 48 : zero;
-            SP_GLDS16(src, st + A_BYTES + (wave + 8) * 1024);
+            const uint32_t off = b_ok[1] ? b_voff[1] : zrelB;
+            SP_GLDS16(baseB + off, st + A_BYTES + (wave + 8) * 1024);
         }
         ++ld_kt;
         if (++ld_cblk == p.ncblk) {
@@ -185,9 +206,15 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed
-    issue_tile(0);
-    if (p.nkt > 1) issue_tile(1);
-    if (p.nkt > 1) {
+    constexpr bool do_load = DBG != 1, do_mma = DBG != 2;
+    int issued = 0;
+    if (do_load)
+        for (; issued < NSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
+    // wait until tile 0 has landed: all but the (issued-1) newest tiles
+    if (issued >= 3) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (issued == 2) {
         if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -197,9 +224,9 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
 
     int stage = 0;
     for (int kt = 0; kt < p.nkt; ++kt) {
-        // prefetch tile kt+2 into the stage that was read in iteration kt-1 (all waves passed the barrier since)
-        const bool pre = kt + 2 < p.nkt;
-        if (pre) issue_tile(stage == 0 ? 2 : stage - 1);
+        // prefetch tile kt+NSTAGE-1 into the stage that was read in iteration kt-1 (all waves passed the barrier since)
+        const bool pre = kt + NSTAGE - 1 < p.nkt;
+        if (pre && do_load) issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);
         const unsigned char* st = smem + stage * STAGE_B;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
@@ -209,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
                 af[i][q] = *reinterpret_cast<const bf16x8*>(st + offA[q] + i * 32 * 96);
                 bf[i][q] = *reinterpret_cast<const bf16x8*>(st + offB[q] + i * 32 * 96);
             }
+        if constexpr (do_mma)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -221,6 +249,12 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
+        if constexpr (!do_mma) {   // keep the fragment reads alive in the no-MFMA timing mode
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(af[i][q]), "v"(bf[i][q]));
+        }
         if ((kt & (CHUNK_KT - 1)) == CHUNK_KT - 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -231,18 +265,23 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
         }
-        // tile kt+1 must have landed (everything but the loads just issued for kt+2), then all waves rendezvous
-        if (pre) {
-            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kt+1 must have landed: everything but the NSTAGE-2 newest tiles (fewer near the end), then rendezvous
+        {
+            const int newer = min(NSTAGE - 2, p.nkt - 2 - kt);      // tiles younger than kt+1 that are in flight
+            if (newer >= 2) {
+                if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (newer == 1) {
+                if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         stage = (stage == NSTAGE - 1) ? 0 : stage + 1;
     }
-    (void)nb_loads;
 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -287,6 +326,7 @@ struct W3Args {
     int64_t rows_per_split, slab_stride;
     float alpha;
     int beta;
+    uint32_t x_bytes, y_bytes;   // data bytes of the split operands (zero block follows)
 };
 
 constexpr int WA_BYTES = 16 * 1536;              // 24576
@@ -320,11 +360,12 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
     const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
     const int nkt = (int)((m_end - m_begin + 15) / 16);
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
     const int HoWo = p.Ho * p.Wo;
 
-    // ---- loader mapping ---------------------------------------------------------------------------------------
-    int a_r[3], a_src[3];          // pixel row inside the K-tile, element offset inside the pixel's channel run
+    // ---- loader mapping (cheap per-K-tile addressing as in b3_kernel: 32-bit lane offsets + scalar base; masked lanes
+    //      read the zero block after the operand; the pixel coordinates of the gathered operand advance incrementally) ----
+    uint32_t a_voff[3];
+    int a_r[3];
     bool a_cok[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -332,46 +373,54 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
         const int r = g / 96, pos = g - r * 96;
         const int js = (pos + 96 - 4 * (r & 3)) % 96;            // un-rotate: which source chunk lands here
         a_r[j] = r;
-        a_src[j] = co0 * 3 + js * 8;
         a_cok[j] = co0 + (js / 6) * 16 < p.Co;
+        a_voff[j] = (uint32_t)r * (uint32_t)(6 * p.Co) + (uint32_t)(co0 * 6 + js * 16);    // bytes relative to pixel mt
     }
-    int b_r[2], b_src[2];
+    int b_r[2], b_c8[2], b_b[2], b_y[2], b_x[2];
     bool b_live[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int g = t + 512 * j;
-        const int r = g / 48, pos = g - r * 48;
+        const int r = (g / 48) & 15, pos = g % 48;
         const int js = (pos + 48 - 4 * (r & 3)) % 48;
-        b_r[j] = r & 15;
-        b_src[j] = ci0 * 3 + js * 8;
+        b_r[j] = r;
+        b_c8[j] = ci0 * 6 + js * 16;
         b_live[j] = g < 768 && n0 + (js / 6) * 16 < p.Ntot;
+        const int64_t m = m_begin + r;                            // coordinates of this lane's pixel in K-tile 0
+        const int b = (int)(m / HoWo);
+        const int rem = (int)(m - (int64_t)b * HoWo);
+        b_b[j] = b;
+        b_y[j] = rem / p.Wo;
+        b_x[j] = rem - b_y[j] * p.Wo;
     }
+    const int y_adv = 16 / p.Wo, x_adv = 16 - y_adv * p.Wo;      // advancing 16 output pixels = y_adv rows + x_adv columns
+    const uint32_t xrow = (uint32_t)(6 * p.Ci);
     int ld_kt = 0;
     auto issue_tile = [&](int stage) {
         unsigned char* st = smem + stage * WSTAGE_B;
         const int64_t mt = m_begin + (int64_t)ld_kt * 16;
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (6 * (int64_t)p.Co);   // scalar
+        const int64_t rem_bytes = (int64_t)p.y_bytes - mt * (6 * (int64_t)p.Co);
+        const uint32_t zrelA = (uint32_t)rem_bytes;
+        const int rows_left = (int)min((int64_t)16, m_end - mt);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int64_t m = mt + a_r[j];
-            const bool ok = a_cok[j] && m < m_end;
-            const uint16_t* src = ok ? p.dY + m * (3 * (int64_t)p.Co) + a_src[j] : zero;
-            SP_GLDS16(src, st + (wave + 8 * j) * 1024);
+            const bool ok = a_cok[j] && a_r[j] < rows_left;
+            SP_GLDS16(baseA + (ok ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
         }
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.X);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && wave >= 4) break;
-            const int64_t m = mt + b_r[j];
-            bool ok = b_live[j] && m < m_end;
-            const uint16_t* src = zero;
-            if (ok) {
-                const int b = (int)(m / HoWo);
-                const int rem = (int)(m - (int64_t)b * HoWo);
-                const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
-                const int iy = yo * p.stride - p.pad + ky * p.dil, ix = xo * p.stride - p.pad + kx * p.dil;
-                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                    src = p.X + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * (3 * (int64_t)p.Ci) + b_src[j];
-            }
-            SP_GLDS16(src, st + WA_BYTES + (wave + 8 * j) * 1024);
+            const int iy = b_y[j] * p.stride - p.pad + ky * p.dil, ix = b_x[j] * p.stride - p.pad + kx * p.dil;
+            const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const uint32_t off = (uint32_t)((b_b[j] * p.Hi + iy) * p.Wi + ix) * xrow + (uint32_t)b_c8[j];
+            SP_GLDS16(baseB + (ok ? off : p.x_bytes), st + WA_BYTES + (wave + 8 * j) * 1024);
+            // advance this lane's pixel by 16 for the next K-tile (no divisions)
+            b_x[j] += x_adv;
+            b_y[j] += y_adv;
+            if (b_x[j] >= p.Wo) { b_x[j] -= p.Wo; ++b_y[j]; }
+            if (b_y[j] >= p.Ho) { b_y[j] -= p.Ho; ++b_b[j]; }
         }
         ++ld_kt;
     };
@@ -404,10 +453,13 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
                 acc[i][j][r] = 0.f;
             }
 
-    if (nkt > 0) {
-        issue_tile(0);
-        if (nkt > 1) issue_tile(1);
-        if (nkt > 1) {
+    {
+        int issued = 0;
+        for (; issued < NSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
+        if (issued >= 3) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (issued == 2) {
             if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
@@ -418,8 +470,8 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
 
     int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        const bool pre = kt + 2 < nkt;
-        if (pre) issue_tile(stage == 0 ? 2 : stage - 1);
+        const bool pre = kt + NSTAGE - 1 < nkt;
+        if (pre) issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);
         const unsigned char* st = smem + stage * WSTAGE_B;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
@@ -450,11 +502,17 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
         }
-        if (pre) {
-            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int newer = min(NSTAGE - 2, nkt - 2 - kt);      // tiles younger than kt+1 that are in flight
+            if (newer >= 2) {
+                if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if (newer == 1) {
+                if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -539,6 +597,8 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* x, int64_t n4,
         *reinterpret_cast<ushort4*>(o + 16) = b;
         *reinterpret_cast<ushort4*>(o + 32) = c;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 8)       // 64-byte zero block right after the data (masked lanes of the GEMM loaders)
+        reinterpret_cast<uint2*>(out + 12 * n4)[threadIdx.x] = make_uint2(0u, 0u);
 }
 
 // w [Co][taps][Ci] fp32 -> rows n = ci, k = (tap, co):  [Ci][taps*Co/16][3][16]  (the K-contiguous B operand of dgrad)
@@ -557,11 +617,12 @@ __global__ __launch_bounds__(256) void split3_wT_kernel(const float* w, int Co, 
         o[16] = b;
         o[32] = c;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(out + 3 * total)[threadIdx.x] = make_uint2(0u, 0u);
 }
 
-template <int MODE>
+template <int MODE, int DBG>
 int launch_b3(const B3Args& a, hipStream_t s) {
-    auto kern = b3_kernel<MODE>;
+    auto kern = b3_kernel<MODE, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B);
@@ -614,8 +675,15 @@ extern "C" int sp_conv_igemm_bf16x3(const sp_conv_desc* d, const void* Xs, const
     a.nkt = d->KH * d->KW * a.ncblk;
     a.tiles_n = (int)sp_cdiv(d->Nout, BN);
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
+    const int64_t xb = 6LL * d->N_img * d->Hi * d->Wi * d->Kc, wb = 6LL * d->Nout * d->KH * d->KW * d->Kc;
+    if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
+    a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
+    static const int dbg = getenv("SP_B3_DBG") ? atoi(getenv("SP_B3_DBG")) : 0;
+    a.dbg = dbg;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
-    return d->mode == 0 ? launch_b3<0>(a, (hipStream_t)stream) : launch_b3<1>(a, (hipStream_t)stream);
+    if (dbg == 1) return d->mode == 0 ? launch_b3<0, 1>(a, (hipStream_t)stream) : launch_b3<1, 1>(a, (hipStream_t)stream);
+    if (dbg == 2) return d->mode == 0 ? launch_b3<0, 2>(a, (hipStream_t)stream) : launch_b3<1, 2>(a, (hipStream_t)stream);
+    return d->mode == 0 ? launch_b3<0, 0>(a, (hipStream_t)stream) : launch_b3<1, 0>(a, (hipStream_t)stream);
 }
 
 extern "C" int64_t sp_conv_wgrad_bf16x3_workspace(const sp_wgrad_desc* d) {
@@ -644,6 +712,9 @@ extern "C" int sp_conv_wgrad_bf16x3(const sp_wgrad_desc* d, const void* Xsplit, 
     a.out = a.splits > 1 ? (float*)workspace : dW;
     a.alpha = d->alpha; a.beta = d->beta;
     if (a.M <= 0) return SP_EINVAL;
+    const int64_t xb = 6LL * d->N_img * d->Hi * d->Wi * d->Ci, yb = 6LL * a.M * d->Co;
+    if (xb + 64 >= (1LL << 32) || yb + 64 >= (1LL << 32) || d->Ho * d->Wo < 1) return SP_EINVAL;
+    a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {

@@ -58,7 +58,7 @@ def split3(x: torch.Tensor) -> torch.Tensor:
     """fp32 [..., K] (K % 16 == 0) -> "split-3 interleaved" bf16 operand [..., K/16, 3, 16] with x = p0+p1+p2 to ~2^-27."""
     x = x.contiguous()
     n = x.numel()
-    out = torch.empty(3 * n, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(3 * n + 32, dtype=torch.bfloat16, device=x.device)      # + 64-byte zero block for masked loader lanes
     check(hip.lib().sp_split3_bf16(ptr(x), n, ptr(out), hip.stream()), "sp_split3_bf16")
     return out
 
@@ -66,7 +66,7 @@ def split3(x: torch.Tensor) -> torch.Tensor:
 def split3_wT(wp: torch.Tensor) -> torch.Tensor:
     """physical weight [Co,KH,KW,Ci] -> split-3 operand with rows ci and k = (tap, co)  (dgrad B operand)."""
     Co, KH, KW, Ci = wp.shape
-    out = torch.empty(3 * wp.numel(), dtype=torch.bfloat16, device=wp.device)
+    out = torch.empty(3 * wp.numel() + 32, dtype=torch.bfloat16, device=wp.device)
     check(hip.lib().sp_split3_bf16_wT(ptr(wp), Co, KH * KW, Ci, ptr(out), hip.stream()), "sp_split3_bf16_wT")
     return out
 
@@ -77,6 +77,8 @@ def _b3_pays(M, N, K, Kc, nbatch=1):
         return False
     flops = 2.0 * M * N * K
     split_bytes = 10.0 * (M * Kc + N * K)
+    if 6.0 * M * Kc * 4 >= 2 ** 32 or 6.0 * N * K >= 2 ** 32:     # loaders use 32-bit byte offsets (x4: strided / dilated sources)
+        return False
     return flops * (1 / 1.1e14 - 1 / 2.5e14) > split_bytes / 4e12 and flops > 2e9
 
 
@@ -101,6 +103,8 @@ def _w3_pays(M, Co, K, Ci, nbatch=1):
         return False
     flops = 2.0 * M * Co * K
     split_bytes = 10.0 * M * (Ci + Co)
+    if 6.0 * M * max(Ci, Co) * 4 >= 2 ** 32:
+        return False
     return flops * (1 / 1.0e14 - 1 / 1.6e14) > split_bytes / 4e12 and flops > 2e9
 
 
