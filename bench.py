@@ -84,10 +84,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    dev_index = (local_rank % max(ndev, 1)) if world > 1 else 0
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        # "nccl" is RCCL on ROCm.  SP_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a 1-GPU test box
+        # (RCCL refuses two ranks on one device).
+        backend = os.environ.get("SP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            torch.distributed.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from scanpaths_amd import hip
@@ -159,9 +167,19 @@ def main():
         dom = max(summ.values(), key=lambda d: d["ms"])
     total_timed_ms = sum(d["ms"] for d in summ.values()) / args.steps
     is_split = dom_kernel.startswith("b3_kernel")
+    traffic = None      # fabric-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hconv.json")))["kernels"]
+        key = "b3_kernel<0, 0>" if is_split else "igemm_kernel<128, 128, 2, 2, 0, false>"
+        if args.batch == 32 and (args.height, args.width) == (320, 512):
+            traffic = round(pmc[key]["hbm_side_bytes_per_launch"])
+    except Exception:
+        traffic = None
     peak = PEAK_SPLIT3_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
     roofline = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(dom["tflops"] / peak, 4), "traffic": None,
+                "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
+                "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes (profiles/r01_pmc_hconv.json); "
+                                "includes Infinity-Cache hits; algorithmic bytes/launch = operands once + output = 0.98e9",
                 "kernel": dom_kernel + ": h-gate conv3x3 512->2048, implicit GEMM M=B*P N=2048 K=4608",
                 "peak_note": ("2500 TFLOP/s dense bf16 MFMA peak / 6 MFMA products per algorithmic fp32-faithful FMA (3xbf16 "
                               "split); the fp32 MFMA pipe peaks at 157.3" if is_split else "fp32 MFMA peak"),

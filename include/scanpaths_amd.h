@@ -54,6 +54,10 @@ typedef struct sp_conv_desc {
     /* batched GEMM: grid.y = nbatch, element strides between batch items (0 = shared) */
     int nbatch;
     int64_t strideX, strideW, strideC;
+    /* split-K for GEMMs with few output tiles (KH=KW=1, nbatch=1): ksplit > 1 partitions the K-tiles over blockIdx.z,
+     * partial tiles go to `workspace` (>= ksplit*M*Nout floats) and are summed in a fixed order; 0/1 = off */
+    int ksplit;
+    void* workspace;
 } sp_conv_desc;
 
 int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float* W, const float* bias, float* out, void* stream);

@@ -161,18 +161,33 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const uint32_t off = a_ok[j] ? a_voff[j] : zrelA;
-            SP_GLDS16(baseA + off, st + (wave + 8 * j) * 1024);
+            if constexpr (DBG == 3) {
+                const uint4 v = *reinterpret_cast<const uint4*>(baseA + off);
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            } else {
+                SP_GLDS16(baseA + off, st + (wave + 8 * j) * 1024);
+            }
         }
         const uint32_t koffB = (uint32_t)ld_kt * 96u;
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
         const uint32_t zrelB = p.w_bytes - koffB;
         {
             const uint32_t off = b_ok[0] ? b_voff[0] : zrelB;
-            SP_GLDS16(baseB + off, st + A_BYTES + wave * 1024);
+            if constexpr (DBG == 3) {
+                const uint4 v = *reinterpret_cast<const uint4*>(baseB + off);
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            } else {
+                SP_GLDS16(baseB + off, st + A_BYTES + wave * 1024);
+            }
         }
         if (wave < 4) {
             const uint32_t off = b_ok[1] ? b_voff[1] : zrelB;
-            SP_GLDS16(baseB + off, st + A_BYTES + (wave + 8) * 1024);
+            if constexpr (DBG == 3) {
+                const uint4 v = *reinterpret_cast<const uint4*>(baseB + off);
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            } else {
+                SP_GLDS16(baseB + off, st + A_BYTES + (wave + 8) * 1024);
+            }
         }
         ++ld_kt;
         if (++ld_cblk == p.ncblk) {
@@ -683,6 +698,7 @@ extern "C" int sp_conv_igemm_bf16x3(const sp_conv_desc* d, const void* Xs, const
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
     if (dbg == 1) return d->mode == 0 ? launch_b3<0, 1>(a, (hipStream_t)stream) : launch_b3<1, 1>(a, (hipStream_t)stream);
     if (dbg == 2) return d->mode == 0 ? launch_b3<0, 2>(a, (hipStream_t)stream) : launch_b3<1, 2>(a, (hipStream_t)stream);
+    if (dbg == 3) return d->mode == 0 ? launch_b3<0, 3>(a, (hipStream_t)stream) : launch_b3<1, 3>(a, (hipStream_t)stream);
     return d->mode == 0 ? launch_b3<0, 0>(a, (hipStream_t)stream) : launch_b3<1, 0>(a, (hipStream_t)stream);
 }
 

@@ -17,6 +17,7 @@
 // MFMA #e consumes element e of both operands, i.e. it sums k = {k0+e, k0+4+e}.  A and B use the same
 // permutation, and the sum over k is order-free, so no shuffles are needed.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -36,6 +37,8 @@ struct IgemmArgs {
     float alpha;
     int beta, relu;
     int64_t strideX, strideW, strideC;
+    int ksplit, kt_per_split;     // split-K: blockIdx.z handles K-tiles [z*kt_per_split, ...), raw partials to slabs
+    int64_t slab_stride;
 };
 
 constexpr int BK = 32;
@@ -97,6 +100,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
 
     // load cursor (uniform): which tap / channel block the NEXT tile to be loaded belongs to
     int ld_ky = 0, ld_kx = 0, ld_cblk = 0, ld_kt = 0;
+    int kt_begin = 0, kt_end = p.nkt;
+    if (p.ksplit > 1) {           // pure GEMM (one tap): the K-tile index is the channel block
+        kt_begin = blockIdx.z * p.kt_per_split;
+        kt_end = min(p.nkt, kt_begin + p.kt_per_split);
+        ld_kt = kt_begin;
+        ld_cblk = kt_begin;
+    }
 
     float4 ra[AR], rb[BR];
 
@@ -218,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     store_tile(smem, smem + A_ELEMS);
     __syncthreads();
 
-    for (int kt = 0; kt < p.nkt; ++kt) {
-        const bool more = kt + 1 < p.nkt;
+    for (int kt = 0; kt < kt_end - kt_begin; ++kt) {
+        const bool more = kt + 1 < kt_end - kt_begin;
         if (more) load_tile();
         const float* sA = smem + (kt & 1) * STAGE;
         const float* sB = sA + A_ELEMS;
@@ -275,6 +285,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
         for (int j = 0; j < TN; ++j) tot[i][j] += acc[i][j];
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    if (p.ksplit > 1) {           // raw partial tile -> slab z (dense [M][Nout]); alpha/bias/beta/relu applied by the reducer
+        float* slab = p.C + (int64_t)blockIdx.z * p.slab_stride;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l32;
+            if (n >= p.Nout) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M) slab[m * p.Nout + n] = tot[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + l32;
@@ -297,8 +323,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs p) {
     }
 }
 
+// out[m][n] = relu?( alpha * sum_z slab[z][m][n] + bias[n] + beta*out[m][n] )
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slab, int ksplit, int64_t slab_stride, int64_t M, int N,
+                                                            int ldc, const float* bias, float alpha, int beta, int relu,
+                                                            float* out) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / N;
+        const int n = (int)(i - m * N);
+        float s = 0.f;
+        for (int z = 0; z < ksplit; ++z) s += slab[(int64_t)z * slab_stride + i];
+        float v = alpha * s + (bias ? bias[n] : 0.f);
+        float* dst = out + m * ldc + n;
+        if (beta) v += *dst;
+        if (relu) v = fmaxf(v, 0.f);
+        *dst = v;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool SMALLC>
-int launch(const IgemmArgs& a, int nbatch, hipStream_t s) {
+int launch(const IgemmArgs& a, int nbatch, hipStream_t s, void* b_workspace = nullptr) {
     constexpr int LDB = (MODE == 0) ? (BK + 4) : (BN + 4);
     constexpr int STAGE = BM * LDA + ((MODE == 0) ? BN * LDB : BK * LDB);
     const size_t lds = 2 * STAGE * sizeof(float);
@@ -313,6 +357,20 @@ int launch(const IgemmArgs& a, int nbatch, hipStream_t s) {
     b.tiles_n = (int)sp_cdiv(a.Nout, BN);
     const int64_t grid = tiles_m * b.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
+    if (b.ksplit > 1) {
+        float* final_out = b.C;
+        const float* bias = b.bias;
+        b.C = (float*)b_workspace;      // slabs
+        b.slab_stride = b.M * b.Nout;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid, 1, (unsigned)b.ksplit), dim3(256), lds, s, b);
+        SP_LAUNCH_CHECK();
+        const int64_t total = b.M * b.Nout;
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(total, 256), 2048));
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)b_workspace, b.ksplit, b.slab_stride,
+                           b.M, b.Nout, b.ldc, bias, b.alpha, b.beta, b.relu, final_out);
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nbatch), dim3(256), lds, s, b);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -343,12 +401,18 @@ extern "C" int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float*
     a.tiles_n = 0;
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
     a.strideX = d->strideX; a.strideW = d->strideW; a.strideC = d->strideC;
+    a.ksplit = 1; a.kt_per_split = a.nkt; a.slab_stride = 0;
+    if (d->ksplit > 1 && d->workspace && taps == 1 && d->nbatch == 1 && !smallc) {
+        a.kt_per_split = (a.nkt + d->ksplit - 1) / d->ksplit;
+        a.ksplit = (a.nkt + a.kt_per_split - 1) / a.kt_per_split;
+    }
+    void* ws = d->workspace;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const bool narrow = d->Nout <= 64;
     if (d->mode == 0) {
         if (smallc) return narrow ? launch<128, 64, 4, 1, 0, true>(a, d->nbatch, s) : launch<128, 128, 2, 2, 0, true>(a, d->nbatch, s);
-        return narrow ? launch<128, 64, 4, 1, 0, false>(a, d->nbatch, s) : launch<128, 128, 2, 2, 0, false>(a, d->nbatch, s);
+        return narrow ? launch<128, 64, 4, 1, 0, false>(a, d->nbatch, s, ws) : launch<128, 128, 2, 2, 0, false>(a, d->nbatch, s, ws);
     }
-    return narrow ? launch<128, 64, 4, 1, 1, false>(a, d->nbatch, s) : launch<128, 128, 2, 2, 1, false>(a, d->nbatch, s);
+    return narrow ? launch<128, 64, 4, 1, 1, false>(a, d->nbatch, s, ws) : launch<128, 128, 2, 2, 1, false>(a, d->nbatch, s, ws);
 }

@@ -23,8 +23,17 @@ from .hip import ConvDesc, WgradDesc, check, ptr
 # ----------------------------------------------------------------------------------------------------
 def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1,
            mode=0, alpha=1.0, beta=0, relu=0, nbatch=1, sX=0, sW=0, sC=0):
+    # split-K when a pure GEMM has too few output tiles to fill 256 CUs (e.g. M = batch rows, K = 13824)
+    ksplit, ws = 0, None
+    if KH * KW == 1 and nbatch == 1:
+        tiles = ((N_img * Ho * Wo + 127) // 128) * ((Nout + 127) // 128)
+        nkt = (Kc + 31) // 32
+        if tiles <= 64 and nkt >= 32:
+            ksplit = max(2, min(nkt // 8, 512 // tiles))
+            ws = hip.workspace(ksplit * N_img * Ho * Wo * Nout * 4, X.device, slot=2)
     d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
-                 int(relu), nbatch, sX, sW, sC)
+                 int(relu), nbatch, sX, sW, sC, ksplit, ptr(ws))
+
     def launch():
         check(hip.lib().sp_conv_igemm(C.byref(d), ptr(X), ptr(W), ptr(bias), ptr(out), hip.stream()), "sp_conv_igemm")
     if hip.TIMER is None:
@@ -85,7 +94,7 @@ def _b3_pays(M, N, K, Kc, nbatch=1):
 def _igemm_b3(Xp, Wp, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
               alpha=1.0, beta=0, relu=0):
     d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
-                 int(relu), 1, 0, 0, 0)
+                 int(relu), 1, 0, 0, 0, 0, None)
 
     def launch():
         check(hip.lib().sp_conv_igemm_bf16x3(C.byref(d), ptr(Xp), ptr(Wp), ptr(bias), ptr(out), hip.stream()),

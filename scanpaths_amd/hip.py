@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                 ("mode", C.c_int), ("ldw", C.c_int),
                 ("alpha", C.c_float), ("beta", C.c_int), ("relu", C.c_int),
                 ("nbatch", C.c_int),
-                ("strideX", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64)]
+                ("strideX", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
+                ("ksplit", C.c_int), ("workspace", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "scanpaths_amd.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(sp_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
