@@ -79,7 +79,8 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
     const int wm = wave >> 1, wn = wave & 1;
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
+    int tn, tmi;
+    supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn);
     const int64_t m0 = (int64_t)tmi * BM;
     const int n0 = tn * BN;
     // ---- loader mapping: LDS chunk g = t + 512 j  ->  row g/6, position g%6; source chunk = position un-rotated.

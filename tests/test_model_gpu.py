@@ -198,6 +198,66 @@ def test_train_step_matches_reference(name):
     print("\n".join(report))
 
 
+def test_air_train_T16_logits_match_reference():
+    """train-mode forward over all 16 decode steps (the bench configuration's depth) against the reference's fp64 run"""
+    meta, g = load_golden("air_train_T16")
+    b = case_inputs(meta, torch.float32)
+    model = _build(meta).train()
+    with torch.no_grad():
+        pred = _call(model, meta, b)
+    report = []
+    tmax = _informative_steps(g, list(pred.keys()), meta["T"])
+    for k, v in pred.items():
+        bars = _check("air_train_T16", k, v, g, report, meta["T"], tmax)
+        if k == "all_actions_prob":
+            n, tot = _check_argmax(v, g["ref64/" + k], bars)
+            report.append(f"  argmax identical on all {n} decisive of {tot} compared (b,t) positions; {tmax} of 16 steps compared")
+    print("\n".join(report[-3:]))
+
+
+def test_air_320x512_train_gradients_match_oracle():
+    """BASELINE.json's image size, train mode, one decode step: loss and parameter gradients vs the fp64 oracle (the
+    reference cannot run 320x512).  Bar: 10x the fp32 oracle's own error, or 1e-4 relative to the largest gradient norm."""
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.spec import is_buffer
+    from scanpaths_amd.synth import make_batch
+    Hm, Wm, T = 40, 64, 1
+    meta = dict(task="AiR", arch="resnet50", T=T, weight_seed=12)
+    b = make_batch("AiR", 2, 320, 512, T, seed=12)
+    grads = {}
+    for dt in (torch.float64, torch.float32):
+        sd = oracle_state("AiR", "resnet50", 12, Hm, Wm, dtype=dt)
+        for k, v in sd.items():
+            if v.is_floating_point() and not is_buffer(k):
+                v.requires_grad_(True)
+        bd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in b.items()}
+        pred = O.forward(sd, "AiR", bd["images"], bd["attention_maps"], bd["performances"], training=True, T=T)
+        loss, _, _ = O.supervised_loss(pred, bd)
+        loss.backward()
+        grads[dt] = ({k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}, float(loss))
+    model = _build(meta, Hm, Wm).train()
+    pred = model(b["images"].to(DEV), b["attention_maps"].to(DEV), b["performances"].to(DEV))
+    loss, _, _ = supervised_loss(pred, b["scanpaths"].to(DEV), b["durations"].to(DEV), b["action_masks"].to(DEV),
+                                 b["duration_masks"].to(DEV), 1.0)
+    loss.backward()
+    g64, l64 = grads[torch.float64]
+    g32, l32 = grads[torch.float32]
+    assert abs(float(loss) - l64) <= max(1e-4, 10 * abs(l32 - l64)), (float(loss), l64, l32)
+    norms = {k: float(v.norm()) for k, v in g64.items()}
+    top = max(norms.values())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k not in g64:
+            continue
+        got = p.grad.detach().cpu().double() if p.grad is not None else torch.zeros_like(g64[k])
+        e = float((got - g64[k]).norm())
+        floor = float((g32[k].double() - g64[k]).norm())
+        assert e <= max(1e-4 * top, 10 * floor), (k, e, floor, norms[k])
+        worst = max(worst, e / max(floor, 1e-30) if floor > 1e-12 * top else 0.0)
+    print(f"320x512 train: loss hip {float(loss):.6f} oracle64 {l64:.6f}; worst grad err / oracle32 err = {worst:.2f}")
+
+
 def test_air_320x512_matches_oracle():
     """BASELINE.json's image size; reference cannot run it -> HIP vs the (golden-pinned) fp64 oracle."""
     from oracle import scanpath_oracle as O
