@@ -212,6 +212,18 @@ int sp_sum(const float* x, int64_t n, float* out, void* workspace, void* stream)
 int sp_sumsq(const float* g, int64_t n, double* out, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Post-hoc sampling (models/sampling.py:16-77), SURVEY.md §8 row f1.
+ * sp_sample_actions: per (b,t) masked categorical draw (terminate action 0 excluded for t < min_length), probability of the
+ *   chosen action from the unmasked distribution, duration = exp(eps*sigma2 + mu); Philox4x32-10(seed; row).
+ * sp_generate_scanpath: first-terminate scan -> length [B] (0 -> T quirk), masks [B][T], fix [B][T][3] = (x, y, duration) in
+ *   pixels for the nfix[b] leading fixations.
+ * ---------------------------------------------------------------------------------------------- */
+int sp_sample_actions(const float* probs, const float* mu, const float* sigma2, int B, int T, int A, int min_length,
+                      uint64_t seed, int64_t* actions, float* action_probs, float* durations, void* stream);
+int sp_generate_scanpath(const int64_t* actions, const float* durations, int B, int T, int map_w, int map_h, int width, int height,
+                         float* length, float* action_masks, float* duration_masks, float* fix, int* nfix, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ + Adam (L2 folded into the gradient) over one flat fp32 buffer.  AiR/train.py:116-117,200-202.
  * g_eff = g*gscale (gscale = 1/world_size after a sum all-reduce); total_norm = sqrt(*sumsq)*gscale;
  * coef = min(1, clip/(total_norm+1e-6)) (clip <= 0: no clipping); bc1 = 1-beta1^t, bc2 = 1-beta2^t from the host.

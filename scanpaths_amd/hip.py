@@ -74,6 +74,8 @@ SIGNATURES = {
     "sp_select_rows_bwd": (_I, [_P, _P, _L, _L, _P, _P, _P]),
     "sp_head_finish_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "sp_head_finish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "sp_sample_actions": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_uint64, _P, _P, _P, _P]),
+    "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sp_scanpath_loss_workspace": (_L, [_I, _I]),
     "sp_scanpath_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sp_scale_by": (_I, [_P, _P, _L, _P, _P]),

@@ -1,14 +1,19 @@
-"""Drop-in for ``models/sampling.py`` (Sampling.random_sample :16-46, .generate_scanpath :48-77).
+"""Drop-in for ``models/sampling.py`` (Sampling.random_sample :16-46, .generate_scanpath :48-77), on the device.
 
-Round 1: host-side restatement of the post-hoc sampler ("next"); the per-step
-categorical / log-normal draws use torch's RNG on the tensors' own device.  The device kernel for the
-first-terminate scan + index->(x,y) mapping is scheduled after the train path (§8 f1)."""
+Both methods run HIP kernels (csrc/sampling.hip): a masked categorical draw per (b,t) by inverse CDF with a Philox counter
+RNG, log-normal durations, the first-terminate scan and the index -> pixel mapping; ``generate_scanpath`` does ONE device->host
+copy for the list of numpy structured arrays the reference returns (the reference loops B*T ``.cpu().numpy()`` calls).
+The random stream is this library's own (seeded per call from ``self.seed`` + a call counter); like the reference's CUDA
+stream it is not torch's CPU stream.  All index arithmetic is bit-exact with the reference (tests/golden/sampling.npz)."""
 import numpy as np
 import torch
 
+from .. import hip
+from ..hip import check, ptr
+
 
 class Sampling():
-    def __init__(self, convLSTM_length=16, min_length=2, map_width=40, map_height=30, width=320, height=240):
+    def __init__(self, convLSTM_length=16, min_length=2, map_width=40, map_height=30, width=320, height=240, seed=0):
         self.convLSTM_length = convLSTM_length
         self.min_length = min_length
         self.map_width = map_width
@@ -17,37 +22,51 @@ class Sampling():
         self.height = height
         self.x_granularity = float(self.width / self.map_width)
         self.y_granularity = float(self.height / self.map_height)
+        self.seed = seed
+        self._calls = 0
+
+    def _scan(self, actions, durations):
+        B, T = actions.shape
+        dev = actions.device
+        length = torch.empty(B, dtype=torch.float32, device=dev)
+        am = torch.empty((B, T), dtype=torch.float32, device=dev)
+        dm = torch.empty((B, T), dtype=torch.float32, device=dev)
+        fix = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
+        nfix = torch.empty(B, dtype=torch.int32, device=dev)
+        check(hip.lib().sp_generate_scanpath(ptr(actions), ptr(durations), B, T, self.map_width, self.map_height, self.width,
+                                             self.height, ptr(length), ptr(am), ptr(dm), ptr(fix), ptr(nfix), hip.stream()),
+              "sp_generate_scanpath")
+        return length, am, dm, fix, nfix
 
     def random_sample(self, all_actions_prob, log_normal_mu, log_normal_sigma2):
-        probs = all_actions_prob.detach().clone()
-        probs[:, :self.min_length, 0] = 0
-        selected = torch.distributions.categorical.Categorical(probs=probs).sample()
-        selected_probs = torch.gather(all_actions_prob, 2, selected.unsqueeze(-1)).squeeze(-1)
-        eps = torch.randn(log_normal_mu.shape, device=log_normal_mu.device)
-        durations = torch.exp(eps * log_normal_sigma2 + log_normal_mu)     # sigma2 used as the scale: reference quirk :27
-        is_term = selected == 0
-        first = torch.where(is_term.any(1), is_term.float().argmax(1), torch.full_like(selected[:, 0], 0)).to(
-            all_actions_prob.dtype)
-        first[first == 0] = self.convLSTM_length                           # terminate at t=0 or never -> T (:33)
-        return {"scanpath_length": first.unsqueeze(-1), "durations": durations, "selected_actions_probs": selected_probs,
-                "selected_actions": selected}
+        probs = all_actions_prob.detach().contiguous().float()
+        mu = log_normal_mu.detach().contiguous().float()
+        s2 = log_normal_sigma2.detach().contiguous().float()
+        B, T, A = probs.shape
+        dev = probs.device
+        actions = torch.empty((B, T), dtype=torch.int64, device=dev)
+        aprob = torch.empty((B, T), dtype=torch.float32, device=dev)
+        dur = torch.empty((B, T), dtype=torch.float32, device=dev)
+        self._calls += 1
+        seed = (int(self.seed) * 0x9E3779B97F4A7C15 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        check(hip.lib().sp_sample_actions(ptr(probs), ptr(mu), ptr(s2), B, T, A, int(self.min_length), seed, ptr(actions),
+                                          ptr(aprob), ptr(dur), hip.stream()), "sp_sample_actions")
+        length, _, _, _, _ = self._scan(actions, dur)
+        if all_actions_prob.requires_grad:      # RL phase differentiates through the gathered probabilities (:22-23)
+            aprob = torch.gather(all_actions_prob, 2, actions.unsqueeze(-1)).squeeze(-1)
+        return {"scanpath_length": length.unsqueeze(-1), "durations": dur, "selected_actions_probs": aprob,
+                "selected_actions": actions}
 
     def generate_scanpath(self, images, prob_sample_actions, durations, sample_actions):
-        acts = sample_actions.detach().cpu().numpy()
-        drts = durations.detach().cpu().numpy()
-        N, T = acts.shape
-        amask = np.zeros((N, T), dtype=np.float32)
-        dmask = np.zeros((N, T), dtype=np.float32)
-        fix_vectors = []
-        for n in range(N):
-            term = np.nonzero(acts[n] == 0)[0]
-            L = int(term[0]) if len(term) else T
-            amask[n, :min(L + 1, T)] = 1
-            dmask[n, :L] = 1
-            idx = acts[n, :L] - 1
-            fv = np.zeros(L, dtype={"names": ("start_x", "start_y", "duration"), "formats": ("f8", "f8", "f8")})
-            fv["start_x"] = (idx % self.map_width) * self.x_granularity + self.x_granularity / 2
-            fv["start_y"] = (idx // self.map_width) * self.y_granularity + self.y_granularity / 2
-            fv["duration"] = drts[n, :L]
-            fix_vectors.append(fv)
-        return fix_vectors, images.new_tensor(amask), images.new_tensor(dmask)
+        acts = sample_actions.detach().to(torch.int64).contiguous()
+        durs = durations.detach().float().contiguous()
+        if not acts.is_cuda:
+            raise hip.HipError("Sampling.generate_scanpath needs device tensors (no CPU path)")
+        _, am, dm, fix, nfix = self._scan(acts, durs)
+        fix_h, n_h = fix.cpu().numpy().astype(np.float64), nfix.cpu().numpy()
+        out = []
+        for b in range(acts.shape[0]):
+            fv = np.zeros(int(n_h[b]), dtype={"names": ("start_x", "start_y", "duration"), "formats": ("f8", "f8", "f8")})
+            fv["start_x"], fv["start_y"], fv["duration"] = fix_h[b, :n_h[b], 0], fix_h[b, :n_h[b], 1], fix_h[b, :n_h[b], 2]
+            out.append(fv)
+        return out, am.to(images.dtype), dm.to(images.dtype)

@@ -81,23 +81,13 @@ def test_opts_flag_surface():
     assert parse_opt("AiR", ["--set_cfgs", "lr", "0.01", "--lr", "0.5"]).lr == 0.5                 # explicit CLI > set_cfgs (:70)
 
 
-def test_sampling_host_logic_matches_reference_known_answers():
+def test_sampling_refuses_cpu():
+    """the sampler is a device kernel now (tests/test_inference_gpu.py holds the known answers); no CPU path"""
+    from scanpaths_amd import hip
     from scanpaths_amd.models.sampling import Sampling
-    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "sampling.npz")))
-    acts, durs = torch.from_numpy(g["acts"]), torch.from_numpy(g["durs"])
     s = Sampling(convLSTM_length=16, min_length=1)
-    fix, am, dm = s.generate_scanpath(torch.zeros(6, 3, 2, 2), torch.zeros(6, 16), durs, acts)
-    assert np.array_equal(am.numpy(), g["action_masks"]) and np.array_equal(dm.numpy(), g["duration_masks"])
-    for b, f in enumerate(fix):
-        ref = g[f"fix{b}"]
-        assert len(f) == len(ref)
-        if len(f):
-            assert np.allclose(np.stack([f["start_x"], f["start_y"], f["duration"]], 1), ref, atol=1e-6)
-    # first-terminate scan inside random_sample (incl. the "terminate at t=0 -> T" quirk), replayed on fixed actions
-    is_term = acts == 0
-    first = torch.where(is_term.any(1), is_term.float().argmax(1), torch.zeros(6, dtype=torch.long)).float()
-    first[first == 0] = 16
-    assert np.array_equal(first.numpy(), g["scanpath_length"])
+    with pytest.raises(hip.HipError):
+        s.generate_scanpath(torch.zeros(2, 3, 2, 2), torch.zeros(2, 16), torch.ones(2, 16), torch.zeros(2, 16, dtype=torch.long))
 
 
 def test_synth_and_procedural_are_deterministic():
