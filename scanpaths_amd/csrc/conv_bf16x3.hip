@@ -242,7 +242,6 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
     for (int kt = 0; kt < p.nkt; ++kt) {
         // prefetch tile kt+NSTAGE-1 into the stage that was read in iteration kt-1 (all waves passed the barrier since)
         const bool pre = kt + NSTAGE - 1 < p.nkt;
-        if (pre && do_load) issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);
         const unsigned char* st = smem + stage * STAGE_B;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
@@ -265,6 +264,10 @@ __global__ __launch_bounds__(512, 2) void b3_kernel(B3Args p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
+        // Prefetch of tile kt+NSTAGE-1 is issued BEHIND the MFMAs in program order: a load whose issue is back-pressured by the
+        // memory queue then stalls the wave while the matrix pipe still has this wave's (and its SIMD partner's) MFMAs queued,
+        // instead of in front of the fragment reads with the pipe idle (measured: fwd 8.06 -> 7.58 ms, wgrad 10.99 -> 8.40 ms).
+        if (pre && do_load) issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);
         if constexpr (!do_mma) {   // keep the fragment reads alive in the no-MFMA timing mode
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -487,7 +490,6 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
     int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const bool pre = kt + NSTAGE - 1 < nkt;
-        if (pre) issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);
         const unsigned char* st = smem + stage * WSTAGE_B;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void w3_kernel(W3Args p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
+        if (pre) issue_tile(stage == 0 ? NSTAGE - 1 : stage - 1);     // behind the MFMAs (see b3_kernel)
         if ((kt & (CHUNK_KT - 1)) == CHUNK_KT - 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
