@@ -185,14 +185,46 @@ int sp_select_rows_bwd(const float* dout, const unsigned char* sel, int64_t rows
  * amap [nheads][B][P] (relu action map, always pre-softmax), mu/sigma2 [nheads][B], drt [nheads][B][dh*dw] (post-relu). */
 int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
                        int cb_per_sample /* 1: cb is [B][nheads][HC] (COCO per-task heads) */, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
-                       float* sigma2, float* drt, void* stream);
+                       float* sigma2, float* drt,
+                       const float* dpre /* nullable: [nheads][B][dh*dw] duration-site sums incl. composed tap biases (sp_drt_direct_fwd);
+                                            then Z needs only the 2 map columns per head */,
+                       int zc /* Z columns per head (<= 0: HC) */, void* stream);
 /* dlogits is the gradient w.r.t. the `logits` output (probabilities if softmax).  dZ is fully written for the nheads*HC
  * columns.  Partials are per sample: dcb [B][nheads][HC], dw2 [B][nheads][2][dh*dw], db2 [B][nheads][2]. */
 int sp_head_finish_bwd(const float* dlogits, const float* damap /* nullable, [nheads][B][P] */, const float* dmu,
                        const float* dsigma2, const float* logits,
                        const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
                        int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
-                       float* dw2_partial, float* db2_partial, void* stream);
+                       float* dw2_partial, float* db2_partial,
+                       float* ddpre /* nullable out, gradient of dpre; tap columns of dZ / dcb are then not produced */, int zc,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * predict_head without the dense 5x5 GEMM (models/baseline_attention.py:149-158), csrc/head_direct.hip.
+ * G physical [nheads*HC][5][5][C] composed head filters (row hd*HC+0/1: sal_layer_2/3 o 5x5, rows +2..+50: the 49 taps of
+ * drt_layer_1 o 5x5), cb [nheads][HC] composed biases.  Border classes: a site's class = which of the 7x7 taps land inside
+ * the zero-padded intermediate map (per axis: first / interior / last); ncls = sp_head_num_classes(Hm, Wm).
+ *   compose11: W11 [nheads][ncls][11*11][C] composite stride-5 windows, cbsum [nheads][ncls] sums of in-range tap biases.
+ *   sal_gather: T [B][P][ldt] tap partials (1x1 GEMM of h with G rows 0/1 reshaped [(src*2+o)*25+tap][C]) ->
+ *               Z2 [B][P][nsel*2] (5x5 spatial sums, zero padding); hmap [B][nsel] int32 = source head of output slot.
+ *   drt_direct: Dpre [nsel][B][dh*dw] = cbsum + <W11[class(site)], 11x11 window of h at 5*site-4>; bwd_data writes (or
+ *               accumulates into) dh [B][P][C]; bwd_weight reduces per-sample slabs in fixed order -> dW11, dcbsum.
+ * ---------------------------------------------------------------------------------------------- */
+int sp_head_num_classes(int Hm, int Wm);
+int sp_head_compose11_fwd(const float* G, const float* cb, int nheads, int HC, int C, int Hm, int Wm, float* W11,
+                          float* cbsum, void* stream);
+int sp_head_compose11_bwd(const float* dW11, const float* dcbsum, int nheads, int HC, int C, int Hm, int Wm, float* dG,
+                          float* dcb, void* stream);
+int sp_sal_gather_fwd(const float* T, int B, int Hm, int Wm, int ldt, int nsel, const int* hmap, float* Z2, void* stream);
+int sp_sal_gather_bwd(const float* dZ2, int B, int Hm, int Wm, int ldt, int nsel, int nsrc, const int* hmap, float* dT,
+                      void* stream);
+int sp_drt_direct_fwd(const float* h, const float* W11, const float* cbsum, const int* hmap, int B, int Hm, int Wm, int C,
+                      int nsel, float* Dpre, void* stream);
+int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
+                           int accumulate, float* dh, void* stream);
+int64_t sp_drt_direct_bwd_weight_workspace(int B, int Hm, int Wm, int C, int nsel);
+int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
+                             int nheads, void* workspace, float* dW11, float* dcbsum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss (models/loss.py:10-14,27-32; AiR/train.py:192-197) -- value and gradient in one pass.

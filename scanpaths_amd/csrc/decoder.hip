@@ -239,12 +239,12 @@ constexpr int MAXS = 256;   // dh*dw upper bound
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, int Hm, int Wm, int ldz, int HC,
                                                        const float* cb, int cb_per_sample, const float* w2,
                                                        const float* b2, int softmax, float* logits, float* amap, float* mu, float* sigma2, float* drt,
-                                                       int dh, int dw) {
+                                                       int dh, int dw, const float* dpre, int zc) {
     __shared__ float sh4[4];
     __shared__ float sdrt[MAXS];
     const int hd = blockIdx.y, b = blockIdx.x;
     const int P = Hm * Wm, S = dh * dw;
-    const float* z = Z + (int64_t)b * P * ldz + hd * HC;
+    const float* z = Z + (int64_t)b * P * ldz + hd * zc;
     const float* c = cb + (cb_per_sample ? ((int64_t)b * gridDim.y + hd) : (int64_t)hd) * HC;
     float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
     float* am = amap + ((int64_t)hd * B + b) * P;
@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, in
     for (int s = threadIdx.x; s < S; s += 256) {
         const int sy = s / dw, sx = s % dw;
         float acc = c[IDX_BD];
+        if (dpre) acc += dpre[((int64_t)hd * B + b) * S + s];   // window sums + composed tap biases (head_direct.hip)
+        else
         for (int ky = 0; ky < 7; ++ky) {
             const int py = 5 * sy - 2 + ky;
             if ((unsigned)py >= (unsigned)Hm) continue;
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
                                                        const float* sigma2,
                                                        const float* drt, int B, int Hm, int Wm, int ldz, int HC,
                                                        const float* w2, int softmax, float* dZ, float* dcb_partial,
-                                                       float* dw2_partial, float* db2_partial, int dh, int dw) {
+                                                       float* dw2_partial, float* db2_partial, int dh, int dw, float* ddpre,
+                                                       int zc) {
     __shared__ float sh4[4];
     __shared__ float sdd[MAXS];
     const int hd = blockIdx.y, b = blockIdx.x, nh = gridDim.y;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
     const float* dl = dlogits + ((int64_t)hd * B + b) * (P + 1);
     const float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
     const float* am = amap + ((int64_t)hd * B + b) * P;
-    float* dz = dZ + (int64_t)b * P * ldz + hd * HC;
+    float* dz = dZ + (int64_t)b * P * ldz + hd * zc;
     float* dcb = dcb_partial + ((int64_t)b * nh + hd) * HC;
     float dot = 0.f;
     if (softmax) {
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
         const float dv = drt[((int64_t)hd * B + b) * S + s];
         const float dd = dv > 0.f ? dt0 * w2[s] + dt1 * w2[S + s] : 0.f;
         sdd[s] = dd;
+        if (ddpre) ddpre[((int64_t)hd * B + b) * S + s] = dd;
         sumdd += dd;
         float* pw = dw2_partial + (((int64_t)b * nh + hd) * 2) * S;
         pw[s] = dt0 * dv;
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
     if (threadIdx.x < NTAP) {
         const int ky = threadIdx.x / 7, kx = threadIdx.x % 7;
         float s = 0.f;
+        if (!ddpre)
         for (int sy = 0; sy < dh; ++sy) {
             if ((unsigned)(5 * sy - 2 + ky) >= (unsigned)Hm) continue;
             for (int sx = 0; sx < dw; ++sx)
@@ -360,8 +365,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
     // dZ, coalesced over the HC columns of this head
     float s1 = 0.f;
     const float invP = 1.f / (float)P;
-    for (int64_t i = threadIdx.x; i < (int64_t)P * HC; i += 256) {
-        const int p = (int)(i / HC), j = (int)(i % HC);
+    for (int64_t i = threadIdx.x; i < (int64_t)P * zc; i += 256) {
+        const int p = (int)(i / zc), j = (int)(i % zc);
         float v = 0.f;
         if (j == 0) {
             v = d0 * invP;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
             if (damap) g += damap[((int64_t)hd * B + b) * P + p];
             v = am[p] > 0.f ? g : 0.f;
             s1 += v;
-        } else if (j < 2 + NTAP) {
+        } else if (j < 2 + NTAP && !ddpre) {
             const int tap = j - 2, ky = tap / 7, kx = tap % 7;
             const int py = p / Wm, px = p % Wm;
             const int ty = py + 2 - ky, tx = px + 2 - kx;
@@ -479,13 +484,14 @@ extern "C" int sp_select_rows_bwd(const float* dout, const unsigned char* sel, i
 
 extern "C" int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
                                   int cb_per_sample, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
-                                  float* sigma2, float* drt, void* stream) {
+                                  float* sigma2, float* drt, const float* dpre, int zc, void* stream) {
     if (!Z || !cb || !w2 || !b2 || !logits || !amap || !mu || !sigma2 || !drt) return SP_ENULL;
     const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
-    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1) return SP_EINVAL;
+    if (zc <= 0) zc = HC;
+    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1 || zc < 2 || (!dpre && zc < 2 + NTAP) || nheads * zc > ldz) return SP_EINVAL;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, Z, B, Hm, Wm, ldz, HC, cb,
                        cb_per_sample, w2, b2,
-                       softmax, logits, amap, mu, sigma2, drt, dh, dw);
+                       softmax, logits, amap, mu, sigma2, drt, dh, dw, dpre, zc);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -494,15 +500,16 @@ extern "C" int sp_head_finish_bwd(const float* dlogits, const float* damap, cons
                                   const float* logits,
                                   const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
                                   int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
-                                  float* dw2_partial, float* db2_partial, void* stream) {
+                                  float* dw2_partial, float* db2_partial, float* ddpre, int zc, void* stream) {
     if (!dlogits || !dmu || !dsigma2 || !logits || !amap || !sigma2 || !drt || !w2 || !dZ || !dcb_partial || !dw2_partial ||
         !db2_partial)
         return SP_ENULL;
     const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
-    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1) return SP_EINVAL;
+    if (zc <= 0) zc = HC;
+    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1 || zc < 2 || (!ddpre && zc < 2 + NTAP) || nheads * zc > ldz) return SP_EINVAL;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, dlogits, damap, dmu, dsigma2, logits,
                        amap,
-                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw);
+                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw, ddpre, zc);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

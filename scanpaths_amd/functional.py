@@ -733,10 +733,14 @@ def select_rows(a, b, sel):
 
 
 class _HeadFinish(Function):
-    """Z [B,Hm,Wm,nh*HC] -> logits [nh,B,1+P], amap [nh,B,P], mu [nh,B], sigma2 [nh,B]"""
+    """Z [B,Hm,Wm,nh*zc] -> logits [nh,B,1+P], amap [nh,B,P], mu [nh,B], sigma2 [nh,B].
+    dpre None: zc = HC and Z carries the 49 duration-tap columns; dpre [nh,B,S]: Z carries the 2 map columns per head only."""
     @staticmethod
-    def forward(ctx, Z, cb, w2, b2, nheads, HC, softmax, per_sample):
+    def forward(ctx, Z, cb, w2, b2, nheads, HC, softmax, per_sample, dpre):
         Z = Z.contiguous()
+        zc = HC if dpre is None else 2
+        if dpre is not None:
+            dpre = dpre.contiguous()
         cb = cb.contiguous()
         w2c = w2.detach().contiguous()
         b2 = b2.contiguous()
@@ -751,15 +755,15 @@ class _HeadFinish(Function):
         drt = torch.empty((nheads, B, dh * dw), dtype=torch.float32, device=dev)
         check(hip.lib().sp_head_finish_fwd(ptr(Z), B, Hm, Wm, ldz, nheads, HC, ptr(cb), int(per_sample), ptr(w2c), ptr(b2),
                                            int(softmax),
-                                           ptr(logits), ptr(amap), ptr(mu), ptr(s2), ptr(drt), hip.stream()),
+                                           ptr(logits), ptr(amap), ptr(mu), ptr(s2), ptr(drt), ptr(dpre), zc, hip.stream()),
               "sp_head_finish_fwd")
-        ctx.cfg = (B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, tuple(w2.shape), per_sample, tuple(cb.shape))
+        ctx.cfg = (B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, tuple(w2.shape), per_sample, tuple(cb.shape), zc)
         ctx.save_for_backward(logits, amap, s2, drt, w2c)
         return logits, amap, mu, s2
 
     @staticmethod
     def backward(ctx, dlogits, damap, dmu, ds2):
-        B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, w2shape, per_sample, cbshape = ctx.cfg
+        B, Hm, Wm, ldz, nheads, HC, softmax, dh, dw, w2shape, per_sample, cbshape, zc = ctx.cfg
         logits, amap, s2, drt, w2c = ctx.saved_tensors
         dev = logits.device
         zf = lambda t, ref: (t.contiguous() if t is not None else torch.zeros_like(ref))
@@ -769,14 +773,15 @@ class _HeadFinish(Function):
         damap = damap.contiguous() if damap is not None else None
         S = dh * dw
         dZ = torch.empty((B, Hm, Wm, ldz), dtype=torch.float32, device=dev)
-        if ldz != nheads * HC:
+        if ldz != nheads * zc:
             dZ.zero_()
+        ddpre = torch.empty((nheads, B, S), dtype=torch.float32, device=dev) if zc != HC else None
         dcbp = torch.empty((B, nheads * HC), dtype=torch.float32, device=dev)
         dw2p = torch.empty((B, nheads * 2 * S), dtype=torch.float32, device=dev)
         db2p = torch.empty((B, nheads * 2), dtype=torch.float32, device=dev)
         check(hip.lib().sp_head_finish_bwd(ptr(dlogits), ptr(damap), ptr(dmu), ptr(ds2), ptr(logits), ptr(amap), ptr(s2),
                                            ptr(drt), B, Hm, Wm, ldz, nheads, HC, ptr(w2c), int(softmax), ptr(dZ), ptr(dcbp),
-                                           ptr(dw2p), ptr(db2p), hip.stream()), "sp_head_finish_bwd")
+                                           ptr(dw2p), ptr(db2p), ptr(ddpre), zc, hip.stream()), "sp_head_finish_bwd")
         dcb = dcbp.view(cbshape) if per_sample else _colsum_any(dcbp, nheads * HC).view(nheads, HC)
         dw2 = _colsum_any(dw2p, nheads * 2 * S).view(nheads, 2 * S)
         db2 = _colsum_any(db2p, nheads * 2).view(nheads, 2)
@@ -784,11 +789,118 @@ class _HeadFinish(Function):
         for k in range(1, nheads):          # drt_layer_2 is shared by the heads
             dw2s = _add_raw(dw2s, dw2[k])
             db2s = _add_raw(db2s, db2[k])
-        return dZ, dcb, dw2s.reshape(w2shape), db2s.reshape(2), None, None, None, None
+        return dZ, dcb, dw2s.reshape(w2shape), db2s.reshape(2), None, None, None, None, ddpre
 
 
-def head_finish(Z, cb, w2, b2, nheads, HC, softmax, per_sample=False):
-    return _HeadFinish.apply(Z, cb, w2, b2, nheads, HC, softmax, per_sample)
+def head_finish(Z, cb, w2, b2, nheads, HC, softmax, per_sample=False, dpre=None):
+    return _HeadFinish.apply(Z, cb, w2, b2, nheads, HC, softmax, per_sample, dpre)
+
+
+# ---- predict_head without the dense 5x5 GEMM (csrc/head_direct.hip) ---------------------------------------------
+def head_num_classes(Hm: int, Wm: int) -> int:
+    n = hip.lib().sp_head_num_classes(Hm, Wm)
+    if n <= 0:
+        raise ValueError(f"unsupported map size {Hm}x{Wm} for the duration branch")
+    return n
+
+
+class _Compose11(Function):
+    """G [nh*HC,C,5,5] (physical [nh*HC,5,5,C]), cb [nh,HC] -> W11 [nh,ncls,121,C], cbsum [nh,ncls]"""
+    @staticmethod
+    def forward(ctx, G, cb, nheads, HC, hw):
+        Gp = _phys(G.detach())
+        cb = cb.contiguous()
+        C_ = Gp.shape[3]
+        Hm, Wm = hw
+        ncls = head_num_classes(Hm, Wm)
+        W11 = torch.empty((nheads, ncls, 121, C_), dtype=torch.float32, device=Gp.device)
+        cbsum = torch.empty((nheads, ncls), dtype=torch.float32, device=Gp.device)
+        check(hip.lib().sp_head_compose11_fwd(ptr(Gp), ptr(cb), nheads, HC, C_, Hm, Wm, ptr(W11), ptr(cbsum), hip.stream()),
+              "sp_head_compose11_fwd")
+        ctx.cfg = (nheads, HC, C_, Hm, Wm)
+        return W11, cbsum
+
+    @staticmethod
+    def backward(ctx, dW11, dcbsum):
+        nheads, HC, C_, Hm, Wm = ctx.cfg
+        dW11 = dW11.contiguous()
+        dcbsum = dcbsum.contiguous() if dcbsum is not None else torch.zeros(dW11.shape[:2], device=dW11.device)
+        dGp = torch.empty((nheads * HC, 5, 5, C_), dtype=torch.float32, device=dW11.device)
+        dcb = torch.empty((nheads, HC), dtype=torch.float32, device=dW11.device)
+        check(hip.lib().sp_head_compose11_bwd(ptr(dW11), ptr(dcbsum), nheads, HC, C_, Hm, Wm, ptr(dGp), ptr(dcb), hip.stream()),
+              "sp_head_compose11_bwd")
+        return dGp.permute(0, 3, 1, 2), dcb, None, None, None
+
+
+def compose11(G, cb, nheads, HC, hw):
+    return _Compose11.apply(G, cb, nheads, HC, hw)
+
+
+class _SalGather(Function):
+    """tap partials T [B,Hm,Wm,ldt] -> maps Z2 [B,Hm,Wm,2*nsel]; hmap int32 [B,nsel] = source head of each output slot"""
+    @staticmethod
+    def forward(ctx, T, hmap, nsel, nsrc):
+        T = T.contiguous()
+        B, Hm, Wm, ldt = T.shape
+        Z2 = torch.empty((B, Hm, Wm, 2 * nsel), dtype=torch.float32, device=T.device)
+        check(hip.lib().sp_sal_gather_fwd(ptr(T), B, Hm, Wm, ldt, nsel, ptr(hmap), ptr(Z2), hip.stream()), "sp_sal_gather_fwd")
+        ctx.cfg = (B, Hm, Wm, ldt, nsel, nsrc)
+        ctx.save_for_backward(hmap)
+        return Z2
+
+    @staticmethod
+    def backward(ctx, dZ2):
+        B, Hm, Wm, ldt, nsel, nsrc = ctx.cfg
+        hmap, = ctx.saved_tensors
+        dZ2 = dZ2.contiguous()
+        dT = torch.empty((B, Hm, Wm, ldt), dtype=torch.float32, device=dZ2.device)
+        check(hip.lib().sp_sal_gather_bwd(ptr(dZ2), B, Hm, Wm, ldt, nsel, nsrc, ptr(hmap), ptr(dT), hip.stream()),
+              "sp_sal_gather_bwd")
+        return dT, None, None, None
+
+
+def sal_gather(T, hmap, nsel, nsrc):
+    return _SalGather.apply(T, hmap, nsel, nsrc)
+
+
+class _DrtDirect(Function):
+    """h [B,Hm,Wm,C], W11 [nheads,ncls,121,C], cbsum [nheads,ncls] -> Dpre [nsel,B,dh*dw]"""
+    @staticmethod
+    def forward(ctx, h, W11, cbsum, hmap, nsel):
+        h = h.contiguous()
+        W11 = W11.contiguous()
+        cbsum = cbsum.contiguous()
+        B, Hm, Wm, C_ = h.shape
+        S = ((Hm + 4 - 7) // 5 + 1) * ((Wm + 4 - 7) // 5 + 1)
+        Dpre = torch.empty((nsel, B, S), dtype=torch.float32, device=h.device)
+        check(hip.lib().sp_drt_direct_fwd(ptr(h), ptr(W11), ptr(cbsum), ptr(hmap), B, Hm, Wm, C_, nsel, ptr(Dpre), hip.stream()),
+              "sp_drt_direct_fwd")
+        ctx.cfg = (B, Hm, Wm, C_, nsel, W11.shape[0], tuple(W11.shape), tuple(cbsum.shape))
+        ctx.save_for_backward(h, W11, hmap)
+        return Dpre
+
+    @staticmethod
+    def backward(ctx, dD):
+        B, Hm, Wm, C_, nsel, nheads, wshape, cshape = ctx.cfg
+        h, W11, hmap = ctx.saved_tensors
+        dD = dD.contiguous()
+        L = hip.lib()
+        dh = dW = dcs = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(h)
+            check(L.sp_drt_direct_bwd_data(ptr(dD), ptr(W11), ptr(hmap), B, Hm, Wm, C_, nsel, 0, ptr(dh), hip.stream()),
+                  "sp_drt_direct_bwd_data")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dW = torch.empty(wshape, dtype=torch.float32, device=h.device)
+            dcs = torch.empty(cshape, dtype=torch.float32, device=h.device)
+            ws = hip.workspace(L.sp_drt_direct_bwd_weight_workspace(B, Hm, Wm, C_, nsel), h.device, slot=0)
+            check(L.sp_drt_direct_bwd_weight(ptr(dD), ptr(h), ptr(hmap), B, Hm, Wm, C_, nsel, nheads, ptr(ws), ptr(dW), ptr(dcs),
+                                             hip.stream()), "sp_drt_direct_bwd_weight")
+        return dh, dW, dcs, None, None
+
+
+def drt_direct(h, W11, cbsum, hmap, nsel):
+    return _DrtDirect.apply(h, W11, cbsum, hmap, nsel)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -72,8 +72,18 @@ SIGNATURES = {
     "sp_mulrelu_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P]),
     "sp_select_rows": (_I, [_P, _P, _P, _L, _L, _P, _P]),
     "sp_select_rows_bwd": (_I, [_P, _P, _L, _L, _P, _P, _P]),
-    "sp_head_finish_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    "sp_head_finish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "sp_head_finish_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "sp_head_finish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I,
+                                _P]),
+    "sp_head_num_classes": (_I, [_I, _I]),
+    "sp_head_compose11_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_head_compose11_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_sal_gather_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_sal_gather_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_drt_direct_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_drt_direct_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_drt_direct_bwd_weight_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "sp_drt_direct_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sp_sample_actions": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_uint64, _P, _P, _P, _P]),
     "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sp_scanpath_loss_workspace": (_L, [_I, _I]),

@@ -311,15 +311,22 @@ class ScanpathModel(nn.Module):
         nh = S
         if head_convs is not None:
             G, cb = self._compose_heads(head_convs)
-        else:
+            nsrc, per_sample = len(head_convs), False
+            hmap = torch.arange(nh, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
+        else:       # COCO: per-sample head selected by task id (...multihead.py:285-288); only the tasks present are composed
             tl = [int(t) for t in tasks.tolist()]            # host sync, as the reference's int(tasks[index])
             uniq = sorted(set(tl))
-            Gt, cbt = self._compose_heads([self.object_sal_layer[self.int2object[t]] for t in uniq])
+            G, cbt = self._compose_heads([self.object_sal_layer[self.int2object[t]] for t in uniq])
             slot = torch.tensor([uniq.index(t) for t in tl], device=dev)
-            order = torch.argsort(slot, stable=True)
-            inv_order = torch.argsort(order)
-            groups = [(k, torch.nonzero(slot == k).flatten()) for k in range(len(uniq))]
-            cb_samples = cbt.index_select(0, slot).view(B, 1, HC)
+            cb = cbt.index_select(0, slot).view(B, 1, HC)
+            nsrc, per_sample = len(uniq), True
+            hmap = slot.to(torch.int32).view(B, 1).contiguous()
+        # the composed 5x5 head is never run as a dense conv (csrc/head_direct.hip): the two saliency maps per head come from a
+        # 1x1 "tap partial" GEMM + 25-tap gather, the duration sites from composite 11x11 stride-5 windows per border class
+        Gp = G.permute(0, 2, 3, 1).reshape(nsrc, HC, 25, 512)
+        R = (nsrc * 50 + 63) // 64 * 64
+        Wsal = torch.cat([Gp[:, :2].reshape(nsrc * 50, 512), torch.zeros(R - nsrc * 50, 512, device=dev)], 0).view(R, 512, 1, 1)
+        W11, cbsum = F.compose11(G, cbt if per_sample else cb, nsrc, HC, (Hm, Wm))
         w2, b2 = self.object_head.drt_layer_2.weight, self.object_head.drt_layer_2.bias
         sp_list: List[torch.Tensor] = []
         se_list: List[torch.Tensor] = []
@@ -346,13 +353,9 @@ class ScanpathModel(nn.Module):
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
             hg = F.gate_conv(h, Wh, spcol, wc, (Hm, Wm))
             h, c = F.lstm_cell(Xg, hg, c)
-            if head_convs is not None:
-                Z = F.conv2d(h, G, None, pad=2)
-                logits, amap, mu, s2 = F.head_finish(Z, cb, w2, b2, nh, HC, not self.training)
-            else:      # COCO: per-sample head conv selected by task id (...multihead.py:285-288), grouped by task
-                Zp = [F.conv2d(h.index_select(0, idx), Gt[k * HC:(k + 1) * HC], None, pad=2) for k, idx in groups]
-                Z = torch.cat(Zp, 0).index_select(0, inv_order)
-                logits, amap, mu, s2 = F.head_finish(Z, cb_samples, w2, b2, nh, HC, not self.training, per_sample=True)
+            Z2 = F.sal_gather(F.conv2d(h, Wsal, None, pad=0), hmap, nh, nsrc)
+            Dpre = F.drt_direct(h, W11, cbsum, hmap, nh)
+            logits, amap, mu, s2 = F.head_finish(Z2, cb, w2, b2, nh, HC, not self.training, per_sample=per_sample, dpre=Dpre)
             outs["logits"].append(logits)
             outs["amap"].append(amap)
             outs["mu"].append(mu)

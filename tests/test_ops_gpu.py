@@ -335,3 +335,82 @@ def test_flat_adam_matches_oracle():
         assert abs(float(tn) - tn_ref) <= 1e-5 * tn_ref
     for p, k in zip(plist, params):
         _close(p, ref[k], 2e-6, k)
+
+
+@pytest.mark.parametrize("hw,per_sample", [((30, 40), False), ((40, 64), False), ((12, 13), True)])
+def test_direct_head_matches_two_conv_formulation(hw, per_sample):
+    """compose11 + sal_gather + drt_direct + head_finish(dpre) against the literal predict_head order in fp64
+    (5x5 conv with the composed filters, then the 7x7 stride-5 pad-2 tap sums with zero padding of the INTERMEDIATE map):
+    maps, duration sites, and the gradients w.r.t. h, the composed filters, the composed biases and drt_layer_2."""
+    from scanpaths_amd import functional as F
+    Hm, Wm = hw
+    B, C_, HC = 3, 32, 64
+    nsrc = 3 if per_sample else 2
+    nsel = 1 if per_sample else 2
+    dh, dw = (Hm + 4 - 7) // 5 + 1, (Wm + 4 - 7) // 5 + 1
+    S, P = dh * dw, Hm * Wm
+    h = _rand(B, Hm, Wm, C_, seed=1)
+    G = _rand(nsrc * HC, 5, 5, C_, seed=2, scale=1.0 / math.sqrt(25 * C_))
+    G.view(nsrc, HC, 5, 5, C_)[:, 51:] = 0
+    cbh = _rand(nsrc, HC, seed=3, scale=0.1)
+    w2 = _rand(2, S, seed=4, scale=0.2)
+    b2 = _rand(2, seed=5, scale=0.1)
+    src = torch.tensor([[2], [0], [2]]) if per_sample else torch.arange(2).repeat(B, 1)      # [B, nsel]
+
+    # ---- fp64 reference ----
+    hr, Gr, cbr = h.double().requires_grad_(True), G.double().requires_grad_(True), cbh.double().requires_grad_(True)
+    w2r, b2r = w2.double().requires_grad_(True), b2.double().requires_grad_(True)
+    Zf = TF.conv2d(hr.permute(0, 3, 1, 2), Gr.permute(0, 3, 1, 2), None, padding=2)           # [B, nsrc*HC, Hm, Wm]
+    Zf = Zf.view(B, nsrc, HC, Hm, Wm)
+    logits_r, amap_r, mu_r, s2_r, dpre_r = [], [], [], [], []
+    for i in range(nsel):
+        lg_b, am_b, mu_b, s2_b, dp_b = [], [], [], [], []
+        for b in range(B):
+            k = int(src[b, i])
+            z, c = Zf[b, k], cbr[k]
+            term = z[0].mean() + c[0]
+            am = torch.relu(z[1] + c[1]).reshape(P)
+            inter = (z[2:51] + c[2:51].view(49, 1, 1))                                           # 49 "channels" = taps
+            # 7x7 stride-5 pad-2 conv whose tap (ky,kx) reads channel ky*7+kx: a one-hot depth filter
+            eye = torch.eye(49, dtype=torch.float64).view(1, 49, 7, 7)
+            d = TF.conv2d(inter.unsqueeze(0), eye, None, stride=5, padding=2).reshape(S)
+            dp_b.append(d)
+            drt = torch.relu(d + c[51])
+            mu_b.append((w2r[0] * drt).sum() + b2r[0])
+            s2_b.append(torch.exp((w2r[1] * drt).sum() + b2r[1]))
+            lg_b.append(torch.cat([term.view(1), am]))
+            am_b.append(am)
+        logits_r.append(torch.stack(lg_b)); amap_r.append(torch.stack(am_b)); mu_r.append(torch.stack(mu_b))
+        s2_r.append(torch.stack(s2_b)); dpre_r.append(torch.stack(dp_b))
+    logits_r, amap_r, mu_r, s2_r = torch.stack(logits_r), torch.stack(amap_r), torch.stack(mu_r), torch.stack(s2_r)
+
+    # ---- HIP path ----
+    dev = _dev()
+    hd = h.to(dev).requires_grad_(True)
+    Gd = G.to(dev).permute(0, 3, 1, 2).requires_grad_(True)           # logical OIHW view of the physical layout
+    cbd = cbh.to(dev).requires_grad_(True)
+    w2d, b2d = w2.to(dev).requires_grad_(True), b2.to(dev).requires_grad_(True)
+    hmap = src.to(torch.int32).to(dev).contiguous()
+    Gp = Gd.permute(0, 2, 3, 1).reshape(nsrc, HC, 25, C_)
+    R = (nsrc * 50 + 63) // 64 * 64
+    Wsal = torch.cat([Gp[:, :2].reshape(nsrc * 50, C_), torch.zeros(R - nsrc * 50, C_, device=dev)], 0).view(R, C_, 1, 1)
+    W11, cbsum = F.compose11(Gd, cbd, nsrc, HC, (Hm, Wm))
+    Z2 = F.sal_gather(F.conv2d(hd, Wsal, None, pad=0), hmap, nsel, nsrc)
+    Dpre = F.drt_direct(hd, W11, cbsum, hmap, nsel)
+    cb_arg = cbd.index_select(0, hmap[:, 0].long()).view(B, 1, HC) if per_sample else cbd
+    logits, amap, mu, s2 = F.head_finish(Z2, cb_arg, w2d, b2d, nsel, HC, False, per_sample=per_sample, dpre=Dpre)
+    _close(Dpre, torch.stack([d for d in dpre_r]), 2e-5, "Dpre")
+    _close(logits, logits_r, 2e-5, "logits")
+    _close(amap, amap_r, 2e-5, "amap")
+    _close(mu, mu_r, 2e-5, "mu")
+    _close(s2, s2_r, 5e-5, "sigma2")
+
+    gl, gm, gs, ga = _rand(*logits.shape, seed=6), _rand(*mu.shape, seed=7), _rand(*s2.shape, seed=8), _rand(*amap.shape, seed=9)
+    ((logits_r * gl.double()).sum() + (mu_r * gm.double()).sum() + (s2_r * gs.double()).sum()
+     + (amap_r * ga.double()).sum()).backward()
+    ((logits * gl.to(dev)).sum() + (mu * gm.to(dev)).sum() + (s2 * gs.to(dev)).sum() + (amap * ga.to(dev)).sum()).backward()
+    _close(hd.grad, hr.grad, 3e-5, "dh")
+    _close(Gd.grad.permute(0, 2, 3, 1), Gr.grad, 3e-5, "dG")
+    _close(cbd.grad, cbr.grad, 3e-5, "dcb")
+    _close(w2d.grad, w2r.grad, 3e-5, "dw2")
+    _close(b2d.grad, b2r.grad, 3e-5, "db2")
