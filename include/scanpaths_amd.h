@@ -244,6 +244,31 @@ int sp_sum(const float* x, int64_t n, float* out, void* workspace, void* stream)
 int sp_sumsq(const float* g, int64_t n, double* out, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ScanMatch scoring (utils/evaltools/scanmatch.py:88-197; callers utils/evaluation.py:22-64,198-235,361-559), SURVEY.md §8
+ * row f2.  float64 with the reference's operation order: scores are bit-exact with the numpy implementation.
+ *   submatrix:  sub [nb*nb] (nb = Xbin*Ybin) = |dist - max| - (max - threshold), maxsub [1] = max(sub)          (:88-103)
+ *   sequences:  scanpath k = rows start[k] .. start[k]+count[k]-1 of fix [rows][ncol] (x, y[, duration]) -> symbols
+ *               seq [nsp][ld] (first seq_len[k] valid; seq may be NULL to size the buffer): offset, clamp to the screen,
+ *               int truncation, bin = int(pixel * bins/res), symbol = ybin*Xbin + xbin (or mask[y][x] when a custom
+ *               [Yres][Xres] int32 mask is given, maskFromArray :199-200); with tempbin != 0 each symbol is repeated
+ *               round_half_even(trunc(duration)/tempbin) times                                                   (:105-135)
+ *   score:      scores[p] for pairs[p] = (index into A, index into B) (pairs NULL: p with p); Needleman-Wunsch with
+ *               F[i][0] = gap*(i+1), F[0][j] = gap*(j+1); score = max(F) / (maxsub * max(n, m)); one wavefront per pair;
+ *               sequence length <= sp_scanmatch_max_len()                                                        (:137-150,188-193)
+ *   align:      single pair: F^T [(m+1)][(n+1)], alignment [nalign][2] (-1 = gap) and score                     (:152-197)
+ * ---------------------------------------------------------------------------------------------- */
+int sp_scanmatch_max_len(void);
+int sp_scanmatch_submatrix(int Xbin, int Ybin, double threshold, double* sub, double* maxsub, void* stream);
+int sp_scanmatch_sequences(const double* fix, int ncol, const int64_t* start, const int* count, int nsp, int Xres, int Yres,
+                           int Xbin, int Ybin, double off_x, double off_y, double tempbin, const int* mask, int ld, int* seq,
+                           int* seq_len, void* stream);
+int sp_scanmatch_score(const int* seqA, const int* lenA, int ldA, const int* seqB, const int* lenB, int ldB, const int* pairs,
+                       int npairs, const double* sub, int nb, const double* maxsub, double gap, double* scores, void* stream);
+int sp_scanmatch_align(const int* A, int n, const int* B, int m, const double* sub, int nb, const double* maxsub, double gap,
+                       double* F_work /* [(n+1)*(m+1)] scratch */, double* Ft, double* align /* [(n+m)][2] */, int* nalign,
+                       double* score, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Post-hoc sampling (models/sampling.py:16-77), SURVEY.md §8 row f1.
  * sp_sample_actions: per (b,t) masked categorical draw (terminate action 0 excluded for t < min_length), probability of the
  *   chosen action from the unmasked distribution, duration = exp(eps*sigma2 + mu); Philox4x32-10(seed; row).

@@ -206,7 +206,7 @@ int choose_splits(const sp_wgrad_desc* d) {
     int64_t want = sp_cdiv(4096, tiles);
     const int64_t max_by_rows = std::max<int64_t>(1, M / 256);   // keep >= 8 K-tiles per split
     want = std::min(want, max_by_rows);
-    want = std::min<int64_t>(want, 64);
+    want = std::min<int64_t>(want, tiles <= 8 ? 128 : 64);   // few-tile cases (Co <= 128 x K <= 512) need > 64 slabs to reach 512 workgroups
     return (int)std::max<int64_t>(1, want);
 }
 

@@ -159,30 +159,41 @@ __global__ __launch_bounds__(256) void sal_gather_bwd_kernel(const float* __rest
 }
 
 // ---- duration sites ------------------------------------------------------------------------------------------
-// Dpre[i][b][s] = cbsum[src][cls(s)] + <W11[src][cls(s)], h[b, 5s-4 .. 5s+6, :]>.  grid (S, B, nsel), 256 threads.
+// Dpre[i][b][s] = cbsum[src][cls(s)] + <W11[src][cls(s)], h[b, 5s-4 .. 5s+6, :]>.  grid (S, B, ceil(nsel/2)), 256 threads;
+// a block evaluates two head slots on one read of the window (AiR: good + poor head).
 __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ h, const float* __restrict__ W11,
                                                       const float* __restrict__ cbsum, const int* __restrict__ hmap, int B,
                                                       int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
                                                       float* __restrict__ Dpre) {
     __shared__ float sh4[4];
-    const int s = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+    const int s = blockIdx.x, b = blockIdx.y, i0 = blockIdx.z * 2;
+    const bool two = i0 + 1 < nsel;
     const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;
     const int sy = s / ax.n, sx = s % ax.n;
     const int cls = ay.cls[sy] * ax.ncls + ax.cls[sx];
-    const int src = hmap[b * nsel + i];
+    const int src0 = hmap[b * nsel + i0], src1 = two ? hmap[b * nsel + i0 + 1] : src0;
     const int oy = 5 * sy - 4, ox = 5 * sx - 4;
     const f32x4* H4 = reinterpret_cast<const f32x4*>(h) + (int64_t)b * Hm * Wm * C4;
-    const f32x4* W4 = reinterpret_cast<const f32x4*>(W11) + ((int64_t)src * ncls + cls) * NV * C4;
-    float acc = 0.f;
+    const f32x4* W40 = reinterpret_cast<const f32x4*>(W11) + ((int64_t)src0 * ncls + cls) * NV * C4;
+    const f32x4* W41 = reinterpret_cast<const f32x4*>(W11) + ((int64_t)src1 * ncls + cls) * NV * C4;
+    float acc0 = 0.f, acc1 = 0.f;
     for (int idx = threadIdx.x; idx < NV * C4; idx += 256) {
         const int v = idx / C4, c4 = idx - v * C4;
         const int qy = oy + v / 11, qx = ox + v % 11;
         if ((unsigned)qy >= (unsigned)Hm || (unsigned)qx >= (unsigned)Wm) continue;
-        const f32x4 a = H4[(int64_t)(qy * Wm + qx) * C4 + c4], w = W4[idx];
-        acc += a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
+        const f32x4 a = H4[(int64_t)(qy * Wm + qx) * C4 + c4], w = W40[idx];
+        acc0 += a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
+        if (two) {
+            const f32x4 u = W41[idx];
+            acc1 += a[0] * u[0] + a[1] * u[1] + a[2] * u[2] + a[3] * u[3];
+        }
     }
-    acc = block_sum_256(acc, sh4);
-    if (threadIdx.x == 0) Dpre[((int64_t)i * B + b) * S + s] = acc + cbsum[src * ncls + cls];
+    acc0 = block_sum_256(acc0, sh4);
+    if (two) acc1 = block_sum_256(acc1, sh4);
+    if (threadIdx.x == 0) {
+        Dpre[((int64_t)i0 * B + b) * S + s] = acc0 + cbsum[src0 * ncls + cls];
+        if (two) Dpre[((int64_t)(i0 + 1) * B + b) * S + s] = acc1 + cbsum[src1 * ncls + cls];
+    }
 }
 
 // dh[b][q][c] (+)= sum over the sites whose window covers q, over the head slots.
@@ -217,28 +228,34 @@ __global__ __launch_bounds__(256) void drt_bwd_data_kernel(const float* __restri
 }
 
 // per-(sample, slot) partial of dW11: slab[b][i][cls][v][c] = sum_{s in cls} dD[i][b][s] * h[b][win(s)+v][c].
-// grid (121*ncls, B, nsel), 128 threads over c4.
+// grid (121*ncls, B, ceil(nsel/2)), 128 threads over c4; two head slots per read of h.
 __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __restrict__ dD, const float* __restrict__ h, int B,
                                                              int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
                                                              float* __restrict__ slab) {
-    const int v = blockIdx.x % NV, cls = blockIdx.x / NV, b = blockIdx.y, i = blockIdx.z;
+    const int v = blockIdx.x % NV, cls = blockIdx.x / NV, b = blockIdx.y, i0 = blockIdx.z * 2;
+    const bool two = i0 + 1 < nsel;
     const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;
     const int vy = v / 11, vx = v % 11;
     const f32x4* H4 = reinterpret_cast<const f32x4*>(h) + (int64_t)b * Hm * Wm * C4;
-    const float* g = dD + ((int64_t)i * B + b) * S;
-    f32x4* O4 = reinterpret_cast<f32x4*>(slab) + ((((int64_t)b * nsel + i) * ncls + cls) * NV + v) * C4;
+    const float* g0 = dD + ((int64_t)i0 * B + b) * S;
+    const float* g1 = dD + ((int64_t)(two ? i0 + 1 : i0) * B + b) * S;
+    f32x4* O40 = reinterpret_cast<f32x4*>(slab) + ((((int64_t)b * nsel + i0) * ncls + cls) * NV + v) * C4;
+    f32x4* O41 = O40 + (int64_t)ncls * NV * C4;
     for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         for (int sy = 0; sy < ay.n; ++sy) {
             const int qy = 5 * sy - 4 + vy;
             if ((unsigned)qy >= (unsigned)Hm) continue;
             for (int sx = 0; sx < ax.n; ++sx) {
                 const int qx = 5 * sx - 4 + vx;
                 if ((unsigned)qx >= (unsigned)Wm || ay.cls[sy] * ax.ncls + ax.cls[sx] != cls) continue;
-                acc += g[sy * ax.n + sx] * H4[(int64_t)(qy * Wm + qx) * C4 + c4];
+                const f32x4 a = H4[(int64_t)(qy * Wm + qx) * C4 + c4];
+                acc0 += g0[sy * ax.n + sx] * a;
+                acc1 += g1[sy * ax.n + sx] * a;
             }
         }
-        O4[c4] = acc;
+        O40[c4] = acc0;
+        if (two) O41[c4] = acc1;
     }
 }
 
@@ -339,7 +356,7 @@ extern "C" int sp_drt_direct_fwd(const float* h, const float* W11, const float* 
     if (!h || !W11 || !cbsum || !hmap || !Dpre) return SP_ENULL;
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
-    hipLaunchKernelGGL(drt_fwd_kernel, dim3(ay.n * ax.n, B, nsel), dim3(256), 0, (hipStream_t)stream, h, W11, cbsum, hmap, B,
+    hipLaunchKernelGGL(drt_fwd_kernel, dim3(ay.n * ax.n, B, (nsel + 1) / 2), dim3(256), 0, (hipStream_t)stream, h, W11, cbsum, hmap, B,
                        C / 4, nsel, ay.ncls * ax.ncls, ay, ax, Dpre);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -368,7 +385,7 @@ extern "C" int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, cons
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || nheads < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
     const int ncls = ay.ncls * ax.ncls;
-    hipLaunchKernelGGL(drt_bwd_weight_kernel, dim3(NV * ncls, B, nsel), dim3(128), 0, (hipStream_t)stream, dDpre, h, B, C / 4,
+    hipLaunchKernelGGL(drt_bwd_weight_kernel, dim3(NV * ncls, B, (nsel + 1) / 2), dim3(128), 0, (hipStream_t)stream, dDpre, h, B, C / 4,
                        nsel, ncls, ay, ax, (float*)workspace);
     SP_LAUNCH_CHECK();
     const int64_t per_head4 = (int64_t)ncls * NV * (C / 4);

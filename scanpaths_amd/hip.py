@@ -84,6 +84,11 @@ SIGNATURES = {
     "sp_drt_direct_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sp_drt_direct_bwd_weight_workspace": (_L, [_I, _I, _I, _I, _I]),
     "sp_drt_direct_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "sp_scanmatch_max_len": (_I, []),
+    "sp_scanmatch_submatrix": (_I, [_I, _I, C.c_double, _P, _P, _P]),
+    "sp_scanmatch_sequences": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, C.c_double, C.c_double, C.c_double, _P, _I, _P, _P, _P]),
+    "sp_scanmatch_score": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, C.c_double, _P, _P]),
+    "sp_scanmatch_align": (_I, [_P, _I, _P, _I, _P, _I, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
     "sp_sample_actions": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_uint64, _P, _P, _P, _P]),
     "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sp_scanpath_loss_workspace": (_L, [_I, _I]),

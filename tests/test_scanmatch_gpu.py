@@ -1,0 +1,128 @@
+"""HIP ScanMatch (csrc/scanmatch.hip through scanpaths_amd.utils.evaltools.scanmatch) against the reference's outputs in
+tests/golden/scanmatch.npz and against the oracle on longer strings -- float64, BIT-EXACT (integer / IEEE max-plus work)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scanmatch_oracle as SO
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "scanmatch.npz"))
+
+
+def unrag(name):
+    cat, off = GOLD[name], GOLD[name + "_off"]
+    return [cat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def fixes(name):
+    cat, off = GOLD[name], GOLD[name + "_off"]
+    return [cat[3 * off[i]:3 * off[i + 1]].reshape(-1, 3) for i in range(len(off) - 1)]
+
+
+def same(a, b, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(a, b, equal_nan=True), (what, np.nanmax(np.abs(a - b)))
+
+
+def _sm(**kw):
+    from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch
+    return ScanMatch(**kw)
+
+
+def test_reference_self_check_known_answers():
+    """the reference's __main__ block (scanmatch.py:222-257) through the drop-in API, incl. F and the alignment"""
+    ex = fixes("ex_fix")
+    cfg = dict(Xres=1024, Yres=768, Xbin=12, Ybin=8, Offset=(0, 0), Threshold=3.5)
+    wd, wod = _sm(TempBin=100, **cfg), _sm(**cfg)
+    same(wd.SubMatrix, GOLD["ex_submatrix"], "SubMatrix")
+    m = wd.mask
+    same(m[0], GOLD["ex_mask_row0"], "mask row")
+    same(m[:, 0], GOLD["ex_mask_col0"], "mask col")
+    s_wd = [wd.fixationToSequence(e).astype(np.int32) for e in ex]
+    s_wod = [wod.fixationToSequence(e[:, :2]).astype(np.int32) for e in ex]
+    for got, want in zip(s_wd, unrag("ex_seq_wd")):
+        same(got, want, "seq wd")
+    for got, want in zip(s_wod, unrag("ex_seq_wod")):
+        same(got, want, "seq wod")
+    s1, a1, f1 = wd.match(s_wd[0], s_wd[1])
+    assert s1 == 0.6725138474550876 == float(GOLD["ex_match01_score"])
+    same(a1, GOLD["ex_match01_align"], "align")
+    same(f1, GOLD["ex_match01_F"], "F")
+    assert wd.match(s_wd[0], s_wd[2])[0] == 0.22829669183275586
+    assert wd.match(s_wd[1], s_wd[2])[0] == 0.253819062877192
+    assert wod.match(s_wod[0], s_wod[1])[0] == 0.6178313750019084
+    assert wod.match(s_wod[0], s_wod[2])[0] == 0.2582431346483109
+    assert wod.match(s_wod[2], s_wod[2])[0] == 1.0
+    s2, a2, f2 = wod.match(s_wod[1], s_wod[2])
+    assert s2 == float(GOLD["ex_match12_wod_score"])
+    same(a2, GOLD["ex_match12_wod_align"], "align wod")
+    same(f2, GOLD["ex_match12_wod_F"], "F wod")
+    with pytest.raises(ValueError, match="Unknown parameter"):
+        _sm(Foo=1)
+
+
+@pytest.mark.parametrize("seqs,scores,kw", [
+    ("rnd_seq_wd", "rnd_scores_wd", dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), TempBin=50, Threshold=3.5)),
+    ("rnd_seq_wod", "rnd_scores_wod", dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), Threshold=3.5)),
+    ("gap_seq", "gap_scores", dict(Xres=300, Yres=200, Xbin=10, Ybin=7, Offset=(10, 20), Threshold=2.0, GapValue=-0.75,
+                                   TempBin=80)),
+])
+def test_all_pairs_bit_exact_with_the_reference(seqs, scores, kw):
+    """28 random scanpaths (out-of-screen fixations, empty strings after temporal binning, round-half-even durations,
+    strings up to ~250 symbols = 4 column strips): sequences and the full 28x28 score matrix incl. the NaN of empty-vs-empty"""
+    sm = _sm(**kw)
+    fx = fixes("rnd_fix")
+    sq, ln = sm.sequences(fx)
+    want = unrag(seqs)
+    assert ln.cpu().tolist() == [len(w) for w in want]
+    for k, w in enumerate(want):
+        same(sq[k, :len(w)].cpu().numpy(), w, f"sequence {k}")
+    got = sm.match_all(fx, fx)
+    same(got, GOLD[scores], scores)
+    if seqs == "rnd_seq_wd":
+        assert np.isnan(got[5, 5]) and got[5, 0] == 0.0
+    # the single-pair drop-in agrees with the batched kernel
+    assert sm.match(want[0], want[1])[0] == got[0, 1]
+
+
+def test_long_strings_against_the_oracle():
+    """strings of 1..700 symbols (up to 11 strips, partial last strips, 1-column last strip), both gap signs"""
+    g = np.random.Generator(np.random.PCG64(7))
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 193, 700, 5, 321]
+    for gap in (0.0, -0.4, 0.3):
+        sm = _sm(Xres=320, Yres=240, Xbin=16, Ybin=12, Threshold=3.5, GapValue=gap)
+        S = SO.submatrix(16, 12, 3.5)
+        same(sm.SubMatrix, S, "S")
+        seqs = [g.integers(0, 192, L).astype(np.int32) for L in lens]
+        ld = max(lens)
+        dev = torch.device("cuda:0")
+        buf = torch.zeros((len(seqs), ld), dtype=torch.int32)
+        for k, s in enumerate(seqs):
+            buf[k, :len(s)] = torch.from_numpy(s)
+        buf = buf.to(dev)
+        ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+        pairs = torch.tensor([(i, j) for i in range(len(lens)) for j in range(len(lens)) if (i + j) % 3 == 0 or i == 9 or j == 9],
+                             dtype=torch.int32)
+        pairs = pairs[:60]
+        got = sm.match_pairs(buf, ln, buf, ln, pairs).cpu().numpy()
+        for (i, j), v in zip(pairs.tolist(), got):
+            assert v == SO.nw_score(seqs[i], seqs[j], S, gap), (gap, lens[i], lens[j])
+
+
+def test_custom_mask_and_errors():
+    sm = _sm(Xres=64, Yres=48, Xbin=4, Ybin=3, Threshold=1.5)
+    g = np.random.Generator(np.random.PCG64(3))
+    mask = g.integers(0, 12, (48, 64))
+    sm.maskFromArray(mask)
+    fix = np.stack([g.uniform(-3, 70, 9), g.uniform(-3, 52, 9)], 1)
+    same(sm.fixationToSequence(fix), SO.fixation_to_sequence(fix, 64, 48, 4, 3, mask=mask), "custom mask")
+    with pytest.raises(ValueError):
+        sm.maskFromArray(np.zeros((3, 3)))
+    with pytest.raises(IndexError):
+        sm.match([0, 99], [1])
+    with pytest.raises(IndexError):
+        _sm(TempBin=50).sequences([np.zeros((2, 2))])

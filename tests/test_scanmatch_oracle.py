@@ -1,0 +1,103 @@
+"""The ScanMatch oracle (oracle/scanmatch_oracle.py) against the outputs of the real reference stored in
+tests/golden/scanmatch.npz (its own .mat example + seeded random scanpaths): float64, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import scanmatch_oracle as SO
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "scanmatch.npz"))
+
+
+def unrag(name):
+    cat, off = GOLD[name], GOLD[name + "_off"]
+    return [cat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def fixes(name):
+    cat, off = GOLD[name], GOLD[name + "_off"]
+    return [cat[3 * off[i]:3 * off[i + 1]].reshape(-1, 3) for i in range(len(off) - 1)]
+
+
+def same(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(a, b, equal_nan=True), np.nanmax(np.abs(a - b))
+
+
+def test_known_answers_of_the_reference_self_check():
+    """the three scores of the reference's __main__ block with and without duration"""
+    wd, wod = GOLD["ex_scores_wd"], GOLD["ex_scores_wod"]
+    assert (wd[0, 1], wd[0, 2], wd[1, 2]) == (0.6725138474550876, 0.22829669183275586, 0.253819062877192)
+    assert (wod[0, 1], wod[0, 2], wod[2, 2]) == (0.6178313750019084, 0.2582431346483109, 1.0)
+
+
+def test_submatrix_and_grid_bit_exact():
+    same(SO.submatrix(12, 8, 3.5), GOLD["ex_submatrix"])
+    xs = SO.bin_of_pixel(np.arange(1024), 12, 1024)
+    ys = SO.bin_of_pixel(np.arange(768), 8, 768)
+    same(ys[0] * 12 + xs, GOLD["ex_mask_row0"])
+    same(ys * 12 + xs[0], GOLD["ex_mask_col0"])
+
+
+@pytest.mark.parametrize("tag,cfg", [
+    ("ex_seq_wd", dict(Xres=1024, Yres=768, Xbin=12, Ybin=8, tempbin=100.0)),
+    ("ex_seq_wod", dict(Xres=1024, Yres=768, Xbin=12, Ybin=8, tempbin=0.0)),
+    ("rnd_seq_wd", dict(Xres=320, Yres=240, Xbin=16, Ybin=12, tempbin=50.0)),
+    ("rnd_seq_wod", dict(Xres=320, Yres=240, Xbin=16, Ybin=12, tempbin=0.0)),
+    ("gap_seq", dict(Xres=300, Yres=200, Xbin=10, Ybin=7, tempbin=80.0, offset=(10, 20))),
+])
+def test_sequences_bit_exact(tag, cfg):
+    fx = fixes("ex_fix" if tag.startswith("ex") else "rnd_fix")
+    want = unrag(tag)
+    for f, w in zip(fx, want):
+        same(SO.fixation_to_sequence(f, **cfg), w)
+    if tag == "rnd_seq_wd":
+        assert len(want[5]) == 0            # all durations round to zero repeats
+        assert len(want[6]) == 0            # 25/50 = 0.5 -> round-half-even -> 0
+        assert len(want[7]) == 2 * len(fx[7])   # 75/50 = 1.5 -> 2
+
+
+@pytest.mark.parametrize("seqs,scores,cfg", [
+    ("ex_seq_wd", "ex_scores_wd", (12, 8, 3.5, 0.0)),
+    ("ex_seq_wod", "ex_scores_wod", (12, 8, 3.5, 0.0)),
+    ("rnd_seq_wod", "rnd_scores_wod", (16, 12, 3.5, 0.0)),
+    ("gap_seq", "gap_scores", (10, 7, 2.0, -0.75)),
+])
+def test_scores_bit_exact(seqs, scores, cfg):
+    S = SO.submatrix(*cfg[:3])
+    sq = unrag(seqs)
+    want = GOLD[scores]
+    n = min(len(sq), 12)                    # pure-python DP: keep the CPU suite short
+    got = np.array([[SO.nw_score(sq[i], sq[j], S, cfg[3]) for j in range(n)] for i in range(n)])
+    same(got, want[:n, :n])
+
+
+def test_empty_sequences_follow_the_reference():
+    S = SO.submatrix(16, 12, 3.5)
+    sq = unrag("rnd_seq_wd")
+    want = GOLD["rnd_scores_wd"]
+    for i, j in [(5, 5), (5, 0), (0, 5), (6, 7), (7, 7), (5, 6)]:
+        got = SO.nw_score(sq[i], sq[j], S, 0.0)
+        assert (np.isnan(got) and np.isnan(want[i, j])) or got == want[i, j], (i, j, got, want[i, j])
+    assert np.isnan(want[5, 5]) and want[5, 0] == 0.0
+
+
+def test_alignment_and_F_bit_exact():
+    S = SO.submatrix(12, 8, 3.5)
+    a, b = unrag("ex_seq_wd")[:2]
+    score, align, F = SO.nw_match(a, b, S, 0.0)
+    assert score == float(GOLD["ex_match01_score"])
+    same(align, GOLD["ex_match01_align"])
+    same(F, GOLD["ex_match01_F"])
+    b2, c2 = unrag("ex_seq_wod")[1:3]
+    score, align, F = SO.nw_match(b2, c2, S, 0.0)
+    assert score == float(GOLD["ex_match12_wod_score"])
+    same(align, GOLD["ex_match12_wod_align"])
+    same(F, GOLD["ex_match12_wod_F"])
+    Sg = SO.submatrix(10, 7, 2.0)
+    g0, g1 = unrag("gap_seq")[:2]
+    _, align, F = SO.nw_match(g0, g1, Sg, -0.75)
+    same(align, GOLD["gap_match01_align"])
+    same(F, GOLD["gap_match01_F"])
