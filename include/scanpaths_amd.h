@@ -268,6 +268,16 @@ int sp_scanmatch_align(const int* A, int n, const int* B, int m, const double* s
                        double* F_work /* [(n+1)*(m+1)] scratch */, double* Ft, double* align /* [(n+m)][2] */, int* nalign,
                        double* score, void* stream);
 
+/* SED / STDE of scanpath pairs (utils/evaltools/visual_attention_metrics.py:205-441; callers utils/evaluation.py:68-72,239-243).
+ * fix [rows][ncol] (x, y, ...), scanpath k = rows start[k] .. +count[k] (count <= sp_scan_max_fixations()); pairs[p] =
+ * (human index, simulated index).  sed[p] = Levenshtein distance of the ngrid x ngrid cell strings (cell = int32(x) //
+ * (width // ngrid) + int32(y) // (height // ngrid) * ngrid), bit-exact; stde[p] = mean over k = 1..min(len) of
+ * exp(-mean_s min_h sum_i ||s_i - h_i|| / k) on coordinates / max_dim, numpy summation order, NaN when a scanpath is empty
+ * (the reference returns None).  Either output may be NULL. */
+int sp_scan_max_fixations(void);
+int sp_scan_sed_stde(const double* fix, int ncol, const int64_t* start, const int* count, const int* pairs, int npairs, int height,
+                     int width, int ngrid, double max_dim, int* sed, double* stde, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Post-hoc sampling (models/sampling.py:16-77), SURVEY.md §8 row f1.
  * sp_sample_actions: per (b,t) masked categorical draw (terminate action 0 excluded for t < min_length), probability of the

@@ -126,3 +126,39 @@ def test_custom_mask_and_errors():
         sm.match([0, 99], [1])
     with pytest.raises(IndexError):
         _sm(TempBin=50).sequences([np.zeros((2, 2))])
+
+
+# ---- SED / STDE ------------------------------------------------------------------------------------------------
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "sed_stde.npz"))
+
+
+def test_sed_stde_reference_self_check_and_random_pairs():
+    """the reference's __main__ block (visual_attention_metrics.py:495-519) and all 40x40 random pairs (1..30 fixations):
+    SED bit-exact; STDE within 4 ulp (numpy evaluation order is reproduced, exp() may differ in the last bit)"""
+    from scanpaths_amd.utils.evaltools.visual_attention_metrics import (scaled_time_delay_embedding_similarity, sed_stde_pairs,
+                                                                        string_edit_distance)
+    ex = fixes("ex_fix")
+    stim = np.zeros((768, 1024, 3), dtype=np.float32)
+    assert string_edit_distance(stim, ex[0], ex[1]) == 9 == int(GOLD2["ex_sed"][0, 1])
+    v = scaled_time_delay_embedding_similarity(ex[0], ex[1], stim)
+    assert abs(v - 0.9064806433533912) <= 4 * np.spacing(0.9064806433533912)
+    assert scaled_time_delay_embedding_similarity(ex[0][:0], ex[1], stim) is None
+    pairs = [(i, j) for i in range(3) for j in range(3)]
+    sed, stde = sed_stde_pairs(ex, pairs, stim.shape)
+    assert np.array_equal(sed.cpu().numpy().reshape(3, 3), GOLD2["ex_sed"])
+    want = GOLD2["ex_stde"]
+    assert np.all(np.abs(stde.cpu().numpy().reshape(3, 3) - want) <= 4 * np.spacing(want))
+
+    cat, off = GOLD2["rnd_fix"], GOLD2["rnd_fix_off"]
+    fx = [cat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    n = len(fx)
+    pairs = [(i, j) for i in range(n) for j in range(n)]
+    sed, stde = sed_stde_pairs(fx, pairs, (240, 320, 3))
+    assert np.array_equal(sed.cpu().numpy().reshape(n, n), GOLD2["rnd_sed"])
+    got, want = stde.cpu().numpy().reshape(n, n), GOLD2["rnd_stde"]
+    ulp = np.abs(got - want) / np.spacing(want)
+    assert ulp.max() <= 4, ulp.max()
+    sed8, _ = sed_stde_pairs(fx, [(i, j) for i in range(12) for j in range(12)], (240, 320, 3), n=8, want_stde=False)
+    assert np.array_equal(sed8.cpu().numpy().reshape(12, 12), GOLD2["rnd_sed_n8"])
+    with pytest.raises(ValueError):
+        sed_stde_pairs([np.zeros((65, 2))], [(0, 0)], (240, 320, 3))

@@ -101,3 +101,34 @@ def test_alignment_and_F_bit_exact():
     _, align, F = SO.nw_match(g0, g1, Sg, -0.75)
     same(align, GOLD["gap_match01_align"])
     same(F, GOLD["gap_match01_F"])
+
+
+# ---- SED / STDE ------------------------------------------------------------------------------------------------
+from oracle import metrics_oracle as MO   # noqa: E402
+
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "sed_stde.npz"))
+
+
+def _rnd_fixes():
+    cat, off = GOLD2["rnd_fix"], GOLD2["rnd_fix_off"]
+    return [cat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def test_sed_stde_known_answers_of_the_reference_self_check():
+    ex = fixes("ex_fix")
+    got_sed = np.array([[MO.sed((768, 1024, 3), a, b) for b in ex] for a in ex])
+    assert np.array_equal(got_sed, GOLD2["ex_sed"]) and got_sed[0, 1] == 9
+    got = np.array([[MO.stde(a, b, (768, 1024, 3)) for b in ex] for a in ex])
+    same(got, GOLD2["ex_stde"])
+    assert got[0, 1] == 0.9064806433533912
+
+
+def test_sed_stde_random_pairs_bit_exact():
+    fx = _rnd_fixes()
+    n = 14
+    got_sed = np.array([[MO.sed((240, 320, 3), fx[i], fx[j]) for j in range(n)] for i in range(n)])
+    assert np.array_equal(got_sed, GOLD2["rnd_sed"][:n, :n])
+    got8 = np.array([[MO.sed((240, 320, 3), fx[i], fx[j], n=8) for j in range(12)] for i in range(12)])
+    assert np.array_equal(got8, GOLD2["rnd_sed_n8"])
+    got = np.array([[MO.stde(fx[i], fx[j], (240, 320, 3)) for j in range(n)] for i in range(n)])
+    same(got, GOLD2["rnd_stde"][:n, :n])
