@@ -150,6 +150,11 @@ int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const float* c_prev, int64_t rows, int C, float* gates,
                           float* c_out, float* h_out, void* stream);
 /* dpre[rows][4C], dc_prev[rows][C] from dh, dc (either may be NULL = 0) */
+/* the same cell with the rank-1 gate terms fused in: pre[b,p,g*C+c] += sum_k spcol[b,p,k] * wc[b,g*C+c,k] for the gates
+ * g = i,f,o (spcol [B][P][KP] 9-tap im2col of the spatial memories, wc [B][3C][KP] per-sample contracted filters;
+ * baseline_attention.py:40-50).  xg/hg/gates [B*P][4C]; C % 64 == 0, KP <= 64. */
+int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* c_prev, const float* spcol, const float* wc, int B, int P,
+                      int C, int KP, float* gates, float* c_out, float* h_out, void* stream);
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, void* stream);
 

@@ -56,6 +56,96 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xg, const fl
     }
 }
 
+// ConvLSTM cell with the rank-1 gate terms fused in (baseline_attention.py:40-50): the i/f/o pre-activations receive
+//   sum_k spcol[b,p,k] * wc[b, g*C + c, k]      (conv3x3(W, spatial (x) semantic) as a 9-tap 1-channel conv per stream with the
+// per-sample contracted filter).  As a separate batched GEMM with beta = 1 this term cost a full read-modify-write of the gate
+// tensor (0.77 ms per decode step at bs 32); here it is KP FMAs per gate value on data the cell already holds in registers.
+// Block = 64 channels x 64 pixels per iteration of ONE sample: the sample's filter slice (3 gates x 64 channels x KP) is staged
+// once per block in LDS as [k][gate][channel] (conflict-free b128 reads, broadcast across the pixel lanes), the pixel taps as
+// [pixel][k]; a thread owns one channel quad of 4 pixels (48 accumulators).  grid (C/64, ceil(P/RB), B).
+constexpr int R1_RB = 256;     // pixels per block
+__global__ __launch_bounds__(256) void lstm_rank1_fwd_kernel(const float* __restrict__ xg, const float* __restrict__ hg,
+                                                             const float* __restrict__ c_prev, const float* __restrict__ spcol,
+                                                             const float* __restrict__ wc, int P, int C, int KP,
+                                                             float* __restrict__ gates, float* __restrict__ c_out,
+                                                             float* __restrict__ h_out) {
+    extern __shared__ __attribute__((aligned(16))) float r1s[];
+    float* wcT = r1s;                       // [KP][3][64]
+    float* sp = r1s + KP * 192;             // [64][KP]
+    const int t = threadIdx.x, q = t & 15, rg = t >> 4;
+    const int c0 = blockIdx.x * 64, b = blockIdx.z;
+    const int p_begin = blockIdx.y * R1_RB, p_end = min(P, p_begin + R1_RB);
+    const int N3 = 3 * C;
+    for (int i = t; i < 192 * KP; i += 256) {            // global [n][k] (k fastest) -> LDS [k][g][j]
+        const int k = i % KP, nj = i / KP;                // nj = g*64 + j
+        const int g = nj >> 6, j = nj & 63;
+        wcT[(k * 3 + g) * 64 + j] = wc[((int64_t)b * N3 + g * C + c0 + j) * KP + k];
+    }
+    for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+        __syncthreads();
+        for (int i = t; i < 64 * KP; i += 256) {
+            const int pr = p0 + i / KP;
+            sp[i] = pr < p_end ? spcol[((int64_t)b * P + p0) * KP + i] : 0.f;
+        }
+        __syncthreads();
+        f32x4 acc[4][3];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[rr][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < KP; ++k) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wcT + (k * 3 + 0) * 64 + q * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wcT + (k * 3 + 1) * 64 + q * 4);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wcT + (k * 3 + 2) * 64 + q * 4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float sv = sp[(rg * 4 + rr) * KP + k];
+                acc[rr][0] += sv * w0;
+                acc[rr][1] += sv * w1;
+                acc[rr][2] += sv * w2;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int pr = p0 + rg * 4 + rr;
+            if (pr >= p_end) continue;
+            const int64_t r = (int64_t)b * P + pr;
+            const int c = c0 + q * 4;
+            const float* px = xg + r * 4 * C + c;
+            f32x4 pi = *reinterpret_cast<const f32x4*>(px) + acc[rr][0];
+            f32x4 pf = *reinterpret_cast<const f32x4*>(px + C) + acc[rr][1];
+            f32x4 po = *reinterpret_cast<const f32x4*>(px + 2 * C) + acc[rr][2];
+            f32x4 pg = *reinterpret_cast<const f32x4*>(px + 3 * C);
+            if (hg) {
+                const float* ph = hg + r * 4 * C + c;
+                pi += *reinterpret_cast<const f32x4*>(ph);
+                pf += *reinterpret_cast<const f32x4*>(ph + C);
+                po += *reinterpret_cast<const f32x4*>(ph + 2 * C);
+                pg += *reinterpret_cast<const f32x4*>(ph + 3 * C);
+            }
+            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+            if (c_prev) cp = *reinterpret_cast<const f32x4*>(c_prev + r * C + c);
+            f32x4 gi, gf, go, gg, cn, hn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gi[e] = sigmoidf_(pi[e]);
+                gf[e] = sigmoidf_(pf[e]);
+                go[e] = sigmoidf_(po[e]);
+                gg[e] = tanhf(pg[e]);
+                cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                hn[e] = go[e] * cn[e];
+            }
+            float* pgt = gates + r * 4 * C + c;
+            *reinterpret_cast<f32x4*>(pgt) = gi;
+            *reinterpret_cast<f32x4*>(pgt + C) = gf;
+            *reinterpret_cast<f32x4*>(pgt + 2 * C) = go;
+            *reinterpret_cast<f32x4*>(pgt + 3 * C) = gg;
+            *reinterpret_cast<f32x4*>(c_out + r * C + c) = cn;
+            *reinterpret_cast<f32x4*>(h_out + r * C + c) = hn;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const float* dc, const float* gates,
                                                        const float* c_prev, const float* c_out, int64_t rows, int C,
                                                        float* dpre, float* dc_prev) {
@@ -398,6 +488,17 @@ extern "C" int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const flo
     if (C % 4) return SP_EINVAL;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, xg, hg, c_prev,
                        rows, C, gates, c_out, h_out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* c_prev, const float* spcol, const float* wc,
+                                 int B, int P, int C, int KP, float* gates, float* c_out, float* h_out, void* stream) {
+    if (!xg || !spcol || !wc || !gates || !c_out || !h_out) return SP_ENULL;
+    if (C % 64 || B < 1 || P < 1 || KP < 1 || KP > 64) return SP_EINVAL;
+    const size_t lds = (size_t)KP * (192 + 64) * sizeof(float);
+    hipLaunchKernelGGL(lstm_rank1_fwd_kernel, dim3(C / 64, (P + R1_RB - 1) / R1_RB, B), dim3(256), lds, (hipStream_t)stream, xg, hg,
+                       c_prev, spcol, wc, P, C, KP, gates, c_out, h_out);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -591,6 +591,62 @@ def lstm_cell(xg, hg, c_prev):
     return _LstmCell.apply(xg, hg, c_prev)
 
 
+class _LstmCellRank1(Function):
+    """ConvLSTM cell with the rank-1 gate terms fused into the pointwise kernel (sp_lstm_rank1_fwd):
+         pre[b,p,n] = xg + hg + sum_k spcol[b,p,k] * wc[b,n,k]   (n < 3C: the i/f/o gates)
+    xg / hg [B,Hm,Wm,4C] (hg may be None at step 0), spcol [B,P,KP], wc [B,3C,KP]."""
+    @staticmethod
+    def forward(ctx, xg, hg, c_prev, spcol, wc):
+        xg = xg.contiguous()
+        hg = hg.contiguous() if hg is not None else None
+        c_prev = c_prev.contiguous() if c_prev is not None else None
+        spcol = spcol.contiguous()
+        wc = wc.contiguous()
+        B, P, KP = spcol.shape
+        C4 = xg.shape[-1]
+        Cc = C4 // 4
+        assert xg.numel() == B * P * C4 and wc.shape == (B, 3 * Cc, KP), (xg.shape, spcol.shape, wc.shape)
+        shp = xg.shape[:-1] + (Cc,)
+        gates = torch.empty_like(xg)
+        c = torch.empty(shp, dtype=torch.float32, device=xg.device)
+        h = torch.empty(shp, dtype=torch.float32, device=xg.device)
+        check(hip.lib().sp_lstm_rank1_fwd(ptr(xg), ptr(hg), ptr(c_prev), ptr(spcol), ptr(wc), B, P, Cc, KP, ptr(gates), ptr(c),
+                                          ptr(h), hip.stream()), "sp_lstm_rank1_fwd")
+        ctx.has = (hg is not None, c_prev is not None)
+        ctx.save_for_backward(gates, c_prev, c, spcol, wc)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, c, spcol, wc = ctx.saved_tensors
+        dh = dh.contiguous() if dh is not None else None
+        dc = dc.contiguous() if dc is not None else None
+        B, P, KP = spcol.shape
+        C4 = gates.shape[-1]
+        Cc = C4 // 4
+        N3 = 3 * Cc
+        rows = gates.numel() // C4
+        dpre = torch.empty_like(gates)
+        dcp = torch.empty_like(c)
+        check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
+                                              ptr(dcp), hip.stream()), "sp_lstm_pointwise_bwd")
+        dsp = dwc = None
+        if ctx.needs_input_grad[3]:
+            dsp = torch.empty_like(spcol)
+            _igemm(dpre, wc, None, dsp, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1,
+                   nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
+        if ctx.needs_input_grad[4]:
+            dwc = torch.empty_like(wc)
+            _wgrad(spcol, dpre, dwc, N_img=P, Hi=1, Wi=1, Ci=KP, ldx=KP, Ho=1, Wo=1, Co=N3, ldy=C4, ldo=KP, nbatch=B,
+                   sX=P * KP, sY=P * C4, sO=N3 * KP)
+        has_hg, has_c = ctx.has
+        return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
+
+
+def lstm_cell_rank1(xg, hg, c_prev, spcol, wc):
+    return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc)
+
+
 class _Im2col(Function):
     """maps [S, R, H, W] -> col [R, H*W, KP]; stream s occupies columns [9s, 9s+9), the rest is zero."""
     @staticmethod

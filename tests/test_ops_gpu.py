@@ -188,9 +188,12 @@ def test_maxpool_ceil_with_ties(hw):
     _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-6, "dx")
 
 
-def test_lstm_cell_and_gate_conv():
+@pytest.mark.parametrize("fused", [False, True])
+def test_lstm_cell_and_gate_conv(fused):
+    """fused=False: rank-1 gate terms accumulated by the batched GEMM of gate_conv; fused=True: the path the model uses --
+    plain h-conv + lstm_cell_rank1 (rank-1 terms inside the pointwise kernel; 135 pixels = 2 full 64-pixel tiles + a tail)"""
     from scanpaths_amd import functional as F
-    B, Hm, Wm, C, S = 2, 6, 8, 32, 2
+    B, Hm, Wm, C, S = (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
     KP = 20
     h, c = _rand(B, C, Hm, Wm, seed=24), _rand(B, C, Hm, Wm, seed=25)
     xg = _rand(B, 4 * C, Hm, Wm, seed=26)
@@ -225,8 +228,11 @@ def test_lstm_cell_and_gate_conv():
         parts.append(F.gemm(seg[s], wflat, None, "nk").view(B, 3 * C, 9))
     wc = torch.cat(parts + [torch.zeros(B, 3 * C, KP - 9 * S, device=dev)], 2)
     spcol = F.im2col3x3(spg, KP)
-    hgate = F.gate_conv(hg_, whg, spcol, wc, (Hm, Wm))
-    hn, cn = F.lstm_cell(xgg, hgate, cg_)
+    if fused:
+        hn, cn = F.lstm_cell_rank1(xgg, F.conv2d(hg_, whg, None, pad=1), cg_, spcol, wc)
+    else:
+        hgate = F.gate_conv(hg_, whg, spcol, wc, (Hm, Wm))
+        hn, cn = F.lstm_cell(xgg, hgate, cg_)
     (hn * nhwc(gh).detach()).sum().add((cn * nhwc(gc).detach()).sum()).backward()
     back = lambda t: t.permute(0, 3, 1, 2)
     _close(back(hn), h2, 3e-6, "h")

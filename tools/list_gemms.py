@@ -23,5 +23,5 @@ step(); torch.cuda.synchronize()
 rows = sorted(hip.TIMER.summary().items(), key=lambda kv: -kv[1]["ms"])
 tot = sum(d["ms"] for _, d in rows)
 print(f"total GEMM ms {tot:.1f}")
-for k, d in rows[:45]:
+for k, d in rows[:int(os.environ.get("NROWS", "45"))]:
     print(f"{str(k):70s} n={d['launches']:3d} avg {d['avg_ms']:8.3f} ms  total {d['ms']:8.2f}  {d['tflops']:7.1f} TF/s")
