@@ -155,6 +155,11 @@ int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const float* c_prev,
  * baseline_attention.py:40-50).  xg/hg/gates [B*P][4C]; C % 64 == 0, KP <= 64. */
 int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* c_prev, const float* spcol, const float* wc, int B, int P,
                       int C, int KP, float* gates, float* c_out, float* h_out, void* stream);
+/* gradient of the per-sample rank-1 filters: dwc [B][N3][KP] = sum_p dpre[b,p,n] * spcol[b,p,k]; dpre rows have ld floats
+ * (= 4C, the first N3 = 3C are used); KP <= 24; workspace >= sp_rank1_dwc_workspace bytes (chunk partials, fixed-order reduce) */
+int64_t sp_rank1_dwc_workspace(int B, int P, int N3, int KP);
+int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P, int ld, int N3, int KP, void* workspace, float* dwc,
+                 void* stream);
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, void* stream);
 

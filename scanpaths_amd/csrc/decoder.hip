@@ -146,6 +146,72 @@ __global__ __launch_bounds__(256) void lstm_rank1_fwd_kernel(const float* __rest
     }
 }
 
+// Gradient of the per-sample contracted rank-1 filters:  dwc[b,n,k] = sum_p dpre[b,p,n] * spcol[b,p,k]  (n < 3C).
+// HBM-bound (one read of the i/f/o part of dpre).  Block = a 256-wide strip of n x a chunk of pixels of one sample; a thread
+// owns 4 consecutive n (16-byte loads: a wave reads 1 KB of a dpre row) and keeps 4 x KP sums in registers; the 4 waves take
+// every 4th pixel (its KP taps are a wave-wide LDS broadcast) and are combined through LDS in fixed order; chunk partials are
+// reduced by rank1_dwc_reduce_kernel.  As a batched TN GEMM with a 128-wide N tile for 20 columns this took 0.45 ms.
+constexpr int R1_MAXKP = 24, R1_PCH = 256;
+__global__ __launch_bounds__(256) void rank1_dwc_kernel(const float* __restrict__ dpre, const float* __restrict__ spcol, int P,
+                                                        int ld, int N3, int KP, int nchunk, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float sp[R1_PCH * R1_MAXKP];      // 24 KB: the chunk's taps
+    __shared__ f32x4 red[3][64][R1_MAXKP / 4 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + lane * 4, ch = blockIdx.y, b = blockIdx.z;
+    const int p_begin = ch * R1_PCH, np = min(P, p_begin + R1_PCH) - p_begin;
+    for (int i = threadIdx.x; i < np * KP; i += 256) sp[i] = spcol[((int64_t)b * P + p_begin) * KP + i];
+    __syncthreads();
+    f32x4 acc[R1_MAXKP];
+#pragma unroll
+    for (int k = 0; k < R1_MAXKP; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < N3) {
+        const float* src = dpre + ((int64_t)b * P + p_begin) * ld + n;
+        for (int pq = wv; pq < np; pq += 16) {              // 4 independent 16-byte row loads in flight per thread
+            f32x4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                g[u] = pq + 4 * u < np ? *reinterpret_cast<const f32x4*>(src + (int64_t)(pq + 4 * u) * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* spr = sp + min(pq + 4 * u, np - 1) * KP;
+#pragma unroll
+                for (int k = 0; k < R1_MAXKP; ++k)
+                    if (k < KP) acc[k] += spr[k] * g[u];
+            }
+        }
+    }
+    // combine the 4 pixel lanes (waves) in fixed order, R1_MAXKP/4 taps per pass
+    for (int k0 = 0; k0 < KP; k0 += R1_MAXKP / 4) {
+        __syncthreads();
+        if (wv > 0) {
+#pragma unroll
+            for (int k = 0; k < R1_MAXKP; ++k)
+                if (k >= k0 && k < k0 + R1_MAXKP / 4) red[wv - 1][lane][k - k0] = acc[k];
+        }
+        __syncthreads();
+        if (wv == 0 && n < N3) {
+#pragma unroll
+            for (int k = 0; k < R1_MAXKP; ++k)
+                if (k >= k0 && k < k0 + R1_MAXKP / 4 && k < KP) {
+                    const f32x4 v = ((acc[k] + red[0][lane][k - k0]) + red[1][lane][k - k0]) + red[2][lane][k - k0];
+                    float* dst = partial + (((int64_t)ch * gridDim.z + b) * N3 + n) * KP + k;
+                    dst[0] = v[0];
+                    dst[KP] = v[1];
+                    dst[2 * KP] = v[2];
+                    dst[3 * KP] = v[3];
+                }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rank1_dwc_reduce_kernel(const float* __restrict__ partial, int64_t n, int nchunk,
+                                                               float* __restrict__ dwc) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += partial[(int64_t)c * n + i];
+        dwc[i] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const float* dc, const float* gates,
                                                        const float* c_prev, const float* c_out, int64_t rows, int C,
                                                        float* dpre, float* dc_prev) {
@@ -499,6 +565,25 @@ extern "C" int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* 
     const size_t lds = (size_t)KP * (192 + 64) * sizeof(float);
     hipLaunchKernelGGL(lstm_rank1_fwd_kernel, dim3(C / 64, (P + R1_RB - 1) / R1_RB, B), dim3(256), lds, (hipStream_t)stream, xg, hg,
                        c_prev, spcol, wc, P, C, KP, gates, c_out, h_out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int64_t sp_rank1_dwc_workspace(int B, int P, int N3, int KP) {
+    return (int64_t)((P + R1_PCH - 1) / R1_PCH) * B * N3 * KP * (int64_t)sizeof(float);
+}
+
+extern "C" int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P, int ld, int N3, int KP, void* workspace,
+                            float* dwc, void* stream) {
+    if (!dpre || !spcol || !workspace || !dwc) return SP_ENULL;
+    if (B < 1 || P < 1 || N3 < 4 || N3 % 4 || ld % 4 || N3 > ld || KP < 1 || KP > R1_MAXKP) return SP_EINVAL;
+    const int nchunk = (P + R1_PCH - 1) / R1_PCH;
+    hipLaunchKernelGGL(rank1_dwc_kernel, dim3((N3 + 255) / 256, nchunk, B), dim3(256), 0, (hipStream_t)stream, dpre, spcol, P, ld,
+                       N3, KP, nchunk, (float*)workspace);
+    SP_LAUNCH_CHECK();
+    const int64_t n = (int64_t)B * N3 * KP;
+    hipLaunchKernelGGL(rank1_dwc_reduce_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, n,
+                       nchunk, dwc);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -214,20 +214,26 @@ class _Conv2d(Function):
         assert Ciw == Ci, (wp.shape, x.shape)
         Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
+        xs = None
         if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
-            _igemm_b3(split3(x), split3(wp), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
+            xs = split3(x)
+            _igemm_b3(xs, split3(wp), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
                       ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
+            # the weight-gradient GEMM consumes the same split operand: keep it (6 B/element) instead of re-splitting x in
+            # backward (HBM pass of 10 B/element per conv); sized for 288 GB
+            if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci)):
+                xs = None
         else:
             _igemm(x, wp, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co, ldw=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
-        ctx.save_for_backward(x, wp, y if relu else None)
+        ctx.save_for_backward(x, wp, y if relu else None, xs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, dil, relu, has_bias = ctx.cfg
-        x, wp, y = ctx.saved_tensors
+        x, wp, y, xs = ctx.saved_tensors
         dy = dy.contiguous()
         N, H, W_, Ci = x.shape
         Co, KH, KW, _ = wp.shape
@@ -250,8 +256,8 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1]:
             dwp = torch.empty_like(wp)
             if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
-                _wgrad_b3(split3(x), dys if dys is not None else split3(dy), dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo,
-                          Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
+                _wgrad_b3(xs if xs is not None else split3(x), dys if dys is not None else split3(dy), dwp, N_img=N, Hi=H,
+                          Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
             else:
                 _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
                        KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
@@ -637,8 +643,13 @@ class _LstmCellRank1(Function):
                    nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
         if ctx.needs_input_grad[4]:
             dwc = torch.empty_like(wc)
-            _wgrad(spcol, dpre, dwc, N_img=P, Hi=1, Wi=1, Ci=KP, ldx=KP, Ho=1, Wo=1, Co=N3, ldy=C4, ldo=KP, nbatch=B,
-                   sX=P * KP, sY=P * C4, sO=N3 * KP)
+            L = hip.lib()
+            if KP <= 24:
+                ws = hip.workspace(L.sp_rank1_dwc_workspace(B, P, N3, KP), dpre.device, slot=0)
+                check(L.sp_rank1_dwc(ptr(dpre), ptr(spcol), B, P, C4, N3, KP, ptr(ws), ptr(dwc), hip.stream()), "sp_rank1_dwc")
+            else:
+                _wgrad(spcol, dpre, dwc, N_img=P, Hi=1, Wi=1, Ci=KP, ldx=KP, Ho=1, Wo=1, Co=N3, ldy=C4, ldo=KP, nbatch=B,
+                       sX=P * KP, sY=P * C4, sO=N3 * KP)
         has_hg, has_c = ctx.has
         return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
 
