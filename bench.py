@@ -26,6 +26,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, dense bf16 MFMA
 # 3xbf16-split kernels spend 6 bf16 MFMA products per algorithmic (fp32-faithful) multiply-add -> their ceiling in
 # algorithmic FLOP/s is the bf16 peak / 6
 PEAK_SPLIT3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_SPLIT2_TFLOPS = 2500.0 / 3.0       # 2xfp16 split: 3 MFMA products per algorithmic FMA
 
 
 def parse():
@@ -159,31 +160,36 @@ def main():
     summ = timer.summary()
     # dominant kernel = the per-step h-gate conv: implicit GEMM  M = B*P, N = 2048, K = 9*512 (forward flavour)
     P = Hm * Wm
-    dom = None
-    for kind in ("b3_fwd", "igemm_fwd"):
-        dom = dom or summ.get((kind, args.batch * P, 2048, 9 * 512, "3x3", 1))
-    dom_kernel = "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)" if ("b3_fwd", args.batch * P, 2048, 9 * 512, "3x3", 1) in summ \
-        else "igemm_kernel<128,128,2,2,fwd> (fp32 MFMA)"
+    dom, dom_kind = None, None
+    for kind in ("h2_fwd", "b3_fwd", "igemm_fwd"):
+        if dom is None and (kind, args.batch * P, 2048, 9 * 512, "3x3", 1) in summ:
+            dom, dom_kind = summ[(kind, args.batch * P, 2048, 9 * 512, "3x3", 1)], kind
     if dom is None:
-        dom = max(summ.values(), key=lambda d: d["ms"])
+        dom, dom_kind = max(summ.values(), key=lambda d: d["ms"]), "igemm_fwd"
+    dom_kernel = {"h2_fwd": "h2_kernel<fwd> (2xfp16 split, 3 MFMA products)",
+                  "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)",
+                  "igemm_fwd": "igemm_kernel<128,128,2,2,fwd> (fp32 MFMA)"}[dom_kind]
     total_timed_ms = sum(d["ms"] for d in summ.values()) / args.steps
-    is_split = dom_kernel.startswith("b3_kernel")
     traffic = None      # fabric-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hconv.json")))["kernels"]
-        key = "b3_kernel<0, 0>" if is_split else "igemm_kernel<128, 128, 2, 2, 0, false>"
+        key = {"h2_fwd": "h2_kernel<0>", "b3_fwd": "b3_kernel<0, 0>", "igemm_fwd": "igemm_kernel<128, 128, 2, 2, 0, false>"}[dom_kind]
         if args.batch == 32 and (args.height, args.width) == (320, 512):
             traffic = round(pmc[key]["hbm_side_bytes_per_launch"])
     except Exception:
         traffic = None
-    peak = PEAK_SPLIT3_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
+    peak = {"h2_fwd": PEAK_SPLIT2_TFLOPS, "b3_fwd": PEAK_SPLIT3_TFLOPS, "igemm_fwd": PEAK_FP32_MFMA_TFLOPS}[dom_kind]
+    peak_note = {"h2_fwd": "2500 TFLOP/s dense fp16 MFMA peak / 3 MFMA products per algorithmic fp32-faithful FMA (2xfp16 split with "
+                           "a per-tensor power-of-two scale); the fp32 MFMA pipe peaks at 157.3",
+                 "b3_fwd": "2500 TFLOP/s dense bf16 MFMA peak / 6 MFMA products per algorithmic fp32-faithful FMA (3xbf16 split); "
+                           "the fp32 MFMA pipe peaks at 157.3",
+                 "igemm_fwd": "fp32 MFMA peak"}[dom_kind]
     roofline = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
                 "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes (profiles/r01_pmc_hconv.json); "
                                 "includes Infinity-Cache hits; algorithmic bytes/launch = operands once + output = 0.98e9",
                 "kernel": dom_kernel + ": h-gate conv3x3 512->2048, implicit GEMM M=B*P N=2048 K=4608",
-                "peak_note": ("2500 TFLOP/s dense bf16 MFMA peak / 6 MFMA products per algorithmic fp32-faithful FMA (3xbf16 "
-                              "split); the fp32 MFMA pipe peaks at 157.3" if is_split else "fp32 MFMA peak"),
+                "peak_note": peak_note,
                 "flops_per_launch": dom["flops_per_launch"], "avg_launch_ms": round(dom["avg_ms"], 4),
                 "launches_timed": dom["launches"],
                 "all_big_gemms_ms_per_step": round(total_timed_ms, 2),

@@ -1,0 +1,710 @@
+// fp32-faithful implicit-GEMM convolution on the fp16 matrix pipe: "2 x fp16 split, 3 products".
+//
+// Every fp32 operand tensor is scaled by a per-tensor power of two s (so that max|x*s| lies in [8192, 16384): exact, no
+// overflow, the residual plane stays a normal fp16 for everything within 2^-11 of the maximum) and split into two fp16 planes
+//     x*s = x1 + x2,   x1 = fp16(x*s),  x2 = fp16(x*s - x1)          |x*s - x1 - x2| <= 2^-22 |x*s|
+// and  a*b = (a1b1 + a1b2 + a2b1) / (sa*sb) + O(2^-22 |ab|)  is evaluated with THREE v_mfma_f32_32x32x16_f16 per fragment
+// pair (fp16 x fp16 products are exact in the fp32 accumulator; smallest first; two-level accumulation every 256 k as in the
+// other GEMM kernels).  The element-wise representation errors are independent, so a length-K dot product is off by
+// ~2^-22 rms|ab| sqrt(K) -- measured 7.6e-8 relative to rms(C) for K = 64 .. 18432, i.e. 2-4x CLOSER to the fp64 result than
+// a CPU fp32 GEMM (1.2e-7 .. 3.0e-7), at half the MFMA work and 2/3 of the operand bytes of the 3 x bf16 / 6-product scheme
+// (conv_bf16x3.hip, 5.8e-9: more exact than the fp32 reference itself can resolve).  tests/test_ops_gpu.py holds all three
+// GEMM back-ends to the same fp64 bar.
+//
+// Operand storage ("split-2 interleaved"): [row][k/16][plane 0..1][16 fp16] = 64 contiguous bytes per (row, 16 k); a K-tile is
+// 32 k = 128 bytes per row.  A 64-byte zero block follows the data (masked loader lanes); the scale lives in a device float.
+#include "common.h"
+#include <algorithm>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+#define SP_GLDS16(src, dst)                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                       \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+constexpr int HBM = 256, HBN = 128, HBK = 32;
+constexpr int HA_BYTES = HBM * 128;              // 32768: [row][8 x 16 B]
+constexpr int HB_BYTES = HBN * 128;              // 16384
+constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
+constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
+constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
+
+struct H2Args {
+    const uint16_t* X;    // [pixels][Kc/16][2][16]
+    const uint16_t* W;    // [Nout][K/16][2][16]
+    const float* bias;
+    float* C;
+    const float* sx;      // device scalars: operand scales
+    const float* sw;
+    int64_t M;
+    int Hi, Wi, Kc;
+    int Ho, Wo, Nout, ldc;
+    int KH, KW, stride, pad, dil;
+    int64_t ldwb;         // bytes per weight row (4 * K)
+    int ncblk, nkt, tiles_n;
+    float alpha;
+    int beta, relu;
+    uint32_t x_bytes, w_bytes;
+};
+
+// Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
+// staging in a 3-stage ring with counted vmcnt (the structure of b3_kernel, see there for why).  Rows are 128 B = half a
+// 256-byte LDS bank row, so the source-side swizzle is an XOR: chunk c of row r is stored at position c ^ ((r>>1)&7); the 16
+// rows of every ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then hit 16 distinct 16-byte slots.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int tn, tmi;
+    supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn);
+    const int64_t m0 = (int64_t)tmi * HBM;
+    const int n0 = tn * HBN;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- loader mapping: LDS chunk g = t + 512 j -> row g/8, position g%8; source chunk = position ^ swizzle(row) ----
+    int a_c8[4], a_py[4], a_px[4], a_boff[4];
+    bool a_rowok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = t + 512 * j;
+        const int row = idx >> 3, pos = idx & 7;
+        a_c8[j] = (pos ^ ((row >> 1) & 7)) * 16;
+        const int64_t m = m0 + row;
+        a_rowok[j] = m < p.M;
+        const int64_t mm = a_rowok[j] ? m : 0;
+        const int b = (int)(mm / HoWo);
+        const int rem = (int)(mm - (int64_t)b * HoWo);
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        a_boff[j] = b * p.Hi * p.Wi;
+        if (MODE == 0) {
+            a_py[j] = yo * p.stride - p.pad;
+            a_px[j] = xo * p.stride - p.pad;
+        } else {
+            a_py[j] = yo + p.pad;
+            a_px[j] = xo + p.pad;
+        }
+    }
+    uint32_t b_voff[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = t + 512 * j;
+        const int row = idx >> 3, pos = idx & 7;
+        const int c8 = (pos ^ ((row >> 1) & 7)) * 16;
+        b_ok[j] = (n0 + row) < p.Nout;
+        b_voff[j] = b_ok[j] ? (uint32_t)((int64_t)(n0 + row) * p.ldwb + c8) : 0u;
+    }
+    int ld_ky = 0, ld_kx = 0, ld_cblk = 0, ld_kt = 0;
+    uint32_t a_voff[4];
+    bool a_ok[4];
+    const int rowbytes = p.Kc * 4;
+
+    auto tap_update = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = a_rowok[j];
+            int iy, ix;
+            if (MODE == 0) {
+                iy = a_py[j] + ld_ky * p.dil;
+                ix = a_px[j] + ld_kx * p.dil;
+                ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            } else {
+                const int ty = a_py[j] - ld_ky * p.dil, tx = a_px[j] - ld_kx * p.dil;
+                ok = ok && ty >= 0 && tx >= 0;
+                if (p.stride == 1) {
+                    iy = ty;
+                    ix = tx;
+                } else {
+                    iy = ty / p.stride;
+                    ix = tx / p.stride;
+                    ok = ok && (iy * p.stride == ty) && (ix * p.stride == tx);
+                }
+                ok = ok && iy < p.Hi && ix < p.Wi;
+            }
+            a_ok[j] = ok;
+            a_voff[j] = ok ? (uint32_t)(a_boff[j] + iy * p.Wi + ix) * (uint32_t)rowbytes + (uint32_t)a_c8[j] : 0u;
+        }
+    };
+
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * HSTAGE;
+        if (ld_cblk == 0) tap_update();
+        const uint32_t koffA = (uint32_t)ld_cblk * 128u;                 // scalar: 32-channel block inside the pixel row
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
+        const uint32_t zrelA = p.x_bytes - koffA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
+        const uint32_t koffB = (uint32_t)ld_kt * 128u;
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
+        const uint32_t zrelB = p.w_bytes - koffB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
+        ++ld_kt;
+        if (++ld_cblk == p.ncblk) {
+            ld_cblk = 0;
+            if (++ld_kx == p.KW) {
+                ld_kx = 0;
+                ++ld_ky;
+            }
+        }
+    };
+
+    // fragment read offsets: row r, chunk c = kk*4 + plane*2 + h stored at position c ^ ((r>>1)&7)
+    const int rot = (l32 >> 1) & 7;
+    int offA[2][2], offB[2][2];      // [kk][plane]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const int pos = (kk * 4 + pl * 2 + h) ^ rot;
+            offA[kk][pl] = (wm * 64 + l32) * 128 + pos * 16;
+            offB[kk][pl] = HA_BYTES + (wn * 64 + l32) * 128 + pos * 16;
+        }
+
+    f32x16 tot[2][2], acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tot[i][j][r] = 0.f;
+                acc[i][j][r] = 0.f;
+            }
+
+    // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
+    int issued = 0;
+    for (; issued < HNSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
+    if (issued >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        const bool pre = kt + HNSTAGE - 1 < p.nkt;
+        const unsigned char* st = smem + stage * HSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 af[2][2], bf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
+                    bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // three products, the two cross terms (~2^-11 of the main one) first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        // prefetch of tile kt+2 behind the MFMAs in program order (see b3_kernel), into the stage read in iteration kt-1
+        if (pre) issue_tile(stage == 0 ? HNSTAGE - 1 : stage - 1);
+        if ((kt & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+        // tile kt+1 must have landed: everything but the one younger tile (if it was issued)
+        if (kt + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+    }
+
+    const float scale = p.alpha / (p.sx[0] * p.sw[0]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l32;
+        if (n >= p.Nout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M) {
+                    float* dst = p.C + m * p.ldc + n;
+                    float v = scale * (tot[i][j][r] + acc[i][j][r]) + bv;
+                    if (p.beta) v += *dst;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================================
+// Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pix(m,tap)][ci]   (K = pixels), the structure of w3_kernel:
+// K-tiles of 32 pixels staged as [pixel][channel chunks] rows by LDS-DMA, K-major fragments by ds_read_b64_tr_b16.
+// Pixel rows are 1024 B (A: 256 co) / 512 B (B: 128 ci), both = 0 mod 256, so the four pixel rows of a transposed-read block
+// would collide; row r is stored rotated by rot(r&3) = {0,2,8,10} chunks, which puts the 4 rows x 2 channel groups of every
+// 32-lane half on 8 distinct 32-byte slots of the 256-byte bank row.
+struct HWArgs {
+    const uint16_t* X;     // split-2 [pixels_in][Ci/16][2][16]
+    const uint16_t* dY;    // split-2 [pixels_out][Co/16][2][16]
+    float* out;
+    const float* sx;
+    const float* sy;
+    int64_t M;
+    int Hi, Wi, Ci, Ho, Wo, Co;
+    int KH, KW, stride, pad, dil;
+    int Ntot, ldo, tiles_n, splits;
+    int64_t rows_per_split, slab_stride;
+    float alpha;
+    int beta;
+    uint32_t x_bytes, y_bytes;
+};
+
+constexpr int HWA_ROW = 1024, HWB_ROW = 512;
+constexpr int HWA_BYTES = 32 * HWA_ROW;          // 32768
+constexpr int HWB_BYTES = 32 * HWB_ROW;          // 16384
+constexpr int HWSTAGE = HWA_BYTES + HWB_BYTES;   // 49152
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f16x8 tr_pair_h(const unsigned char* base, int off0, int off1) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + off0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + off1));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, v);
+}
+
+__device__ __forceinline__ int rot4(int q) { return 2 * (q & 1) + 8 * (q >> 1); }
+
+__global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
+    const int co0 = tmi * 256, n0 = tn * 128;
+    const int tap = n0 / p.Ci, ci0 = n0 - tap * p.Ci;           // Ci % 128 == 0: a column tile lies inside one tap
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int split = blockIdx.y;
+    const int64_t m_begin = (int64_t)split * p.rows_per_split;
+    const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nkt = (int)((m_end - m_begin + 31) / 32);
+    const int HoWo = p.Ho * p.Wo;
+
+    uint32_t a_voff[4];
+    int a_r[4];
+    bool a_cok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = t + 512 * j;
+        const int r = g >> 6, pos = g & 63;
+        const int js = (pos - rot4(r & 3)) & 63;                 // un-rotate: which source chunk lands here
+        a_r[j] = r;
+        a_cok[j] = co0 + (js >> 2) * 16 < p.Co;
+        a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.Co) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
+    }
+    int b_r[2], b_c8[2], b_b[2], b_y[2], b_x[2];
+    bool b_live[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = t + 512 * j;
+        const int r = g >> 5, pos = g & 31;
+        const int js = (pos - rot4(r & 3)) & 31;
+        b_r[j] = r;
+        b_c8[j] = ci0 * 4 + js * 16;
+        b_live[j] = n0 + (js >> 2) * 16 < p.Ntot;
+        const int64_t m = m_begin + r;                            // coordinates of this lane's pixel in K-tile 0
+        const int b = (int)(m / HoWo);
+        const int rem = (int)(m - (int64_t)b * HoWo);
+        b_b[j] = b;
+        b_y[j] = rem / p.Wo;
+        b_x[j] = rem - b_y[j] * p.Wo;
+    }
+    const int y_adv = 32 / p.Wo, x_adv = 32 - y_adv * p.Wo;      // advancing 32 output pixels = y_adv rows + x_adv columns
+    const uint32_t xrow = (uint32_t)(4 * p.Ci);
+    int ld_kt = 0;
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * HWSTAGE;
+        const int64_t mt = m_begin + (int64_t)ld_kt * 32;
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (4 * (int64_t)p.Co);   // scalar
+        const uint32_t zrelA = (uint32_t)((int64_t)p.y_bytes - mt * (4 * (int64_t)p.Co));
+        const int rows_left = (int)min((int64_t)32, m_end - mt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = a_cok[j] && a_r[j] < rows_left;
+            SP_GLDS16(baseA + (ok ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
+        }
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.X);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int iy = b_y[j] * p.stride - p.pad + ky * p.dil, ix = b_x[j] * p.stride - p.pad + kx * p.dil;
+            const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const uint32_t off = (uint32_t)((b_b[j] * p.Hi + iy) * p.Wi + ix) * xrow + (uint32_t)b_c8[j];
+            SP_GLDS16(baseB + (ok ? off : p.x_bytes), st + HWA_BYTES + (wave + 8 * j) * 1024);
+            // advance this lane's pixel by 32 for the next K-tile (no divisions)
+            b_x[j] += x_adv;
+            b_y[j] += y_adv;
+            if (b_x[j] >= p.Wo) { b_x[j] -= p.Wo; ++b_y[j]; }
+            while (b_y[j] >= p.Ho) { b_y[j] -= p.Ho; ++b_b[j]; }
+        }
+        ++ld_kt;
+    };
+
+    // transposed-read offsets (k-group kk adds 16 pixel rows): lane (g4 = (lane>>4)&1, q = (lane>>2)&3, pp = lane&3) addresses
+    // pixel row 8h + 4s + q, channels cbase + 16*g4 + 4pp .. +3 of plane pl
+    const int g4 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    int offA[2][2][2], offB[2][2][2];     // [i][plane][s]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int row = 8 * h + 4 * s2 + q;
+                const int ja = (wm * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
+                offA[i][pl][s2] = row * HWA_ROW + ((ja + rot4(q)) & 63) * 16 + (pp & 1) * 8;
+                const int jb = (wn * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
+                offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + ((jb + rot4(q)) & 31) * 16 + (pp & 1) * 8;
+            }
+
+    f32x16 tot[2][2], acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tot[i][j][r] = 0.f;
+                acc[i][j][r] = 0.f;
+            }
+
+    {
+        int issued = 0;
+        for (; issued < HNSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
+        if (issued >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool pre = kt + HNSTAGE - 1 < nkt;
+        const unsigned char* st = smem + stage * HWSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 af[2][2], bf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
+                    bf[i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (pre) issue_tile(stage == 0 ? HNSTAGE - 1 : stage - 1);
+        if ((kt & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    tot[i][j] += acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+    }
+
+    float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
+    const bool direct = p.splits == 1;
+    const float scale = p.alpha / (p.sx[0] * p.sy[0]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l32;
+        if (n >= p.Ntot) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Co) {
+                    float* dst = out + (int64_t)co * p.ldo + n;
+                    const float v = tot[i][j][r] + acc[i][j][r];
+                    if (direct) {
+                        float w = scale * v;
+                        if (p.beta) w += *dst;
+                        *dst = w;
+                    } else {
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void hw_reduce_kernel(const float* slab, float* out, int Co, int Ntot, int ldo, int splits, int64_t slab_stride,
+                                 float alpha, const float* sx, const float* sy, int beta) {
+    const int64_t total = (int64_t)Co * Ntot;
+    const float scale = alpha / (sx[0] * sy[0]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Ntot), n = (int)(i - (int64_t)co * Ntot);
+        const int64_t off = (int64_t)co * ldo + n;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * slab_stride + off];
+        s *= scale;
+        if (beta) s += out[off];
+        out[off] = s;
+    }
+}
+
+int hw_splits(const sp_wgrad_desc* d) {
+    const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
+    const int64_t tiles = sp_cdiv(d->Co, 256) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, 128);
+    int64_t want = sp_cdiv(2048, tiles);                          // 1 workgroup per CU: aim for >= 8 rounds of 256
+    want = std::min<int64_t>(want, std::max<int64_t>(1, M / 1024));   // >= 32 K-tiles per split
+    want = std::min<int64_t>(want, 64);
+    return (int)std::max<int64_t>(1, want);
+}
+
+// ---- scale + split kernels ------------------------------------------------------------------------------------
+// amax over a tensor: atomicMax on the bit pattern of |x| (non-negative floats order like unsigned ints) -- exact, order-free.
+__global__ __launch_bounds__(256) void amax_kernel(const float* x, int64_t n4, int64_t n, unsigned* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+// power-of-two scale with amax * s in [8192, 16384)
+__device__ __forceinline__ float scale_of(unsigned amax_bits) {
+    const float a = __uint_as_float(amax_bits);
+    if (!(a > 0.f) || !(a < INFINITY)) return 1.f;
+    int e;
+    (void)frexpf(a, &e);                 // a = f * 2^e, f in [0.5, 1)
+    e = 14 - e;                          // a * 2^(14-e) in [8192, 16384)
+    e = max(-126, min(126, e));
+    return ldexpf(1.f, e);
+}
+
+__device__ __forceinline__ void split2(float v, float s, uint16_t& a, uint16_t& b) {
+    const float xs = v * s;
+    const _Float16 x1 = (_Float16)xs;
+    const float r1 = xs - (float)x1;
+    const _Float16 x2 = (_Float16)r1;
+    a = __builtin_bit_cast(uint16_t, x1);
+    b = __builtin_bit_cast(uint16_t, x2);
+}
+
+// x fp32 [rows][K] (K % 16 == 0)  ->  [rows][K/16][2][16] fp16.  One thread per 4 consecutive k.
+__global__ __launch_bounds__(256) void split2_kernel(const float* x, int64_t n4, const unsigned* amax, uint16_t* out,
+                                                     float* scale_out) {
+    const float s = scale_of(*amax);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        ushort4 a, b;
+        split2(v.x, s, a.x, b.x);
+        split2(v.y, s, a.y, b.y);
+        split2(v.z, s, a.z, b.z);
+        split2(v.w, s, a.w, b.w);
+        const int64_t g = i >> 2;            // 16-k group
+        const int sub = (int)(i & 3) * 4;
+        uint16_t* o = out + g * 32 + sub;
+        *reinterpret_cast<ushort4*>(o) = a;
+        *reinterpret_cast<ushort4*>(o + 16) = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8)       // 64-byte zero block right after the data
+        reinterpret_cast<uint2*>(out + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+}
+
+// w [Co][taps][Ci] fp32 -> rows n = ci, k = (tap, co):  [Ci][taps*Co/16][2][16]  (the K-contiguous B operand of dgrad)
+__global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, int taps, int Ci, const unsigned* amax,
+                                                        uint16_t* out, float* scale_out) {
+    const float s = scale_of(*amax);
+    const int64_t total = (int64_t)Co * taps * Ci;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co);
+        int64_t r = i / Co;
+        const int tap = (int)(r % taps);
+        const int ci = (int)(r / taps);
+        uint16_t a, b;
+        split2(w[((int64_t)co * taps + tap) * Ci + ci], s, a, b);
+        const int64_t k = (int64_t)tap * Co + co;
+        uint16_t* o = out + ((int64_t)ci * ((int64_t)taps * Co / 16) + (k >> 4)) * 32 + (k & 15);
+        o[0] = a;
+        o[16] = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(out + 2 * total)[threadIdx.x] = make_uint2(0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+}
+
+template <int MODE>
+int launch_h2(const H2Args& a, hipStream_t s) {
+    auto kern = h2_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HSTAGE);
+        attr_set = true;
+    }
+    const int64_t grid = sp_cdiv(a.M, HBM) * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), HNSTAGE * HSTAGE, s, a);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return (int)e;
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256 * 4), 2048));
+    hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, n, amax);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+}  // namespace
+
+// out: 2*n fp16 + 64-byte zero block; scale_amax: two 4-byte device words {scale (float, written), amax bits (scratch)}
+extern "C" int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax, void* stream) {
+    if (!x || !out || !scale_amax) return SP_ENULL;
+    if (n % 16) return SP_EINVAL;            // every row must be a multiple of 16 long
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* amax = reinterpret_cast<unsigned*>(scale_amax + 1);
+    const int rc = launch_amax(x, n, amax, s);
+    if (rc != SP_OK) return rc;
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256), 4096));
+    hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, s, x, n4, amax, (uint16_t*)out, scale_amax);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* out, float* scale_amax, void* stream) {
+    if (!w || !out || !scale_amax) return SP_ENULL;
+    if (((int64_t)taps * Co) % 16) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* amax = reinterpret_cast<unsigned*>(scale_amax + 1);
+    const int64_t total = (int64_t)Co * taps * Ci;
+    const int rc = launch_amax(w, total, amax, s);
+    if (rc != SP_OK) return rc;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(total, 256), 4096));
+    hipLaunchKernelGGL(split2_wT_kernel, dim3(blocks), dim3(256), 0, s, w, Co, taps, Ci, amax, (uint16_t*)out, scale_amax);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
+                                   const float* w_scale, const float* bias, float* out, void* stream) {
+    if (!d || !Xs || !Ws || !x_scale || !w_scale || !out) return SP_ENULL;
+    if (d->mode != 0 && d->mode != 1) return SP_EINVAL;
+    if (d->Kc % 32 || d->ldx != d->Kc) return SP_EINVAL;      // a 32-k K-tile must lie inside one filter tap
+    if (((uintptr_t)Xs | (uintptr_t)Ws) & 15) return SP_EINVAL;
+    if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
+    H2Args a;
+    a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
+    a.sx = x_scale; a.sw = w_scale;
+    a.M = (int64_t)d->N_img * d->Ho * d->Wo;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->ldc;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.ldwb = 4 * (int64_t)d->KH * d->KW * d->Kc;
+    a.ncblk = d->Kc / 32;
+    a.nkt = d->KH * d->KW * a.ncblk;
+    a.tiles_n = (int)sp_cdiv(d->Nout, HBN);
+    a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
+    const int64_t xb = 4LL * d->N_img * d->Hi * d->Wi * d->Kc, wb = 4LL * d->Nout * d->KH * d->KW * d->Kc;
+    if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
+    a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
+    if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
+    return d->mode == 0 ? launch_h2<0>(a, (hipStream_t)stream) : launch_h2<1>(a, (hipStream_t)stream);
+}
+
+extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
+    if (!d) return 0;
+    const int sp = hw_splits(d);
+    return sp <= 1 ? 0 : (int64_t)sp * d->Co * d->ldo * (int64_t)sizeof(float);
+}
+
+extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
+                                   const float* y_scale, float* dW, void* workspace, void* stream) {
+    if (!d || !Xsplit || !dYsplit || !x_scale || !y_scale || !dW) return SP_ENULL;
+    if (d->Ci % 128 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
+    if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
+    HWArgs a;
+    a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;
+    a.sx = x_scale; a.sy = y_scale;
+    a.M = (int64_t)d->N_img * d->Ho * d->Wo;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.Ntot = d->KH * d->KW * d->Ci;
+    a.ldo = d->ldo;
+    a.tiles_n = (int)sp_cdiv(a.Ntot, 128);
+    a.splits = hw_splits(d);
+    if (a.splits > 1 && !workspace) return SP_ENULL;
+    a.rows_per_split = sp_cdiv(sp_cdiv(a.M, a.splits), 32) * 32;
+    a.slab_stride = (int64_t)d->Co * d->ldo;
+    a.out = a.splits > 1 ? (float*)workspace : dW;
+    a.alpha = d->alpha; a.beta = d->beta;
+    if (a.M <= 0) return SP_EINVAL;
+    const int64_t xb = 4LL * d->N_img * d->Hi * d->Wi * d->Ci, yb = 4LL * a.M * d->Co;
+    if (xb + 64 >= (1LL << 32) || yb + 64 >= (1LL << 32) || d->Ho * d->Wo < 1) return SP_EINVAL;
+    a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HNSTAGE * HWSTAGE);
+        attr_set = true;
+    }
+    const int64_t grid = sp_cdiv(d->Co, 256) * a.tiles_n;
+    hipLaunchKernelGGL(hw_kernel, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
+    SP_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        const int64_t total = (int64_t)d->Co * a.Ntot;
+        const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);
+        hipLaunchKernelGGL(hw_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot, d->ldo,
+                           a.splits, a.slab_stride, d->alpha, x_scale, y_scale, d->beta);
+        SP_LAUNCH_CHECK();
+    }
+    return SP_OK;
+}

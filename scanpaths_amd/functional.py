@@ -59,8 +59,22 @@ def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=
     hip.TIMER.bracket(key, 2.0 * M * Co * KH * KW * Ci * nbatch, launch)
 
 
-# ---- fp32-faithful GEMM on the bf16 pipe (csrc/conv_bf16x3.hip) -----------------------------------------------
+# ---- fp32-faithful GEMMs on the 16-bit matrix pipe (csrc/conv_f16x2.hip, csrc/conv_bf16x3.hip) ---------------------
 USE_BF16X3 = True          # False -> every GEMM on the fp32 MFMA kernel (parity triage / A-B timing)
+SPLIT_SCHEME = "f16x2"     # "f16x2": 2 fp16 planes + per-tensor power-of-two scale, 3 MFMA products (default);
+                           # "bf16x3": 3 bf16 planes, 6 products (no scale pass; used when a channel count is not a multiple of 32)
+
+
+class SplitOperand:
+    """a GEMM operand in split form: buf (16-bit planes, interleaved per 16 k) + device scale (f16x2 only)"""
+    __slots__ = ("buf", "scale", "scheme")
+
+    def __init__(self, buf, scale, scheme):
+        self.buf, self.scale, self.scheme = buf, scale, scheme
+
+
+def _scheme_for(kc: int) -> str:
+    return "f16x2" if SPLIT_SCHEME == "f16x2" and kc % 32 == 0 else "bf16x3"
 
 
 def split3(x: torch.Tensor) -> torch.Tensor:
@@ -80,54 +94,104 @@ def split3_wT(wp: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
+    """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree)"""
+    scheme = scheme or _scheme_for(x.shape[-1])
+    if scheme == "bf16x3":
+        return SplitOperand(split3(x), None, scheme)
+    x = x.contiguous()
+    n = x.numel()
+    out = torch.empty(2 * n + 32, dtype=torch.float16, device=x.device)
+    scale = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(hip.lib().sp_split2_f16(ptr(x), n, ptr(out), ptr(scale), hip.stream()), "sp_split2_f16")
+    return SplitOperand(out, scale, scheme)
+
+
+def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
+    Co, KH, KW, Ci = wp.shape
+    scheme = scheme or _scheme_for(Co)
+    if scheme == "bf16x3":
+        return SplitOperand(split3_wT(wp), None, scheme)
+    out = torch.empty(2 * wp.numel() + 32, dtype=torch.float16, device=wp.device)
+    scale = torch.empty(2, dtype=torch.float32, device=wp.device)
+    check(hip.lib().sp_split2_f16_wT(ptr(wp), Co, KH * KW, Ci, ptr(out), ptr(scale), hip.stream()), "sp_split2_f16_wT")
+    return SplitOperand(out, scale, scheme)
+
+
 def _b3_pays(M, N, K, Kc, nbatch=1):
-    """cost model: split pass (10 B per operand element at ~4 TB/s) + GEMM at ~2.3x the fp32 rate < fp32 GEMM"""
+    """cost model: split passes (10-12 B per operand element at ~4 TB/s) + split GEMM (~2.3x / ~4x the fp32 rate) < fp32 GEMM"""
     if not USE_BF16X3 or nbatch != 1 or Kc % 16 or N < 64:
         return False
+    f16 = _scheme_for(Kc) == "f16x2"
     flops = 2.0 * M * N * K
-    split_bytes = 10.0 * (M * Kc + N * K)
+    split_bytes = (12.0 if f16 else 10.0) * (M * Kc + N * K)
     if 6.0 * M * Kc * 4 >= 2 ** 32 or 6.0 * N * K >= 2 ** 32:     # loaders use 32-bit byte offsets (x4: strided / dilated sources)
         return False
-    return flops * (1 / 1.1e14 - 1 / 2.5e14) > split_bytes / 4e12 and flops > 2e9
+    return flops * (1 / 1.1e14 - 1 / (4.0e14 if f16 else 2.5e14)) > split_bytes / 4e12 and flops > 2e9
 
 
-def _igemm_b3(Xp, Wp, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
+def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
               alpha=1.0, beta=0, relu=0):
+    """implicit-GEMM conv / dgrad on split operands (SplitOperand, or a raw split-3 buffer)"""
+    if not isinstance(Xs, SplitOperand):
+        Xs, Ws = SplitOperand(Xs, None, "bf16x3"), SplitOperand(Ws, None, "bf16x3")
+    assert Xs.scheme == Ws.scheme, (Xs.scheme, Ws.scheme)
     d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
                  int(relu), 1, 0, 0, 0, 0, None)
+    f16 = Xs.scheme == "f16x2"
 
     def launch():
-        check(hip.lib().sp_conv_igemm_bf16x3(C.byref(d), ptr(Xp), ptr(Wp), ptr(bias), ptr(out), hip.stream()),
-              "sp_conv_igemm_bf16x3")
+        if f16:
+            check(hip.lib().sp_conv_igemm_f16x2(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(Ws.buf), ptr(Ws.scale), ptr(bias),
+                                                ptr(out), hip.stream()), "sp_conv_igemm_f16x2")
+        else:
+            check(hip.lib().sp_conv_igemm_bf16x3(C.byref(d), ptr(Xs.buf), ptr(Ws.buf), ptr(bias), ptr(out), hip.stream()),
+                  "sp_conv_igemm_bf16x3")
     if hip.TIMER is None:
         return launch()
     M = N_img * Ho * Wo
     K = KH * KW * Kc
-    key = ("b3_fwd" if mode == 0 else "b3_dgrad", M, Nout, K, f"{KH}x{KW}", 1)
+    pre = "h2" if f16 else "b3"
+    key = (pre + ("_fwd" if mode == 0 else "_dgrad"), M, Nout, K, f"{KH}x{KW}", 1)
     hip.TIMER.bracket(key, 2.0 * M * Nout * K, launch)
 
 
 def _w3_pays(M, Co, K, Ci, nbatch=1):
     if not USE_BF16X3 or nbatch != 1 or Ci % 128 or Co % 16 or Co < 128:
         return False
+    f16 = _scheme_for(Co) == "f16x2"
     flops = 2.0 * M * Co * K
-    split_bytes = 10.0 * M * (Ci + Co)
+    split_bytes = (12.0 if f16 else 10.0) * M * (Ci + Co)
     if 6.0 * M * max(Ci, Co) * 4 >= 2 ** 32:
         return False
-    return flops * (1 / 1.0e14 - 1 / 1.6e14) > split_bytes / 4e12 and flops > 2e9
+    return flops * (1 / 1.0e14 - 1 / (3.2e14 if f16 else 1.6e14)) > split_bytes / 4e12 and flops > 2e9
+
+
+def _wgrad_scheme(Ci, Co) -> str:
+    return "f16x2" if _scheme_for(Ci) == "f16x2" and _scheme_for(Co) == "f16x2" else "bf16x3"
 
 
 def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0, alpha=1.0):
+    if not isinstance(Xs, SplitOperand):
+        Xs, dYs = SplitOperand(Xs, None, "bf16x3"), SplitOperand(dYs, None, "bf16x3")
+    assert Xs.scheme == dYs.scheme, (Xs.scheme, dYs.scheme)
     d = WgradDesc(N_img, Hi, Wi, Ci, Ci, Ho, Wo, Co, Co, KH, KW, stride, pad, dil, ldo, int(beta), float(alpha), 1, 0, 0, 0)
     L = hip.lib()
-    ws = hip.workspace(L.sp_conv_wgrad_bf16x3_workspace(C.byref(d)), dW.device, slot=0)
+    f16 = Xs.scheme == "f16x2"
+    ws = hip.workspace((L.sp_conv_wgrad_f16x2_workspace if f16 else L.sp_conv_wgrad_bf16x3_workspace)(C.byref(d)), dW.device,
+                       slot=0)
 
     def launch():
-        check(L.sp_conv_wgrad_bf16x3(C.byref(d), ptr(Xs), ptr(dYs), ptr(dW), ptr(ws), hip.stream()), "sp_conv_wgrad_bf16x3")
+        if f16:
+            check(L.sp_conv_wgrad_f16x2(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(dYs.buf), ptr(dYs.scale), ptr(dW), ptr(ws),
+                                        hip.stream()), "sp_conv_wgrad_f16x2")
+        else:
+            check(L.sp_conv_wgrad_bf16x3(C.byref(d), ptr(Xs.buf), ptr(dYs.buf), ptr(dW), ptr(ws), hip.stream()),
+                  "sp_conv_wgrad_bf16x3")
     if hip.TIMER is None:
         return launch()
     M = N_img * Ho * Wo
-    hip.TIMER.bracket(("b3_wgrad", M, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * M * Co * KH * KW * Ci, launch)
+    hip.TIMER.bracket((("h2" if f16 else "b3") + "_wgrad", M, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * M * Co * KH * KW * Ci, launch)
 
 
 def colsum(x2d: torch.Tensor, C_: int, ld: int, M: int) -> torch.Tensor:
@@ -216,24 +280,28 @@ class _Conv2d(Function):
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
         xs = None
         if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
-            xs = split3(x)
-            _igemm_b3(xs, split3(wp), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
+            xs = split_op(x)
+            _igemm_b3(xs, split_op(wp, xs.scheme), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
                       ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
             # the weight-gradient GEMM consumes the same split operand: keep it (6 B/element) instead of re-splitting x in
             # backward (HBM pass of 10 B/element per conv); sized for 288 GB
-            if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci)):
+            if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci)
+                    and xs.scheme == _wgrad_scheme(Ci, Co)):
                 xs = None
         else:
             _igemm(x, wp, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co, ldw=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
+        ctx.xs_scheme = xs.scheme if xs is not None else None
+        xs_buf, xs_scale = (xs.buf, xs.scale) if xs is not None else (None, None)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
-        ctx.save_for_backward(x, wp, y if relu else None, xs)
+        ctx.save_for_backward(x, wp, y if relu else None, xs_buf, xs_scale)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, dil, relu, has_bias = ctx.cfg
-        x, wp, y, xs = ctx.saved_tensors
+        x, wp, y, xs_buf, xs_scale = ctx.saved_tensors
+        xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
         dy = dy.contiguous()
         N, H, W_, Ci = x.shape
         Co, KH, KW, _ = wp.shape
@@ -247,8 +315,8 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co):
-                dys = split3(dy)
-                _igemm_b3(dys, split3_wT(wp), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
+                dys = split_op(dy)
+                _igemm_b3(dys, split_op_wT(wp, dys.scheme), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
                           ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
             else:
                 _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
@@ -256,7 +324,9 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1]:
             dwp = torch.empty_like(wp)
             if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
-                _wgrad_b3(xs if xs is not None else split3(x), dys if dys is not None else split3(dy), dwp, N_img=N, Hi=H,
+                wsch = _wgrad_scheme(Ci, Co)
+                _wgrad_b3(xs if xs is not None else split_op(x, wsch),
+                          dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch), dwp, N_img=N, Hi=H,
                           Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
             else:
                 _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
@@ -499,7 +569,8 @@ class _GateConv(Function):
             _, Hm, Wm, Cc = h.shape
             hg = torch.empty((B, Hm, Wm, C4), dtype=torch.float32, device=spcol.device)
             if _b3_pays(B * Hm * Wm, C4, 9 * Cc, Cc):
-                _igemm_b3(split3(h), split3(wp), None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4,
+                hs_ = split_op(h)
+                _igemm_b3(hs_, split_op(wp, hs_.scheme), None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4,
                           ldc=C4, ldw=9 * Cc, KH=3, KW=3, pad=1, mode=0)
             else:
                 _igemm(h, wp, None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4, ldc=C4, ldw=9 * Cc,
@@ -526,8 +597,8 @@ class _GateConv(Function):
             if ctx.needs_input_grad[0]:
                 dh = torch.empty_like(h)
                 if _b3_pays(B * Hm * Wm, Cc, 9 * C4, C4):
-                    dys = split3(dhg)
-                    _igemm_b3(dys, split3_wT(wp), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
+                    dys = split_op(dhg)
+                    _igemm_b3(dys, split_op_wT(wp, dys.scheme), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
                               Nout=Cc, ldc=Cc, ldw=9 * C4, KH=3, KW=3, pad=1, mode=1)
                 else:
                     _igemm(dhg, wp, None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm, Nout=Cc, ldc=Cc, ldw=Cc,
@@ -535,7 +606,8 @@ class _GateConv(Function):
             if ctx.needs_input_grad[1]:
                 dwp = torch.empty_like(wp)
                 if _w3_pays(B * Hm * Wm, C4, 9 * Cc, Cc):
-                    _wgrad_b3(split3(h), dys if dys is not None else split3(dhg), dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, Ho=Hm,
+                    wsch = _wgrad_scheme(Cc, C4)
+                    _wgrad_b3(split_op(h, wsch), dys if dys is not None and dys.scheme == wsch else split_op(dhg, wsch), dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, Ho=Hm,
                               Wo=Wm, Co=C4, ldo=9 * Cc, KH=3, KW=3, pad=1)
                 else:
                     _wgrad(h, dhg, dwp, N_img=B, Hi=Hm, Wi=Wm, Ci=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Co=C4, ldy=C4, ldo=9 * Cc,

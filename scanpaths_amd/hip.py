@@ -42,6 +42,11 @@ SIGNATURES = {
     "sp_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_split3_bf16": (_I, [_P, _L, _P, _P]),
     "sp_split3_bf16_wT": (_I, [_P, _I, _I, _I, _P, _P]),
+    "sp_split2_f16": (_I, [_P, _L, _P, _P, _P]),
+    "sp_split2_f16_wT": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "sp_conv_igemm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_conv_wgrad_f16x2_workspace": (_L, [_P]),
+    "sp_conv_wgrad_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_igemm_bf16x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_bf16x3_workspace": (_L, [C.POINTER(WgradDesc)]),
     "sp_conv_wgrad_bf16x3": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),

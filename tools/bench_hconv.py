@@ -18,6 +18,11 @@ hip.TIMER = hip.KernelTimer(min_flops=1e9)
 for _ in range(10):
     y = F.conv2d(h, w, None, pad=1); y.backward(gy)
 torch.cuda.synchronize()
+if F.SPLIT_SCHEME != "bf16x3":          # the 3 x bf16 / 6-product scheme next to the default 2 x fp16 / 3-product one
+    F.SPLIT_SCHEME = "bf16x3"
+    for _ in range(6):
+        y = F.conv2d(h, w, None, pad=1); y.backward(gy)
+    torch.cuda.synchronize()
 out = {}
 F.USE_BF16X3 = False
 for _ in range(6):

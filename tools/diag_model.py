@@ -7,6 +7,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from helpers import case_inputs, load_golden, max_err
 from test_model_gpu import _build, _call, DEV
 from scanpaths_amd.models.loss import supervised_loss
+from scanpaths_amd import functional as F
+if os.environ.get("SP_SPLIT_SCHEME"):
+    F.SPLIT_SCHEME = os.environ["SP_SPLIT_SCHEME"]
+if os.environ.get("SP_NO_SPLIT"):
+    F.USE_BF16X3 = False
 
 def fwd(name):
     meta, g = load_golden(name)
