@@ -504,14 +504,27 @@ int hw_splits(const sp_wgrad_desc* d) {
 // amax over a tensor: atomicMax on the bit pattern of |x| (non-negative floats order like unsigned ints) -- exact, order-free.
 __global__ __launch_bounds__(256) void amax_kernel(const float* x, int64_t n4, int64_t n, unsigned* out) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // 4 independent 16-byte loads in flight per thread
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float mb = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
+        const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+        const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+    }
+    for (; i < n4; i += stride) {
+        const float4 v = x4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     if (blockIdx.x == 0)
-        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+        for (int64_t j = n4 * 4 + threadIdx.x; j < n; j += blockDim.x) m = fmaxf(m, fabsf(x[j]));
+    // one atomic per block: same-address atomics serialise at the L2 (32k of them cost 0.3 ms)
+    __shared__ float sh4[4];
+    m = block_max_256(m, sh4);
+    if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
 }
 
 // power-of-two scale with amax * s in [8192, 16384)
@@ -596,7 +609,7 @@ int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
     hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned), s);
     if (e != hipSuccess) return (int)e;
     const int64_t n4 = n / 4;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256 * 4), 2048));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256 * 4), 1024));
     hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, n, amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
