@@ -103,7 +103,7 @@ int sp_conv_wgrad_bf16x3(const sp_wgrad_desc* d, const void* Xsplit, const void*
  * power-of-two scale s (amax * s in [8192, 16384)), a*b = (a1b1 + a1b2 + a2b1)/(sa*sb); still closer to fp64 than a CPU fp32
  * GEMM (7.6e-8 vs 1.2e-7..3e-7 relative) at half the MFMA work of the bf16x3 scheme.  sp_split2_f16: fp32 [rows][K]
  * (K % 16 == 0) -> [rows][K/16][2][16] fp16 + 64-byte zero block (2n+32 halfs); scale_amax = 2 device words {scale (written),
- * scratch}.  igemm: Kc % 32 == 0 (a 32-k K-tile must lie inside one tap); wgrad: Ci % 128 == 0, Co % 16 == 0. */
+ * scratch}.  igemm: Kc % 32 == 0 (a 32-k K-tile must lie inside one tap); wgrad: Ci % 16 == 0, Co % 16 == 0. */
 int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax, void* stream);
 int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* out, float* scale_amax, void* stream);
 int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit, const float* w_scale,

@@ -304,8 +304,6 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
     const int co0 = tmi * 256, n0 = tn * 128;
-    const int tap = n0 / p.Ci, ci0 = n0 - tap * p.Ci;           // Ci % 128 == 0: a column tile lies inside one tap
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
     const int split = blockIdx.y;
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
     const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
@@ -324,16 +322,23 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         a_cok[j] = co0 + (js >> 2) * 16 < p.Co;
         a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.Co) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
     }
-    int b_r[2], b_c8[2], b_b[2], b_y[2], b_x[2];
+    // a 128-column tile of (tap, ci) may span several filter taps when Ci < 128: every 16-channel chunk group lies inside one
+    // tap (Ci % 16 == 0), so the tap is a per-lane constant
+    int b_r[2], b_c8[2], b_b[2], b_y[2], b_x[2], b_dy[2], b_dx[2];
     bool b_live[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 5, pos = g & 31;
         const int js = (pos - rot4(r & 3)) & 31;
+        const int col = n0 + (js >> 2) * 16;                      // first column of this lane's 16-channel group
+        const int tap = col / p.Ci, ci = col - tap * p.Ci;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        b_dy[j] = ky * p.dil - p.pad;
+        b_dx[j] = kx * p.dil - p.pad;
         b_r[j] = r;
-        b_c8[j] = ci0 * 4 + js * 16;
-        b_live[j] = n0 + (js >> 2) * 16 < p.Ntot;
+        b_c8[j] = ci * 4 + (js & 3) * 16;
+        b_live[j] = col < p.Ntot;
         const int64_t m = m_begin + r;                            // coordinates of this lane's pixel in K-tile 0
         const int b = (int)(m / HoWo);
         const int rem = (int)(m - (int64_t)b * HoWo);
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.X);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int iy = b_y[j] * p.stride - p.pad + ky * p.dil, ix = b_x[j] * p.stride - p.pad + kx * p.dil;
+            const int iy = b_y[j] * p.stride + b_dy[j], ix = b_x[j] * p.stride + b_dx[j];
             const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             const uint32_t off = (uint32_t)((b_b[j] * p.Hi + iy) * p.Wi + ix) * xrow + (uint32_t)b_c8[j];
             SP_GLDS16(baseB + (ok ? off : p.x_bytes), st + HWA_BYTES + (wave + 8 * j) * 1024);
@@ -681,7 +686,7 @@ extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
 extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                                    const float* y_scale, float* dW, void* workspace, void* stream) {
     if (!d || !Xsplit || !dYsplit || !x_scale || !y_scale || !dW) return SP_ENULL;
-    if (d->Ci % 128 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
+    if (d->Ci % 16 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
     if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
     HWArgs a;
     a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;

@@ -156,19 +156,19 @@ def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, l
     hip.TIMER.bracket(key, 2.0 * M * Nout * K, launch)
 
 
+def _wgrad_scheme(Ci, Co) -> str:
+    return "f16x2" if _scheme_for(Ci) == "f16x2" and _scheme_for(Co) == "f16x2" else "bf16x3"
+
+
 def _w3_pays(M, Co, K, Ci, nbatch=1):
-    if not USE_BF16X3 or nbatch != 1 or Ci % 128 or Co % 16 or Co < 128:
+    f16 = _wgrad_scheme(Ci, Co) == "f16x2"          # the 2xfp16 kernel takes any Ci % 16 == 0, the 3xbf16 one needs Ci % 128 == 0
+    if not USE_BF16X3 or nbatch != 1 or Co % 16 or Co < 64 or (Ci % 128 and not f16):
         return False
-    f16 = _scheme_for(Co) == "f16x2"
     flops = 2.0 * M * Co * K
     split_bytes = (12.0 if f16 else 10.0) * M * (Ci + Co)
     if 6.0 * M * max(Ci, Co) * 4 >= 2 ** 32:
         return False
     return flops * (1 / 1.0e14 - 1 / (3.2e14 if f16 else 1.6e14)) > split_bytes / 4e12 and flops > 2e9
-
-
-def _wgrad_scheme(Ci, Co) -> str:
-    return "f16x2" if _scheme_for(Ci) == "f16x2" and _scheme_for(Co) == "f16x2" else "bf16x3"
 
 
 def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0, alpha=1.0):
