@@ -15,6 +15,7 @@
 // 32 k = 128 bytes per row.  A 64-byte zero block follows the data (masked loader lanes); the scale lives in a device float.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -53,7 +54,8 @@ struct H2Args {
 // staging in a 3-stage ring with counted vmcnt (the structure of b3_kernel, see there for why).  Rows are 128 B = half a
 // 256-byte LDS bank row, so the source-side swizzle is an XOR: chunk c of row r is stored at position c ^ ((r>>1)&7); the 16
 // rows of every ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then hit 16 distinct 16-byte slots.
-template <int MODE>
+// DBG (env SP_H2_DBG, timing experiments only): 1 = no global loads (MFMA + LDS side alone), 2 = no MFMAs (load side alone)
+template <int MODE, int DBG>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -181,35 +183,51 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
+    constexpr bool do_load = DBG != 1, do_mma = DBG != 2;
     int issued = 0;
-    for (; issued < HNSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
+    if (do_load)
+        for (; issued < HNSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
     if (issued >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int stage = 0;
     for (int kt = 0; kt < p.nkt; ++kt) {
-        const bool pre = kt + HNSTAGE - 1 < p.nkt;
+        const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
         const unsigned char* st = smem + stage * HSTAGE;
+        // all 16 fragment reads of the K-tile are issued up front (64 VGPRs): the reads of the second 16-k group then complete
+        // behind the MFMAs of the first (with the reads interleaved per group the MFMA+LDS side alone took 3.4 ms)
+        f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 af[2][2], bf[2][2];
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
-                    bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
+                    af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
+                    bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
                 }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int kk = 0; kk < 2; ++kk) {
+            if constexpr (do_mma) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // three products, the two cross terms (~2^-11 of the main one) first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // three products, the two cross terms (~2^-11 of the main one) first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const f16x8 x0 = af[kk][i][pl], x1 = bf[kk][i][pl];
+                        asm volatile("" ::"v"(x0), "v"(x1));
+                    }
+            }
         }
         // prefetch of tile kt+2 behind the MFMAs in program order (see b3_kernel), into the stage read in iteration kt-1
         if (pre) issue_tile(stage == 0 ? HNSTAGE - 1 : stage - 1);
@@ -595,9 +613,9 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
-template <int MODE>
+template <int MODE, int DBG>
 int launch_h2(const H2Args& a, hipStream_t s) {
-    auto kern = h2_kernel<MODE>;
+    auto kern = h2_kernel<MODE, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HSTAGE);
@@ -674,7 +692,10 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
     if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
-    return d->mode == 0 ? launch_h2<0>(a, (hipStream_t)stream) : launch_h2<1>(a, (hipStream_t)stream);
+    static const int dbg = getenv("SP_H2_DBG") ? atoi(getenv("SP_H2_DBG")) : 0;
+    if (dbg == 1) return d->mode == 0 ? launch_h2<0, 1>(a, (hipStream_t)stream) : launch_h2<1, 1>(a, (hipStream_t)stream);
+    if (dbg == 2) return d->mode == 0 ? launch_h2<0, 2>(a, (hipStream_t)stream) : launch_h2<1, 2>(a, (hipStream_t)stream);
+    return d->mode == 0 ? launch_h2<0, 0>(a, (hipStream_t)stream) : launch_h2<1, 0>(a, (hipStream_t)stream);
 }
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {

@@ -1,0 +1,32 @@
+"""Diagnostic: eval outputs of samples 0..1 at per-GPU batch 32 (320x512) vs the same samples at batch 2 vs the fp64 / fp32 oracle.
+Separates 'rounding noise of a random-weight net' from a large-batch bug."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import scanpath_oracle as O
+from scanpaths_amd import functional as F
+from scanpaths_amd.models.baseline_attention import baseline
+from scanpaths_amd.procedural import fill_module, procedural_state_dict
+from scanpaths_amd.spec import model_spec
+from scanpaths_amd.synth import make_batch
+if os.environ.get("SP_SPLIT_SCHEME"):
+    F.SPLIT_SCHEME = os.environ["SP_SPLIT_SCHEME"]
+if os.environ.get("SP_NO_SPLIT"):
+    F.USE_BF16X3 = False
+DEV = torch.device("cuda:0")
+T, B = 1, int(os.environ.get("B", 32))
+m = baseline(convLSTM_length=T, map_width=64, map_height=40); fill_module(m, 4); m = m.to(DEV).eval()
+b = make_batch("AiR", B, 320, 512, T, seed=4)
+img, att = b["images"].to(DEV), b["attention_maps"].to(DEV)
+with torch.no_grad():
+    big = {k: v.cpu() for k, v in m(img, att).items()}
+    small = {k: v.cpu() for k, v in m(img[:2].contiguous(), att[:2].contiguous()).items()}
+sd = procedural_state_dict(model_spec("AiR", "resnet50", 40, 64), seed=4)
+sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+with torch.no_grad():
+    r64 = O.forward(sd64, "AiR", b["images"][:2].double(), b["attention_maps"][:2].double(), None, training=False, T=T)
+    r32 = O.forward(sd, "AiR", b["images"][:2], b["attention_maps"][:2], None, training=False, T=T)
+for k in big:
+    ref = r64[k].double()
+    sc = float(ref.abs().max())
+    e = lambda t: float((t.double() - ref).abs().max()) / sc
+    print(f"{k:28s} scale {sc:9.3e}  bs{B}[:2] {e(big[k][:2]):.2e}  bs2 {e(small[k]):.2e}  oracle32 {e(r32[k]):.2e}")
