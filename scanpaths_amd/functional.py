@@ -160,12 +160,14 @@ def _wgrad_scheme(Ci, Co) -> str:
     return "f16x2" if _scheme_for(Ci) == "f16x2" and _scheme_for(Co) == "f16x2" else "bf16x3"
 
 
-def _w3_pays(M, Co, K, Ci, nbatch=1):
+def _w3_pays(M, Co, K, Ci, nbatch=1, free_splits=False):
+    """free_splits: both split operands already exist (x kept from the forward GEMM, dy split for the data-gradient GEMM), so
+    the split weight-gradient kernel only has to beat the fp32 one"""
     f16 = _wgrad_scheme(Ci, Co) == "f16x2"          # the 2xfp16 kernel takes any Ci % 16 == 0, the 3xbf16 one needs Ci % 128 == 0
     if not USE_BF16X3 or nbatch != 1 or Co % 16 or Co < 64 or (Ci % 128 and not f16):
         return False
     flops = 2.0 * M * Co * K
-    split_bytes = (12.0 if f16 else 10.0) * M * (Ci + Co)
+    split_bytes = 0.0 if free_splits else (12.0 if f16 else 10.0) * M * (Ci + Co)
     if 6.0 * M * max(Ci, Co) * 4 >= 2 ** 32:
         return False
     return flops * (1 / 1.0e14 - 1 / (3.2e14 if f16 else 1.6e14)) > split_bytes / 4e12 and flops > 2e9
@@ -285,7 +287,7 @@ class _Conv2d(Function):
                       ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
             # the weight-gradient GEMM consumes the same split operand: keep it (6 B/element) instead of re-splitting x in
             # backward (HBM pass of 10 B/element per conv); sized for 288 GB
-            if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci)
+            if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=True)
                     and xs.scheme == _wgrad_scheme(Ci, Co)):
                 xs = None
         else:
@@ -323,8 +325,9 @@ class _Conv2d(Function):
                        KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
         if ctx.needs_input_grad[1]:
             dwp = torch.empty_like(wp)
-            if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
-                wsch = _wgrad_scheme(Ci, Co)
+            wsch = _wgrad_scheme(Ci, Co)
+            free = xs is not None and (dys is not None and dys.scheme == wsch)
+            if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=free):
                 _wgrad_b3(xs if xs is not None else split_op(x, wsch),
                           dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch), dwp, N_img=N, Hi=H,
                           Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)

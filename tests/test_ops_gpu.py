@@ -54,9 +54,9 @@ def test_conv2d_fwd_bwd(case, path, monkeypatch):
     if path != "fp32_mfma":    # force the split kernels even where the cost model would not pick them
         monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1: nbatch == 1 and Kc % 16 == 0)
         if path == "f16x2":    # the 2xfp16 weight-gradient kernel also takes column tiles that span several filter taps (Ci < 128)
-            monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1: nbatch == 1 and Ci % 32 == 0 and Co % 32 == 0)
+            monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1, **kw: nbatch == 1 and Ci % 32 == 0 and Co % 32 == 0)
         else:
-            monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1: nbatch == 1 and Ci % 128 == 0 and Co % 16 == 0)
+            monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1, **kw: nbatch == 1 and Ci % 128 == 0 and Co % 16 == 0)
     N, H, W, Ci, Co, k, s, p, d, has_b, relu = case
     x = _rand(N, Ci, H, W, seed=1)
     w = _rand(Co, Ci, k, k, seed=2, scale=1.0 / math.sqrt(Ci * k * k))
@@ -449,7 +449,7 @@ def test_split_gemms_are_as_accurate_as_cpu_fp32():
     try:
         F.USE_BF16X3 = True
         F._b3_pays = lambda M, N, K, Kc, nbatch=1: True
-        F._w3_pays = lambda M, Co, K, Ci, nbatch=1: True
+        F._w3_pays = lambda M, Co, K, Ci, nbatch=1, **kw: True
         for scheme in ("f16x2", "bf16x3"):
             F.SPLIT_SCHEME = scheme
             hd = h.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
