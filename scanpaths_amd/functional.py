@@ -118,14 +118,16 @@ def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     return SplitOperand(out, scale, scheme)
 
 
-def _b3_pays(M, N, K, Kc, nbatch=1):
-    """cost model: split passes (10-12 B per operand element at ~4 TB/s) + split GEMM (~2.3x / ~4x the fp32 rate) < fp32 GEMM"""
+def _b3_pays(M, N, K, Kc, nbatch=1, a_elems=None):
+    """cost model: split passes (10-12 B per operand element at ~4 TB/s) + split GEMM (~2.3x / ~4x the fp32 rate) < fp32 GEMM.
+    a_elems: elements of the activation-side tensor (the loaders use 32-bit byte offsets into the split operand)"""
     if not USE_BF16X3 or nbatch != 1 or Kc % 16 or N < 64:
         return False
     f16 = _scheme_for(Kc) == "f16x2"
     flops = 2.0 * M * N * K
     split_bytes = (12.0 if f16 else 10.0) * (M * Kc + N * K)
-    if 6.0 * M * Kc * 4 >= 2 ** 32 or 6.0 * N * K >= 2 ** 32:     # loaders use 32-bit byte offsets (x4: strided / dilated sources)
+    bpe = 4.0 if f16 else 6.0
+    if bpe * (a_elems if a_elems is not None else 4.0 * M * Kc) + 64 >= 2 ** 32 or bpe * N * K + 64 >= 2 ** 32:
         return False
     return flops * (1 / 1.1e14 - 1 / (4.0e14 if f16 else 2.5e14)) > split_bytes / 4e12 and flops > 2e9
 
@@ -281,7 +283,7 @@ class _Conv2d(Function):
         Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
         xs = None
-        if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci):
+        if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel()):
             xs = split_op(x)
             _igemm_b3(xs, split_op(wp, xs.scheme), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
                       ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
@@ -316,7 +318,7 @@ class _Conv2d(Function):
         dys = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co):
+            if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel()):
                 dys = split_op(dy)
                 _igemm_b3(dys, split_op_wT(wp, dys.scheme), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
                           ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)

@@ -52,7 +52,7 @@ def test_conv2d_fwd_bwd(case, path, monkeypatch):
     monkeypatch.setattr(F, "USE_BF16X3", path != "fp32_mfma")
     monkeypatch.setattr(F, "SPLIT_SCHEME", path if path != "fp32_mfma" else "bf16x3")
     if path != "fp32_mfma":    # force the split kernels even where the cost model would not pick them
-        monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1: nbatch == 1 and Kc % 16 == 0)
+        monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1, **kw: nbatch == 1 and Kc % 16 == 0)
         if path == "f16x2":    # the 2xfp16 weight-gradient kernel also takes column tiles that span several filter taps (Ci < 128)
             monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1, **kw: nbatch == 1 and Ci % 32 == 0 and Co % 32 == 0)
         else:
@@ -448,7 +448,7 @@ def test_split_gemms_are_as_accurate_as_cpu_fp32():
     saved = (F.USE_BF16X3, F.SPLIT_SCHEME, F._b3_pays, F._w3_pays)
     try:
         F.USE_BF16X3 = True
-        F._b3_pays = lambda M, N, K, Kc, nbatch=1: True
+        F._b3_pays = lambda M, N, K, Kc, nbatch=1, **kw: True
         F._w3_pays = lambda M, Co, K, Ci, nbatch=1, **kw: True
         for scheme in ("f16x2", "bf16x3"):
             F.SPLIT_SCHEME = scheme
