@@ -39,6 +39,18 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
     return w
 
 
+def union_flags(flags, device, group=None):
+    """Element-wise OR across ranks of a list of booleans (which parameters received a gradient this step).  Under the
+    reference's DataParallel one optimizer sees the reduce-added gradients, so a parameter is updated when ANY replica used
+    it (COCO_Search18: the per-category heads of the categories present anywhere in the global batch); every rank must take
+    the same decision or the replicas drift apart."""
+    if world_size(group) == 1:
+        return list(flags)
+    t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [bool(v) for v in t.tolist()]
+
+
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
     """DataParallel-style scatter along dim 0 (AiR/train.py:170): every tensor input splits the same way."""
     out = {}

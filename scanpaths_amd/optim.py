@@ -94,8 +94,10 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         world = 1
         if self.process_group is not False:   # RCCL sum over xGMI of ONE flat buffer; averaged inside the Adam kernel
-            from .ddp import allreduce_sum_
+            from .ddp import allreduce_sum_, union_flags
             world = allreduce_sum_(self.flat_g, self.process_group)
+            if world > 1:      # e.g. COCO heads of categories absent from this rank's shard; unconditional: a collective
+                self._touched = union_flags(self._touched, self.flat_g.device, self.process_group)
         L = hip.lib()
         ws = hip.workspace(L.sp_sumsq_workspace(self.numel), self.flat_g.device, slot=1)
         check(L.sp_sumsq(ptr(self.flat_g), self.numel, ptr(self._sumsq), ptr(ws), hip.stream()), "sp_sumsq")

@@ -47,6 +47,9 @@ def _worker(rank, world, port, q):
     flat /= n
     loss_sum = la_r.detach().clone()
     dist.all_reduce(loss_sum)
+    from scanpaths_amd.ddp import union_flags
+    mine = [rank == 0, rank == 1, False, True]          # which "parameters" this rank touched
+    assert union_flags(mine, torch.device("cpu")) == [True, True, False, True]
     q.put((rank, float((flat - gref).abs().max()), float(loss_sum / world - la), float(norm[0] * world - fd["action_masks"].sum())))
     dist.destroy_process_group()
 
