@@ -202,7 +202,9 @@ def main():
            "value_per_gpu": round(value / world, 3),
            "config": {"workload": f"AiR supervised train step (fwd+loss+bwd+clip+Adam), {args.arch}, T={args.T}, "
                                   f"{args.height}x{args.width}, per-GPU batch {args.batch}",
-                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 5)},
+                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 5),
+                      "arithmetic": "fp32 in / fp32 out / fp32 accumulation; GEMM operands as exact-scaled 2xfp16 splits with 3 MFMA "
+                                    "products (error vs fp64 below a CPU fp32 GEMM, tools/gemm_error.py); no reduced-precision storage"},
            "roofline": roofline}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

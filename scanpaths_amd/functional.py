@@ -9,6 +9,7 @@ implicit-GEMM kernels consume and the layout their weight gradients are produced
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -60,9 +61,14 @@ def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=
 
 
 # ---- fp32-faithful GEMMs on the 16-bit matrix pipe (csrc/conv_f16x2.hip, csrc/conv_bf16x3.hip) ---------------------
-USE_BF16X3 = True          # False -> every GEMM on the fp32 MFMA kernel (parity triage / A-B timing)
-SPLIT_SCHEME = "f16x2"     # "f16x2": 2 fp16 planes + per-tensor power-of-two scale, 3 MFMA products (default);
-                           # "bf16x3": 3 bf16 planes, 6 products (no scale pass; used when a channel count is not a multiple of 32)
+# USE_BF16X3 False -> every GEMM on the fp32 MFMA kernel (parity triage / A-B timing).
+# SPLIT_SCHEME "f16x2": 2 fp16 planes + per-tensor power-of-two scale, 3 MFMA products (default);
+#              "bf16x3": 3 bf16 planes, 6 products (no scale pass; also used when a channel count is not a multiple of 32).
+# Environment overrides: SP_NO_SPLIT=1, SP_SPLIT_SCHEME=bf16x3|f16x2.
+USE_BF16X3 = not os.environ.get("SP_NO_SPLIT")
+SPLIT_SCHEME = os.environ.get("SP_SPLIT_SCHEME", "f16x2")
+if SPLIT_SCHEME not in ("f16x2", "bf16x3"):
+    raise ValueError(f"SP_SPLIT_SCHEME must be f16x2 or bf16x3, got {SPLIT_SCHEME!r}")
 
 
 class SplitOperand:
