@@ -259,6 +259,15 @@ int64_t sp_scanpath_loss_workspace(int B, int T);
 int sp_scanpath_loss(const float* z, const float* gt, const float* amask, const float* mu, const float* sigma2,
                      const float* dur, const float* dmask, int B, int T, int A, float lambda1, const float* mask_sums,
                      float* out3, float* dz, float* dmu, float* dsigma2, void* workspace, void* stream);
+/* RL (self-critical) phase log-probabilities, models/loss.py:34-45 (callers AiR/train.py:288-289).  Value and per-element
+ * derivative in one pass; mask_sum = device scalar sum(mask) over the whole tensor (the reference's normaliser).
+ *   log_action:   out[b] = sum_t log(p[b,t] + 1e-7) * mask[b,t] / mask_sum;   dcoef[b,t] = d out[b] / d p[b,t]
+ *   log_duration: out[b] = sum_t (log(1/(d+1e-7) * 1/sqrt(2 pi s2)) - (log(d+1e-7) - mu)^2 / (2 s2)) * mask / mask_sum
+ *   rowscale:     out[b,t] = coef[b,t] * g[b]   (chain rule of the two above) */
+int sp_log_action(const float* p, const float* mask, int B, int T, const float* mask_sum, float* out, float* dcoef, void* stream);
+int sp_log_duration(const float* d, const float* mu, const float* sigma2, const float* mask, int B, int T, const float* mask_sum,
+                    float* out, float* dmu, float* dsigma2, void* stream);
+int sp_rowscale(const float* coef, const float* g, int B, int T, float* out, void* stream);
 /* out = x * (*scale) with the scalar on the device (chain-rule factor of the loss, no host sync) */
 int sp_scale_by(const float* x, const float* scale, int64_t n, float* out, void* stream);
 /* deterministic sums (fp64 accumulation); workspace >= sp_sumsq_workspace(n) bytes for both */

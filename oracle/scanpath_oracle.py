@@ -313,3 +313,13 @@ def scanpath_length(selected_actions, T):
         length[torch.logical_and(length == 0, selected_actions[:, t] == 0)] = t
     length[length == 0] = T
     return length.unsqueeze(-1)
+
+
+# ---- RL (self-critical) phase log-probabilities, AiR/models/loss.py:34-45 ------------------------------------------------
+def log_action(p, mask):
+    return (torch.log(p + EPS) * mask).sum(dim=-1) / mask.sum()
+
+
+def log_duration(d, mu, sigma2, mask):
+    items = torch.log(1 / (d + EPS) * 1 / (torch.sqrt(2 * math.pi * sigma2))) + (-(torch.log(d + EPS) - mu) ** 2 / (2 * sigma2))
+    return (items * mask).sum(dim=-1) / mask.sum()

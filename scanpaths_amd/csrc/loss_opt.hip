@@ -140,6 +140,47 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* x, const flo
         out[i] = x[i] * k;
 }
 
+// ---- RL (self-critical) log-probabilities, models/loss.py:34-45 -- value and per-element derivative in one pass ----------
+// LogAction:   out[b] = sum_t log(p[b,t] + eps) * mask[b,t] / sum(mask)                       dcoef = d out[b] / d p[b,t]
+// LogDuration: item = log(1/(d+eps) * 1/sqrt(2 pi s2)) - (log(d+eps) - mu)^2 / (2 s2);  out[b] = sum_t item * mask / sum(mask)
+// msum: device scalar sum(mask) over the WHOLE tensor (the reference divides every row by the global mask sum).
+__global__ __launch_bounds__(64) void log_action_kernel(const float* p, const float* mask, int T, const float* msum, float* out,
+                                                        float* dcoef) {
+    const int b = blockIdx.x;
+    const float inv = 1.f / msum[0];
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < T; t += 64) {
+        const float v = p[(int64_t)b * T + t], m = mask[(int64_t)b * T + t];
+        acc += logf(v + EPS) * m;
+        dcoef[(int64_t)b * T + t] = m / (v + EPS) * inv;
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[b] = acc * inv;
+}
+
+__global__ __launch_bounds__(64) void log_duration_kernel(const float* d, const float* mu, const float* s2, const float* mask,
+                                                          int T, const float* msum, float* out, float* dmu, float* ds2) {
+    const int b = blockIdx.x;
+    const float inv = 1.f / msum[0];
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < T; t += 64) {
+        const int64_t i = (int64_t)b * T + t;
+        const float m = mask[i], sg = s2[i];
+        const float Lg = logf(d[i] + EPS), r = Lg - mu[i];
+        const float item = logf(1.f / (d[i] + EPS) * 1.f / sqrtf(2.f * 3.14159265358979323846f * sg)) - r * r / (2.f * sg);
+        acc += item * m;
+        dmu[i] = m * inv * (r / sg);
+        ds2[i] = m * inv * (-0.5f / sg + r * r / (2.f * sg * sg));
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[b] = acc * inv;
+}
+
+// out[b,t] = coef[b,t] * g[b]
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* coef, const float* g, int64_t n, int T, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = coef[i] * g[i / T];
+}
+
 }  // namespace
 
 extern "C" int sp_scale_by(const float* x, const float* scale, int64_t n, float* out, void* stream) {
@@ -203,6 +244,35 @@ extern "C" int sp_clip_adam(float* p, const float* g, float* m, float* v, int64_
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n, 256), 4096));
     hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, gscale, clip,
                        lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_log_action(const float* p, const float* mask, int B, int T, const float* mask_sum, float* out, float* dcoef,
+                             void* stream) {
+    if (!p || !mask || !mask_sum || !out || !dcoef) return SP_ENULL;
+    if (B < 1 || T < 1) return SP_EINVAL;
+    hipLaunchKernelGGL(log_action_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, p, mask, T, mask_sum, out, dcoef);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_log_duration(const float* d, const float* mu, const float* sigma2, const float* mask, int B, int T,
+                               const float* mask_sum, float* out, float* dmu, float* dsigma2, void* stream) {
+    if (!d || !mu || !sigma2 || !mask || !mask_sum || !out || !dmu || !dsigma2) return SP_ENULL;
+    if (B < 1 || T < 1) return SP_EINVAL;
+    hipLaunchKernelGGL(log_duration_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, d, mu, sigma2, mask, T, mask_sum, out, dmu,
+                       dsigma2);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_rowscale(const float* coef, const float* g, int B, int T, float* out, void* stream) {
+    if (!coef || !g || !out) return SP_ENULL;
+    if (B < 1 || T < 1) return SP_EINVAL;
+    const int64_t n = (int64_t)B * T;
+    hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)std::min<int64_t>(sp_cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream,
+                       coef, g, n, T, out);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -260,6 +260,26 @@ def touch_zero_grad(t, params):
     return _ZeroGradTouch.apply(t, *params)
 
 
+class _ScaleConst(Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        x = x.contiguous()
+        ctx.c = float(c)
+        cs = torch.full((1,), float(c), dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        check(hip.lib().sp_scale_by(ptr(x), ptr(cs), x.numel(), ptr(out), hip.stream()), "sp_scale_by")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScaleConst.apply(g, ctx.c), None
+
+
+def scale_const(x: torch.Tensor, c: float) -> torch.Tensor:
+    """x * c (python constant), differentiable"""
+    return _ScaleConst.apply(x, c)
+
+
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a + b (same shape) as a differentiable HIP op."""
     return _Add.apply(a, b)

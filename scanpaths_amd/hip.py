@@ -103,6 +103,9 @@ SIGNATURES = {
     "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sp_scanpath_loss_workspace": (_L, [_I, _I]),
     "sp_scanpath_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_log_action": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
+    "sp_log_duration": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "sp_rowscale": (_I, [_P, _P, _I, _I, _P, _P]),
     "sp_scale_by": (_I, [_P, _P, _L, _P, _P]),
     "sp_sumsq_workspace": (_L, [_L]),
     "sp_sum": (_I, [_P, _L, _P, _P, _P]),

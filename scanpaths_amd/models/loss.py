@@ -65,3 +65,62 @@ class _Split(torch.autograd.Function):
 
 def _both(z, mu, s2, gt, am, dur, dm, sums):
     return _Split.apply(z, mu, s2, gt.contiguous(), am.contiguous(), dur.contiguous(), dm.contiguous(), sums)
+
+
+# ---- RL (self-critical) phase: per-sample log-probabilities of sampled scanpaths, AiR/models/loss.py:34-45 ----------------
+class _LogAction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, mask):
+        from ..hip import check, lib, ptr, stream
+        p, m = input.contiguous().float(), mask.contiguous().float()
+        B, T = p.shape
+        out = torch.empty(B, device=p.device)
+        coef = torch.empty_like(p)
+        check(lib().sp_log_action(ptr(p), ptr(m), B, T, ptr(F.device_sum(m)), ptr(out), ptr(coef), stream()), "sp_log_action")
+        ctx.save_for_backward(coef)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..hip import check, lib, ptr, stream
+        (coef,) = ctx.saved_tensors
+        B, T = coef.shape
+        dp = torch.empty_like(coef)
+        check(lib().sp_rowscale(ptr(coef), ptr(g.contiguous()), B, T, ptr(dp), stream()), "sp_rowscale")
+        return dp, None
+
+
+class _LogDuration(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, mu, sigma2, mask):
+        from ..hip import check, lib, ptr, stream
+        d, mu_, s2, m = (t.contiguous().float() for t in (input, mu, sigma2, mask))
+        B, T = d.shape
+        out = torch.empty(B, device=d.device)
+        dmu, ds2 = torch.empty_like(d), torch.empty_like(d)
+        check(lib().sp_log_duration(ptr(d), ptr(mu_), ptr(s2), ptr(m), B, T, ptr(F.device_sum(m)), ptr(out), ptr(dmu), ptr(ds2),
+                                    stream()), "sp_log_duration")
+        ctx.save_for_backward(dmu, ds2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..hip import check, lib, ptr, stream
+        dmu, ds2 = ctx.saved_tensors
+        B, T = dmu.shape
+        g = g.contiguous()
+        gmu, gs2 = torch.empty_like(dmu), torch.empty_like(ds2)
+        check(lib().sp_rowscale(ptr(dmu), ptr(g), B, T, ptr(gmu), stream()), "sp_rowscale")
+        check(lib().sp_rowscale(ptr(ds2), ptr(g), B, T, ptr(gs2), stream()), "sp_rowscale")
+        return None, gmu, gs2, None
+
+
+def LogAction(input, mask):
+    """[B] = sum_t log(p + eps) * mask / mask.sum()  -- probabilities of the sampled actions (AiR/models/loss.py:34-37)"""
+    return _LogAction.apply(input, mask)
+
+
+def LogDuration(input, log_normal_mu, log_normal_sigma2, mask):
+    """[B] = sum_t logpdf_lognormal(duration; mu, sigma2) * mask / mask.sum()  (AiR/models/loss.py:39-45); the sampled
+    durations carry no gradient (the reference passes durations.data)"""
+    return _LogDuration.apply(input, log_normal_mu, log_normal_sigma2, mask)

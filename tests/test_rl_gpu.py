@@ -1,0 +1,91 @@
+"""RL (self-critical) phase on the HIP path: log-probability kernels and the reward glue against the
+reference's outputs (tests/golden/rl.npz), the loss shaping against a literal torch restatement of AiR/train.py:296-342,
+and one end-to-end rl_step."""
+import os
+
+import numpy as np
+import pytest
+import scipy.stats
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "rl.npz"))
+
+
+def test_log_action_and_log_duration_match_reference():
+    from scanpaths_amd.models.loss import LogAction, LogDuration
+    t = lambda k: torch.from_numpy(GOLD[k]).float().to(DEV)
+    p = t("la_p").requires_grad_(True)
+    mu, s2 = t("ld_mu").requires_grad_(True), t("ld_s2").requires_grad_(True)
+    la = LogAction(p, t("la_mask"))
+    ld = LogDuration(t("ld_d"), mu, s2, t("ld_mask"))
+    ((la * t("w")).sum() + (ld * t("w")).sum() * 0.5).backward()
+    for got, want in ((la, "la_out"), (ld, "ld_out"), (p.grad, "la_dp"), (mu.grad, "ld_dmu"), (s2.grad, "ld_ds2")):
+        ref = GOLD[want]
+        err = np.abs(got.detach().cpu().double().numpy() - ref).max()
+        assert err <= 2e-6 * max(1.0, np.abs(ref).max()), (want, err)          # fp32 kernel vs the fp64 reference run
+
+
+def test_reward_glue_with_the_hip_scanmatch_matches_reference():
+    from test_scanmatch_oracle import check_rl_glue
+    from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch
+    cfg = dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), Threshold=3.5)
+    check_rl_glue(ScanMatch(TempBin=50, **cfg), ScanMatch(**cfg))               # bit-exact, batched on the device
+
+
+def test_rl_loss_matches_literal_restatement():
+    """AiR/train.py:296-342 restated literally in torch (incl. the lambda_5 no-op quirk) on random rewards"""
+    from scanpaths_amd.rl import rl_loss
+    g = np.random.Generator(np.random.PCG64(3))
+    S, N = 3, 5
+    same = g.uniform(0, 1, (2 * S, N, 2)); diff = g.uniform(0, 1, (2 * S, N, 2))
+    same[1, 2] = np.nan; diff[4, 0, 1] = np.nan; same[0, 3, 0] = 0.0
+    gg, gp, gd = g.uniform(0, 1, (N, 2)), g.uniform(0, 1, (N, 2)), g.uniform(0, 1, (N, 2))
+    gg[1] = np.nan
+    nla = torch.from_numpy(g.uniform(0.1, 2, (2 * S, N))).float()
+    nld = torch.from_numpy(g.uniform(0.1, 2, (2 * S, N))).float()
+    # literal restatement
+    s_, d_ = same.copy(), diff.copy()
+    s_[np.isnan(s_)] = 0; d_[np.isnan(d_)] = 0
+    st, dt = torch.tensor(s_, dtype=torch.float32), torch.tensor(d_, dtype=torch.float32)
+    with np.errstate(divide="ignore"):
+        sh = torch.tensor(scipy.stats.hmean(st, axis=-1)); dh = torch.tensor(scipy.stats.hmean(dt, axis=-1))
+    base = sh.view(2, -1, N).mean(1, keepdim=True).expand((2, S, N)).contiguous().view(-1, N)
+    a = nla.clone().requires_grad_(True); b = nld.clone().requires_grad_(True)
+    ref = (a * (sh - base)).sum() + (b * (sh - base)).sum()
+    ref.backward()
+    ad, bd = nla.to(DEV).requires_grad_(True), nld.to(DEV).requires_grad_(True)
+    loss, info = rl_loss(ad, bd, same, diff, gg, gp, gd, S, lambda_5=0.7)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert (ad.grad.cpu() - a.grad).abs().max() <= 1e-6 and (bd.grad.cpu() - b.grad).abs().max() <= 1e-6
+    assert info["lambda_5_terms_are_noops_in_the_reference"]
+
+
+def test_rl_step_end_to_end():
+    """eval-mode forward with autograd -> sampled scanpaths -> device ScanMatch rewards -> REINFORCE loss -> clip + Adam"""
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.sampling import Sampling
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.rl import rl_step
+    from scanpaths_amd.synth import make_batch
+    from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch
+    from test_scanmatch_oracle import rl_case
+    T, N = 4, 2
+    m = baseline(convLSTM_length=T)
+    fill_module(m, 6)
+    m = m.to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-5, weight_decay=5e-5, clip=12.5)
+    b = make_batch("AiR", N, 240, 320, T, seed=6)
+    gt, perf, _ = rl_case()
+    gt, perf = [gt[0], gt[3]], [perf[0], perf[3]]                         # two images with good and poor human scanpaths
+    cfg = dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), Threshold=3.5)
+    before = opt.flat_p.detach().clone()
+    loss, info = rl_step(m, Sampling(convLSTM_length=T, min_length=1, map_width=40, map_height=30, width=320, height=240, seed=1),
+                         opt, b["images"].to(DEV), b["attention_maps"].to(DEV), gt, perf, ScanMatch(TempBin=50, **cfg),
+                         ScanMatch(**cfg), rl_sample_number=2)
+    assert np.isfinite(float(loss)) and torch.isfinite(opt.flat_p).all()
+    assert float(info["grad_norm"]) > 0 and not torch.equal(before, opt.flat_p)
+    assert info["same_reward_hmean"].shape == (4, N) and not m.training

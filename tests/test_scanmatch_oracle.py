@@ -132,3 +132,61 @@ def test_sed_stde_random_pairs_bit_exact():
     assert np.array_equal(got8, GOLD2["rnd_sed_n8"])
     got = np.array([[MO.stde(fx[i], fx[j], (240, 320, 3)) for j in range(n)] for i in range(n)])
     same(got, GOLD2["rnd_stde"][:n, :n])
+
+
+# ---- RL reward glue: host grouping logic against the reference, with an oracle-backed scorer -----------------
+GOLD3 = np.load(os.path.join(os.path.dirname(__file__), "golden", "rl.npz"))
+_DT = {"names": ("start_x", "start_y", "duration"), "formats": ("f8", "f8", "f8")}
+
+
+class OracleScanMatch:
+    """the reference's ScanMatch call surface on top of oracle/scanmatch_oracle.py (tests only)"""
+    def __init__(self, tempbin):
+        self.tempbin = tempbin
+        self.S = SO.submatrix(16, 12, 3.5)
+
+    def fixationToSequence(self, data):
+        return SO.fixation_to_sequence(data, 320, 240, 16, 12, tempbin=self.tempbin).astype(np.float64)
+
+    def match(self, a, b):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return SO.nw_score(a, b, self.S, 0.0), None, None
+
+
+def rl_case():
+    def unflat(fix, lens):
+        out, o = [], 0
+        for n in lens:
+            fv = np.zeros(int(n), dtype=_DT)
+            fv["start_x"], fv["start_y"], fv["duration"] = fix[o:o + n, 0], fix[o:o + n, 1], fix[o:o + n, 2]
+            out.append(fv)
+            o += int(n)
+        return out
+    flat = unflat(GOLD3["gt_fix"], GOLD3["gt_len"])
+    gt, perf, o = [], [], 0
+    for c in GOLD3["gt_count"]:
+        gt.append(flat[o:o + int(c)])
+        perf.append([bool(v) for v in GOLD3["perf"][o:o + int(c)]])
+        o += int(c)
+    return gt, perf, unflat(GOLD3["pred_fix"], GOLD3["pred_len"])
+
+
+def check_rl_glue(wd, wod):
+    from scanpaths_amd.utils.evaluation import (gtpairs_eval_scanmatch_performance_related,
+                                                pairs_eval_scanmatch_performance_related)
+    gt, perf, pred = rl_case()
+    for given, tag in ((True, "good"), (False, "poor")):
+        s, d, acc = pairs_eval_scanmatch_performance_related(gt, pred, wd, wod, perf, given)
+        same(s, GOLD3[f"pairs_{tag}_same"])
+        same(d, GOLD3[f"pairs_{tag}_diff"])
+        assert int(acc) == int(GOLD3[f"pairs_{tag}_accept"])
+    g, p, dd = gtpairs_eval_scanmatch_performance_related(gt, wd, wod, perf)
+    same(g, GOLD3["gtpairs_good"])
+    same(p, GOLD3["gtpairs_poor"])
+    same(dd, GOLD3["gtpairs_diff"])
+
+
+def test_rl_reward_glue_matches_reference():
+    check_rl_glue(OracleScanMatch(50.0), OracleScanMatch(0.0))
