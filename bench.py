@@ -203,6 +203,7 @@ def main():
            "config": {"workload": f"AiR supervised train step (fwd+loss+bwd+clip+Adam), {args.arch}, T={args.T}, "
                                   f"{args.height}x{args.width}, per-GPU batch {args.batch}",
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 5),
+                      "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                       "arithmetic": "fp32 in / fp32 out / fp32 accumulation; GEMM operands as exact-scaled 2xfp16 splits with 3 MFMA "
                                     "products (error vs fp64 below a CPU fp32 GEMM, tools/gemm_error.py); no reduced-precision storage"},
            "roofline": roofline}

@@ -89,3 +89,67 @@ def test_rl_step_end_to_end():
     assert np.isfinite(float(loss)) and torch.isfinite(opt.flat_p).all()
     assert float(info["grad_norm"]) > 0 and not torch.equal(before, opt.flat_p)
     assert info["same_reward_hmean"].shape == (4, N) and not m.training
+
+
+def test_eval_mode_backward_matches_oracle():
+    """The RL phase differentiates the EVAL-mode forward (softmax heads, running-stat BatchNorm; AiR/train.py:244-251).  One
+    decode step at 240x320: a weighted sum of the eval outputs and its parameter gradients against the fp64 oracle; bar =
+    20x the fp32 oracle's own error or 1e-4 of the largest gradient norm (the bars of tests/test_model_gpu.py)."""
+    from helpers import oracle_state
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.spec import is_buffer
+    from scanpaths_amd.synth import make_batch
+    from test_model_gpu import _build
+    T = 1
+    meta = dict(task="AiR", arch="resnet50", T=T, weight_seed=21)
+    b = make_batch("AiR", 2, 240, 320, T, seed=21)
+    g = torch.Generator().manual_seed(21)
+    w = {k: torch.randn(s, generator=g) for k, s in (("good_all_actions_prob", (2, T, 1201)), ("poor_all_actions_prob", (2, T, 1201)),
+                                                      ("good_log_normal_mu", (2, T)), ("poor_log_normal_sigma2", (2, T)))}
+
+    def objective(pred, dt, dev):
+        return sum((pred[k] * w[k].to(dt).to(dev)).sum() for k in w)
+
+    # Random weights with the initial running statistics (mean 0, var 1) let activations explode layer by layer; the LSTM
+    # gates then saturate everywhere and the few gradients that survive depend on WHICH element is accidentally
+    # unsaturated (rounding noise of pre-activations of size 1e9).  Calibrate the running statistics to this batch instead
+    # (one train-mode pass of the oracle, momentum undone), as trained checkpoints have them.
+    base = oracle_state("AiR", "resnet50", 21, 30, 40, dtype=torch.float64)
+    bn_new = {}
+    with torch.no_grad():
+        O.forward(base, "AiR", b["images"].double(), b["attention_maps"].double(), b["performances"], training=True, T=T,
+                  bn_new=bn_new)
+    calib = {}
+    for k, v in bn_new.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            calib[k] = (v - 0.9 * base[k]) / 0.1
+    grads = {}
+    for dt in (torch.float64, torch.float32):
+        sd = oracle_state("AiR", "resnet50", 21, 30, 40, dtype=dt)
+        sd.update({k: v.to(dt) for k, v in calib.items()})
+        for k, v in sd.items():
+            if v.is_floating_point() and not is_buffer(k):
+                v.requires_grad_(True)
+        pred = O.forward(sd, "AiR", b["images"].to(dt), b["attention_maps"].to(dt), None, training=False, T=T)
+        val = objective(pred, dt, "cpu")
+        val.backward()
+        grads[dt] = ({k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}, float(val))
+    model = _build(meta, 30, 40)
+    model.load_state_dict({k: v.float() for k, v in calib.items()}, strict=False)
+    model = model.to(DEV).eval()
+    pred = model(b["images"].to(DEV), b["attention_maps"].to(DEV))
+    val = objective(pred, torch.float32, DEV)
+    val.backward()
+    g64, v64 = grads[torch.float64]
+    g32, v32 = grads[torch.float32]
+    assert abs(float(val) - v64) <= max(1e-4 * abs(v64), 20 * abs(v32 - v64)), (float(val), v64, v32)
+    top = max(float(v.norm()) for v in g64.values())
+    bad = []
+    for k, p in model.named_parameters():
+        if k not in g64:
+            continue
+        got = p.grad.detach().cpu().double() if p.grad is not None else torch.zeros_like(g64[k])
+        e, floor = float((got - g64[k]).norm()), float((g32[k].double() - g64[k]).norm())
+        if not e <= max(1e-4 * top, 20 * floor):
+            bad.append((k, e, floor, float(g64[k].norm())))
+    assert not bad, bad[:12]
