@@ -150,6 +150,9 @@ int sp_maxpool3s2_bwd(const float* dy, const float* x, const float* y, int N, in
 int sp_nchw_to_nhwc_pad(const float* x, int N, int C, int H, int W, int Cp, float* y, void* stream);
 int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, void* stream);
 /* dx = dy * (y > 0)  (ReLU fused into a conv epilogue, e.g. F.relu(sal_conv(x)) baseline_attention.py:270) */
+/* out = inputs[0] + ... + inputs[count-1] in list order (count <= 32 host array of device pointers, n % 4 == 0): the gradient
+ * fan-in of a tensor consumed by every decode step (x-gate pre-activations), one pass instead of count-1 adds */
+int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, void* stream);
 int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
 /* out = a + b (residual joins in backward), n elements */
 int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -348,6 +348,22 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
         reinterpret_cast<float4*>(o)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
     }
 }
+// out = sum of up to 32 equally sized tensors in list order (gradient fan-in of a tensor used by every decode step: one
+// pass over T inputs instead of T-1 read-read-write adds)
+struct SumList {
+    const float* p[32];
+    int n;
+};
+__global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc = reinterpret_cast<const float4*>(l.p[0])[i];
+        for (int k = 1; k < l.n; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(l.p[k])[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(o)[i] = acc;
+    }
+}
 __global__ __launch_bounds__(256) void add_tail_kernel(const float* a, const float* b, float* o, int64_t start, int64_t n) {
     const int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = a[i] + b[i];
@@ -504,6 +520,20 @@ extern "C" int sp_add(const float* a, const float* b, float* out, int64_t n, voi
         hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, b, out, n4 * 4, n);
         SP_LAUNCH_CHECK();
     }
+    return SP_OK;
+}
+
+extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, void* stream) {
+    if (!inputs || !out) return SP_ENULL;
+    if (count < 1 || count > 32 || n % 4) return SP_EINVAL;
+    SumList l;
+    l.n = count;
+    for (int k = 0; k < count; ++k) {
+        if (!inputs[k]) return SP_ENULL;
+        l.p[k] = inputs[k];
+    }
+    hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4);
+    SP_LAUNCH_CHECK();
     return SP_OK;
 }
 

@@ -260,6 +260,37 @@ def touch_zero_grad(t, params):
     return _ZeroGradTouch.apply(t, *params)
 
 
+class _FanOut(Function):
+    """x -> n aliases of x for n consumers; backward adds the n gradients in ONE pass (sp_sum_n) instead of the n-1
+    read-read-write adds autograd would issue.  Used for the hoisted x-gate pre-activations (one consumer per decode step)."""
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        n = out.numel()
+        if n % 4 or len(gs) > 32:
+            acc = gs[0]
+            for g in gs[1:]:
+                acc = _add_raw(acc, g)
+            return acc, None
+        arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), hip.stream()), "sp_sum_n")
+        return out, None
+
+
+def fanout(x: torch.Tensor, n: int):
+    return _FanOut.apply(x, n)
+
+
 class _ScaleConst(Function):
     @staticmethod
     def forward(ctx, x, c):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sp_bn_eval_stats": (_I, [_P, _P, _I, _F, _P, _P, _P]),
     "sp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P]),
     "sp_bn_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "sp_sum_n": (_I, [_P, _I, _L, _P, _P]),
     "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
     "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sp_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
