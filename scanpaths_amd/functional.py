@@ -331,7 +331,9 @@ def _out_hw(H, W, KH, KW, stride, pad, dil):
 # ----------------------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, relu):
+    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None):
+        # wcache: dict shared by all applications of the SAME weight inside one forward/backward (the h-gate conv runs T times):
+        # its split forms ("w": forward operand, "wT": data-gradient operand) are produced once instead of per step
         x = x.contiguous()
         N, H, W_, Ci = x.shape
         wp = _phys(w.detach())
@@ -342,7 +344,12 @@ class _Conv2d(Function):
         xs = None
         if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel()):
             xs = split_op(x)
-            _igemm_b3(xs, split_op(wp, xs.scheme), bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
+            wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
+            if wsplit is None:
+                wsplit = split_op(wp, xs.scheme)
+                if wcache is not None:
+                    wcache[("w", xs.scheme)] = wsplit
+            _igemm_b3(xs, wsplit, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
                       ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
             # the weight-gradient GEMM consumes the same split operand: keep it (6 B/element) instead of re-splitting x in
             # backward (HBM pass of 10 B/element per conv); sized for 288 GB
@@ -355,6 +362,7 @@ class _Conv2d(Function):
         ctx.xs_scheme = xs.scheme if xs is not None else None
         xs_buf, xs_scale = (xs.buf, xs.scale) if xs is not None else (None, None)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
+        ctx.wcache = wcache
         ctx.save_for_backward(x, wp, y if relu else None, xs_buf, xs_scale)
         return y
 
@@ -377,7 +385,13 @@ class _Conv2d(Function):
             dx = torch.empty_like(x)
             if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel()):
                 dys = split_op(dy)
-                _igemm_b3(dys, split_op_wT(wp, dys.scheme), None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
+                wcache = ctx.wcache
+                wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
+                if wT is None:
+                    wT = split_op_wT(wp, dys.scheme)
+                    if wcache is not None:
+                        wcache[("wT", dys.scheme)] = wT
+                _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
                           ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
             else:
                 _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
@@ -396,11 +410,11 @@ class _Conv2d(Function):
             dw = dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum_any(dy, Co)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False):
-    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu)
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None):
+    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache)
 
 
 class _PadLast(Function):

@@ -346,13 +346,14 @@ class ScanpathModel(nn.Module):
         h = c = None
         outs = {"logits": [], "amap": [], "mu": [], "s2": []}
         zpad = torch.zeros(B, 3 * 512, KP - 9 * S, device=dev) if KP > 9 * S else None
+        wh_cache = {}          # split forms of the h-gate weight, shared by the T applications (and their backward)
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t in range(T):
             se = se_mem.view(S, B, Cc)
             parts = [F.gemm(se[s], Wr[s], None, "nk").view(B, 3 * 512, 9) for s in range(S)]
             wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
-            hg = F.conv2d(h, Wh, None, pad=1) if h is not None else None        # step 0: h == 0
+            hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache) if h is not None else None        # step 0: h == 0
             h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc)
             Z2 = F.sal_gather(F.conv2d(h, Wsal, None, pad=0), hmap, nh, nsrc)
             Dpre = F.drt_direct(h, W11, cbsum, hmap, nh)
