@@ -249,7 +249,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
     }
 
-    const float scale = p.alpha / (p.sx[0] * p.sw[0]);
+    // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
+    // ordinary weights) although every intermediate value here is representable
+    const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l32;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < p.M) {
                     float* dst = p.C + m * p.ldc + n;
-                    float v = scale * (tot[i][j][r] + acc[i][j][r]) + bv;
+                    float v = p.alpha * (((tot[i][j][r] + acc[i][j][r]) * isx) * isw) + bv;
                     if (p.beta) v += *dst;
                     if (p.relu) v = fmaxf(v, 0.f);
                     *dst = v;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
-    const float scale = p.alpha / (p.sx[0] * p.sy[0]);
+    const float isx = 1.f / p.sx[0], isy = 1.f / p.sy[0];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l32;
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                     float* dst = out + (int64_t)co * p.ldo + n;
                     const float v = tot[i][j][r] + acc[i][j][r];
                     if (direct) {
-                        float w = scale * v;
+                        float w = p.alpha * ((v * isx) * isy);
                         if (p.beta) w += *dst;
                         *dst = w;
                     } else {
@@ -502,13 +504,13 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 __global__ void hw_reduce_kernel(const float* slab, float* out, int Co, int Ntot, int ldo, int splits, int64_t slab_stride,
                                  float alpha, const float* sx, const float* sy, int beta) {
     const int64_t total = (int64_t)Co * Ntot;
-    const float scale = alpha / (sx[0] * sy[0]);
+    const float isx = 1.f / sx[0], isy = 1.f / sy[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int co = (int)(i / Ntot), n = (int)(i - (int64_t)co * Ntot);
         const int64_t off = (int64_t)co * ldo + n;
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * slab_stride + off];
-        s *= scale;
+        s = alpha * ((s * isx) * isy);
         if (beta) s += out[off];
         out[off] = s;
     }

@@ -462,3 +462,34 @@ def test_split_gemms_are_as_accurate_as_cpu_fp32():
                 assert got[k] <= 1.5 * cpu[k], (scheme, k, got[k], cpu[k])
     finally:
         F.USE_BF16X3, F.SPLIT_SCHEME, F._b3_pays, F._w3_pays = saved
+
+
+def test_f16x2_scales_survive_extreme_operand_magnitudes():
+    """per-tensor power-of-two scales of the 2xfp16 GEMMs: operands of magnitude 1e-30 (vanishing gradients) and 1e+20 must
+    give the same relative accuracy as ordinary ones -- the product of the two scales leaves the fp32 range, each one alone
+    does not"""
+    from scanpaths_amd import functional as F
+    saved = (F.USE_BF16X3, F.SPLIT_SCHEME, F._b3_pays, F._w3_pays)
+    dev = _dev()
+    try:
+        F.USE_BF16X3, F.SPLIT_SCHEME = True, "f16x2"
+        F._b3_pays = lambda M, N, K, Kc, nbatch=1, **kw: True
+        F._w3_pays = lambda M, Co, K, Ci, nbatch=1, **kw: True
+        x = _rand(2, 9, 11, 64, seed=1)
+        w = _rand(128, 64, 3, 3, seed=2, scale=1.0 / math.sqrt(576))
+        gy = _rand(2, 9, 11, 128, seed=3)
+        for sx, sw, sg in ((1.0, 1.0, 1.0), (1e-30, 1.0, 1e-5), (1e-3, 1e20, 1e-10), (1e15, 1e-20, 1e8)):     # all results representable in fp32
+            xr = (x.double() * sx).permute(0, 3, 1, 2).requires_grad_(True)
+            wr = (w.double() * sw).requires_grad_(True)
+            yr = TF.conv2d(xr, wr, padding=1)
+            yr.backward((gy.double() * sg).permute(0, 3, 1, 2))
+            xd = (x * sx).to(dev).requires_grad_(True)
+            wd = (w * sw).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = F.conv2d(xd, wd, None, pad=1)
+            y.backward((gy * sg).to(dev))
+            for got, ref, what in ((y.permute(0, 3, 1, 2), yr, "y"), (xd.grad.permute(0, 3, 1, 2), xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
+                ref = ref.detach()
+                rel = float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max())
+                assert rel <= 3e-6, (sx, sw, sg, what, rel)
+    finally:
+        F.USE_BF16X3, F.SPLIT_SCHEME, F._b3_pays, F._w3_pays = saved
