@@ -104,7 +104,9 @@ int sp_conv_wgrad_bf16x3(const sp_wgrad_desc* d, const void* Xsplit, const void*
  * GEMM (7.6e-8 vs 1.2e-7..3e-7 relative) at half the MFMA work of the bf16x3 scheme.  sp_split2_f16: fp32 [rows][K]
  * (K % 16 == 0) -> [rows][K/16][2][16] fp16 + 64-byte zero block (2n+32 halfs); scale_amax = 2 device words {scale (written),
  * scratch}.  igemm: Kc % 32 == 0 (a 32-k K-tile must lie inside one tap); wgrad: Ci % 16 == 0, Co % 16 == 0. */
-int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax, void* stream);
+int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax,
+                  int have_amax /* scale_amax[1] already holds max|x| as float bits (fused into the producer: *_amax outputs) */,
+                  void* stream);
 int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* out, float* scale_amax, void* stream);
 int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit, const float* w_scale,
                         const float* bias, float* out, void* stream);
@@ -135,12 +137,14 @@ int sp_bn_eval_stats(const float* running_mean, const float* running_var, int C,
                      float* invstd, void* stream);
 /* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) */
 int sp_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                const float* residual, int relu, int64_t M, int C, float* y, void* stream);
+                const float* residual, int relu, int64_t M, int C, float* y,
+                unsigned* y_amax /* nullable: atomicMax of the float bits of max|y| (zero it first) */, void* stream);
 /* backward.  dy_eff = dy * (y>0 if relu).  train: dx = gamma*invstd*(dy_eff - mean(dy_eff) - xhat*mean(dy_eff*xhat));
  * eval: dx = gamma*invstd*dy_eff.  dgamma/dbeta always.  dres (optional) receives dy_eff. */
 int sp_bn_backward(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                    const float* gamma, int relu, int training, int64_t M, int C, float* dx, float* dres,
-                   float* dgamma, float* dbeta, void* workspace, void* stream);
+                   float* dgamma, float* dbeta, void* workspace,
+                   unsigned* dx_amax /* nullable, as y_amax */, void* stream);
 
 /* MaxPool2d(3, stride 2, pad 0, ceil_mode=True), NHWC.  models/resnet.py:104. */
 int sp_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int Ho, int Wo, void* stream);
@@ -170,14 +174,16 @@ int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const float* c_prev,
  * g = i,f,o (spcol [B][P][KP] 9-tap im2col of the spatial memories, wc [B][3C][KP] per-sample contracted filters;
  * baseline_attention.py:40-50).  xg/hg/gates [B*P][4C]; C % 64 == 0, KP <= 64. */
 int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* c_prev, const float* spcol, const float* wc, int B, int P,
-                      int C, int KP, float* gates, float* c_out, float* h_out, void* stream);
+                      int C, int KP, float* gates, float* c_out, float* h_out,
+                      unsigned* h_amax /* nullable, as y_amax */, void* stream);
 /* gradient of the per-sample rank-1 filters: dwc [B][N3][KP] = sum_p dpre[b,p,n] * spcol[b,p,k]; dpre rows have ld floats
  * (= 4C, the first N3 = 3C are used); KP <= 24; workspace >= sp_rank1_dwc_workspace bytes (chunk partials, fixed-order reduce) */
 int64_t sp_rank1_dwc_workspace(int B, int P, int N3, int KP);
 int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P, int ld, int N3, int KP, void* workspace, float* dwc,
                  void* stream);
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
-                          const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, void* stream);
+                          const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
+                          unsigned* dpre_amax /* nullable, as y_amax */, void* stream);
 
 /* 3x3 zero-padded im2col of single-channel maps [R][H][W] into columns [koff,koff+9) of col[r][p][ldk], and adjoint.
  * Feeds the rank-1 gate convolutions conv3x3(W, spatial (x) semantic) (baseline_attention.py:40-50) and the

@@ -133,7 +133,9 @@ __global__ void bn_eval_stats(const float* rmean, const float* rvar, int C, floa
 // ---------------------------------------------------------------- BN apply (+res, +relu)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* mean, const float* invstd,
                                                        const float* gamma, const float* beta, const float* res,
-                                                       int relu, int64_t n4, int C, float* y) {
+                                                       int relu, int64_t n4, int C, float* y, unsigned* amax) {
+    __shared__ float sh4[4];
+    float mx = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         const float4 a = reinterpret_cast<const float4*>(x)[i];
@@ -154,7 +156,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
         reinterpret_cast<float4*>(y)[i] = o;
+        mx = amax4(mx, o.x, o.y, o.z, o.w);
     }
+    if (amax) block_amax_commit(mx, amax, sh4);
 }
 
 // ---------------------------------------------------------------- BN backward
@@ -192,7 +196,10 @@ __global__ __launch_bounds__(FIN_C * FIN_L) void bn_bwd_final(const double* part
 
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean,
                                                     const float* invstd, const float* gamma, const float* coef,
-                                                    int relu, int training, int64_t n4, int C, float* dx, float* dres) {
+                                                    int relu, int training, int64_t n4, int C, float* dx, float* dres,
+                                                    unsigned* amax) {
+    __shared__ float sh4[4];
+    float mx = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         float4 d = reinterpret_cast<const float4*>(dy)[i];
@@ -218,7 +225,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* dy, const float
             o.x = ga.x * is.x * d.x; o.y = ga.y * is.y * d.y; o.z = ga.z * is.z * d.z; o.w = ga.w * is.w * d.w;
         }
         reinterpret_cast<float4*>(dx)[i] = o;
+        mx = amax4(mx, o.x, o.y, o.z, o.w);
     }
+    if (amax) block_amax_commit(mx, amax, sh4);
 }
 
 // ---------------------------------------------------------------- column sums / row sums
@@ -407,19 +416,19 @@ extern "C" int sp_bn_eval_stats(const float* running_mean, const float* running_
 }
 
 extern "C" int sp_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                           const float* residual, int relu, int64_t M, int C, float* y, void* stream) {
+                           const float* residual, int relu, int64_t M, int C, float* y, unsigned* y_amax, void* stream) {
     if (!x || !mean || !invstd || !gamma || !beta || !y) return SP_ENULL;
     if (C % 4) return SP_EINVAL;
     const int64_t n4 = M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma,
-                       beta, residual, relu, n4, C, y);
+                       beta, residual, relu, n4, C, y, y_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
 
 extern "C" int sp_bn_backward(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                               const float* gamma, int relu, int training, int64_t M, int C, float* dx, float* dres,
-                              float* dgamma, float* dbeta, void* workspace, void* stream) {
+                              float* dgamma, float* dbeta, void* workspace, unsigned* dx_amax, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return SP_ENULL;
     if (relu && !y) return SP_ENULL;
     if (C % 4 || M <= 0) return SP_EINVAL;
@@ -435,7 +444,7 @@ extern "C" int sp_bn_backward(const float* dy, const float* x, const float* y, c
     SP_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, relu,
-                       training, n4, C, dx, dres);
+                       training, n4, C, dx, dres, dx_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

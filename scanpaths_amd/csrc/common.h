@@ -49,6 +49,19 @@ __device__ __forceinline__ float block_max_256(float v, float* sh4) {
     return fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
 }
 
+// Fused amax of a producer's output (operand scale of the 2xfp16 GEMMs, conv_f16x2.hip): block maximum, then at most one
+// atomicMax per block -- skipped when the block cannot raise the current value (monotone, so a stale read is safe).  256 threads.
+__device__ __forceinline__ void block_amax_commit(float m, unsigned* amax, float* sh4) {
+    m = block_max_256(m, sh4);
+    if (threadIdx.x == 0 && m > 0.f) {
+        const unsigned b = __float_as_uint(m);
+        if (b > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, b);
+    }
+}
+__device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (same id % 8 under the
 // observed round-robin dispatch) receive a contiguous range of logical tile ids, so neighbouring
 // tiles (which share operand panels) hit the same per-XCD L2.  Speed only, never correctness.

@@ -643,13 +643,15 @@ int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
 }  // namespace
 
 // out: 2*n fp16 + 64-byte zero block; scale_amax: two 4-byte device words {scale (float, written), amax bits (scratch)}
-extern "C" int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax, void* stream) {
+extern "C" int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax, int have_amax, void* stream) {
     if (!x || !out || !scale_amax) return SP_ENULL;
     if (n % 16) return SP_EINVAL;            // every row must be a multiple of 16 long
     hipStream_t s = (hipStream_t)stream;
     unsigned* amax = reinterpret_cast<unsigned*>(scale_amax + 1);
-    const int rc = launch_amax(x, n, amax, s);
-    if (rc != SP_OK) return rc;
+    if (!have_amax) {                        // else: the producer of x already left max|x| (float bits) in scale_amax[1]
+        const int rc = launch_amax(x, n, amax, s);
+        if (rc != SP_OK) return rc;
+    }
     const int64_t n4 = n / 4;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256), 4096));
     hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, s, x, n4, amax, (uint16_t*)out, scale_amax);

@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256) void lstm_rank1_fwd_kernel(const float* __rest
                                                              const float* __restrict__ c_prev, const float* __restrict__ spcol,
                                                              const float* __restrict__ wc, int P, int C, int KP,
                                                              float* __restrict__ gates, float* __restrict__ c_out,
-                                                             float* __restrict__ h_out) {
+                                                             float* __restrict__ h_out, unsigned* __restrict__ h_amax) {
     extern __shared__ __attribute__((aligned(16))) float r1s[];
+    __shared__ float sh4[4];
+    float hmx = 0.f;
     float* wcT = r1s;                       // [KP][3][64]
     float* sp = r1s + KP * 192;             // [64][KP]
     const int t = threadIdx.x, q = t & 15, rg = t >> 4;
@@ -142,8 +144,10 @@ __global__ __launch_bounds__(256) void lstm_rank1_fwd_kernel(const float* __rest
             *reinterpret_cast<f32x4*>(pgt + 3 * C) = gg;
             *reinterpret_cast<f32x4*>(c_out + r * C + c) = cn;
             *reinterpret_cast<f32x4*>(h_out + r * C + c) = hn;
+            hmx = amax4(hmx, hn[0], hn[1], hn[2], hn[3]);
         }
     }
+    if (h_amax) block_amax_commit(hmx, h_amax, sh4);
 }
 
 // Gradient of the per-sample contracted rank-1 filters:  dwc[b,n,k] = sum_p dpre[b,p,n] * spcol[b,p,k]  (n < 3C).
@@ -214,7 +218,9 @@ __global__ __launch_bounds__(256) void rank1_dwc_reduce_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const float* dc, const float* gates,
                                                        const float* c_prev, const float* c_out, int64_t rows, int C,
-                                                       float* dpre, float* dc_prev) {
+                                                       float* dpre, float* dc_prev, unsigned* dpre_amax) {
+    __shared__ float sh4[4];
+    float dmx = 0.f;
     const int C4 = C / 4;
     const int64_t total = rows * C4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -246,7 +252,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const fl
         *reinterpret_cast<float4*>(pd + 2 * C) = dov;
         *reinterpret_cast<float4*>(pd + 3 * C) = dg;
         *reinterpret_cast<float4*>(dc_prev + r * C + c) = dcp;
+        dmx = amax4(amax4(dmx, di.x, di.y, di.z, di.w), df.x, df.y, df.z, df.w);
+        dmx = amax4(amax4(dmx, dov.x, dov.y, dov.z, dov.w), dg.x, dg.y, dg.z, dg.w);
     }
+    if (dpre_amax) block_amax_commit(dmx, dpre_amax, sh4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,12 +568,13 @@ extern "C" int sp_lstm_pointwise_fwd(const float* xg, const float* hg, const flo
 }
 
 extern "C" int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* c_prev, const float* spcol, const float* wc,
-                                 int B, int P, int C, int KP, float* gates, float* c_out, float* h_out, void* stream) {
+                                 int B, int P, int C, int KP, float* gates, float* c_out, float* h_out, unsigned* h_amax,
+                                 void* stream) {
     if (!xg || !spcol || !wc || !gates || !c_out || !h_out) return SP_ENULL;
     if (C % 64 || B < 1 || P < 1 || KP < 1 || KP > 64) return SP_EINVAL;
     const size_t lds = (size_t)KP * (192 + 64) * sizeof(float);
     hipLaunchKernelGGL(lstm_rank1_fwd_kernel, dim3(C / 64, (P + R1_RB - 1) / R1_RB, B), dim3(256), lds, (hipStream_t)stream, xg, hg,
-                       c_prev, spcol, wc, P, C, KP, gates, c_out, h_out);
+                       c_prev, spcol, wc, P, C, KP, gates, c_out, h_out, h_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -589,11 +599,12 @@ extern "C" int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P,
 }
 
 extern "C" int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
-                                     const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, void* stream) {
+                                     const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, unsigned* dpre_amax,
+                                     void* stream) {
     if (!gates || !c_out || !dpre || !dc_prev) return SP_ENULL;
     if (C % 4) return SP_EINVAL;
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
-                       c_prev, c_out, rows, C, dpre, dc_prev);
+                       c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

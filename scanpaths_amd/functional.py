@@ -65,6 +65,7 @@ def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=
 # SPLIT_SCHEME "f16x2": 2 fp16 planes + per-tensor power-of-two scale, 3 MFMA products (default);
 #              "bf16x3": 3 bf16 planes, 6 products (no scale pass; also used when a channel count is not a multiple of 32).
 # Environment overrides: SP_NO_SPLIT=1, SP_SPLIT_SCHEME=bf16x3|f16x2.
+FUSED_AMAX = not os.environ.get("SP_NO_AMAX_HINT")    # producers leave max|output| behind for the operand split (see _amax_hint)
 USE_BF16X3 = not os.environ.get("SP_NO_SPLIT")
 SPLIT_SCHEME = os.environ.get("SP_SPLIT_SCHEME", "f16x2")
 if SPLIT_SCHEME not in ("f16x2", "bf16x3"):
@@ -100,16 +101,30 @@ def split3_wT(wp: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _amax_hint(device) -> Optional[torch.Tensor]:
+    """{scale, amax bits} buffer for a producer kernel that leaves max|output| behind (block max + one guarded atomic per block);
+    attached to the produced tensor as ``_sp_amax`` so that split_op can skip its read-only amax pass.  None when the 2xfp16
+    back-end is not in use."""
+    if not USE_BF16X3 or SPLIT_SCHEME != "f16x2" or not FUSED_AMAX:
+        return None
+    return torch.zeros(2, dtype=torch.float32, device=device)
+
+
+def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
+    return None if hint is None else hint.data_ptr() + 4
+
+
 def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree)"""
     scheme = scheme or _scheme_for(x.shape[-1])
     if scheme == "bf16x3":
         return SplitOperand(split3(x), None, scheme)
+    hint = getattr(x, "_sp_amax", None)          # left by the kernel that produced x (same tensor object, never modified since)
     x = x.contiguous()
     n = x.numel()
     out = torch.empty(2 * n + 32, dtype=torch.float16, device=x.device)
-    scale = torch.empty(2, dtype=torch.float32, device=x.device)
-    check(hip.lib().sp_split2_f16(ptr(x), n, ptr(out), ptr(scale), hip.stream()), "sp_split2_f16")
+    scale = hint if hint is not None else torch.empty(2, dtype=torch.float32, device=x.device)
+    check(hip.lib().sp_split2_f16(ptr(x), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
     return SplitOperand(out, scale, scheme)
 
 
@@ -564,8 +579,11 @@ class _BnAct(Function):
                   "sp_bn_eval_stats")
         y = torch.empty_like(x)
         res = residual.contiguous() if residual is not None else None
+        hint = _amax_hint(dev)
         check(L.sp_bn_apply(ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(res), int(relu), M, Cc, ptr(y),
-                            hip.stream()), "sp_bn_apply")
+                            _hint_ptr(hint), hip.stream()), "sp_bn_apply")
+        if hint is not None:
+            y._sp_amax = hint
         ctx.cfg = (training, relu, residual is not None)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma.detach())
         return y
@@ -583,8 +601,12 @@ class _BnAct(Function):
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
         ws = hip.workspace(L.sp_bn_workspace(M, Cc), x.device, slot=1)
+        hint = _amax_hint(x.device)
         check(L.sp_bn_backward(ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), int(relu), int(training), M, Cc,
-                               ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), hip.stream()), "sp_bn_backward")
+                               ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), _hint_ptr(hint), hip.stream()),
+              "sp_bn_backward")
+        if hint is not None:
+            dx._sp_amax = hint
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
@@ -736,7 +758,7 @@ class _LstmCell(Function):
         dpre = torch.empty_like(gates)
         dcp = torch.empty_like(c)
         check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
-                                              ptr(dcp), hip.stream()), "sp_lstm_pointwise_bwd")
+                                              ptr(dcp), None, hip.stream()), "sp_lstm_pointwise_bwd")
         has_hg, has_c = ctx.has
         return dpre, (dpre if has_hg else None), (dcp if has_c else None)
 
@@ -764,8 +786,11 @@ class _LstmCellRank1(Function):
         gates = torch.empty_like(xg)
         c = torch.empty(shp, dtype=torch.float32, device=xg.device)
         h = torch.empty(shp, dtype=torch.float32, device=xg.device)
+        hint = _amax_hint(xg.device)
         check(hip.lib().sp_lstm_rank1_fwd(ptr(xg), ptr(hg), ptr(c_prev), ptr(spcol), ptr(wc), B, P, Cc, KP, ptr(gates), ptr(c),
-                                          ptr(h), hip.stream()), "sp_lstm_rank1_fwd")
+                                          ptr(h), _hint_ptr(hint), hip.stream()), "sp_lstm_rank1_fwd")
+        if hint is not None:
+            h._sp_amax = hint
         ctx.has = (hg is not None, c_prev is not None)
         ctx.save_for_backward(gates, c_prev, c, spcol, wc)
         return h, c
@@ -782,8 +807,11 @@ class _LstmCellRank1(Function):
         rows = gates.numel() // C4
         dpre = torch.empty_like(gates)
         dcp = torch.empty_like(c)
+        hint = _amax_hint(gates.device)
         check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
-                                              ptr(dcp), hip.stream()), "sp_lstm_pointwise_bwd")
+                                              ptr(dcp), _hint_ptr(hint), hip.stream()), "sp_lstm_pointwise_bwd")
+        if hint is not None:
+            dpre._sp_amax = hint
         dsp = dwc = None
         if ctx.needs_input_grad[3]:
             dsp = torch.empty_like(spcol)

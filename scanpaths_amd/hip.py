@@ -42,7 +42,7 @@ SIGNATURES = {
     "sp_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_split3_bf16": (_I, [_P, _L, _P, _P]),
     "sp_split3_bf16_wT": (_I, [_P, _I, _I, _I, _P, _P]),
-    "sp_split2_f16": (_I, [_P, _L, _P, _P, _P]),
+    "sp_split2_f16": (_I, [_P, _L, _P, _P, _I, _P]),
     "sp_split2_f16_wT": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "sp_conv_igemm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x2_workspace": (_L, [_P]),
@@ -59,8 +59,8 @@ SIGNATURES = {
     "sp_bn_workspace": (_L, [_L, _I]),
     "sp_bn_stats": (_I, [_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "sp_bn_eval_stats": (_I, [_P, _P, _I, _F, _P, _P, _P]),
-    "sp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P]),
-    "sp_bn_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "sp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P]),
+    "sp_bn_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sp_sum_n": (_I, [_P, _I, _L, _P, _P]),
     "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
     "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -69,10 +69,10 @@ SIGNATURES = {
     "sp_pad_lastdim": (_I, [_P, _L, _I, _I, _P, _P]),
     "sp_add": (_I, [_P, _P, _P, _L, _P]),
     "sp_lstm_pointwise_fwd": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P]),
-    "sp_lstm_rank1_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "sp_lstm_rank1_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sp_rank1_dwc_workspace": (_L, [_I, _I, _I, _I]),
     "sp_rank1_dwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "sp_im2col3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_col2im3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_listatt_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),

@@ -493,3 +493,34 @@ def test_f16x2_scales_survive_extreme_operand_magnitudes():
                 assert rel <= 3e-6, (sx, sw, sg, what, rel)
     finally:
         F.USE_BF16X3, F.SPLIT_SCHEME, F._b3_pays, F._w3_pays = saved
+
+
+def test_fused_amax_hints_equal_the_separate_pass():
+    """producers (BN apply / backward, LSTM cell forward / backward) leave max|output| behind for the 2xfp16 operand split:
+    the hinted split must be bit-identical to the split that runs its own amax pass, and a tensor without a hint still works"""
+    from scanpaths_amd import functional as F
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3:
+        pytest.skip("2xfp16 back-end not active")
+    dev = _dev()
+    x = _rand(3, 7, 9, 64, seed=5, scale=3.0).to(dev).requires_grad_(True)
+    ga, be = (_rand(64, seed=6) * 0.5 + 1).to(dev).requires_grad_(True), _rand(64, seed=7).to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    y = F.bn_act(x, ga, be, rm, rv, None, True, 0.1, 1e-5, True)
+    assert getattr(y, "_sp_amax", None) is not None
+    hinted = F.split_op(y)
+    plain = F.split_op(y.detach().clone())                       # no hint: separate amax pass
+    assert torch.equal(hinted.buf, plain.buf) and float(hinted.scale[0]) == float(plain.scale[0])
+    amax = torch.tensor([hinted.scale[1].item()]).view(torch.int32).view(torch.float32)     # float bits stored by atomicMax
+    assert float(amax) == float(y.abs().max())
+    # backward hints: dx of BN, and the LSTM cell pair
+    gy = _rand(*y.shape, seed=8).to(dev)
+    (dx,) = torch.autograd.grad(y, x, gy)
+    if getattr(dx, "_sp_amax", None) is not None:                # identity of the grad tensor object is up to autograd
+        a = F.split_op(dx); b = F.split_op(dx.detach().clone())
+        assert torch.equal(a.buf, b.buf)
+    B, Hm, Wm, C = 2, 5, 7, 64
+    xg = _rand(B, Hm, Wm, 4 * C, seed=9).to(dev)
+    spcol, wc = _rand(B, Hm * Wm, 12, seed=10).to(dev), _rand(B, 3 * C, 12, seed=11, scale=0.1).to(dev)
+    h, c = F.lstm_cell_rank1(xg, None, None, spcol, wc)
+    a = F.split_op(h); b = F.split_op(h.detach().clone())
+    assert getattr(h, "_sp_amax", None) is not None and torch.equal(a.buf, b.buf)
