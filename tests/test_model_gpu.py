@@ -12,6 +12,7 @@ the bar is, per decode step,   err(hip32, ref64) <= max(1e-4 * scale, NOISE_X * 
 O(1) after ~10 eval-mode steps, so only the early steps carry a tight bar -- that is the reference's property).
 Argmax must match wherever the fp64 top-2 margin exceeds that error bar."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -338,3 +339,56 @@ def test_full_size_train_step_is_reproducible_and_finite():
     assert torch.equal(p1, p2)
     assert all(math.isfinite(v) for pair in o1 for v in pair) and torch.isfinite(p1).all()
     assert o1[0][1] > 0
+
+
+def test_checkpoint_resume_is_bit_identical_and_adam_format_compatible(tmp_path):
+    """SURVEY §8 f4 (checkpoint I/O): the reference's CheckpointManager stores {"model": state_dict, "optimizer": Adam state_dict}
+    (utils/checkpointing.py:93-110) and resumes with load_state_dict (AiR/train.py:145-151).  (i) save after one step, resume in
+    fresh objects, take the next step in both -> bit-identical parameters; (ii) the optimizer state has torch.optim.Adam's
+    layout, and a state written by torch.optim.Adam itself loads into FlatAdam."""
+    from scanpaths_amd.models.baseline_attention import baseline_osie
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    T = 2
+
+    def make():
+        m = baseline_osie(convLSTM_length=T, arch="resnet18")
+        fill_module(m, 9)
+        m = m.to(DEV).train()
+        return m, FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5)
+
+    def step(m, opt, seed):
+        b = {k: v.to(DEV) for k, v in make_batch("OSIE", 2, 240, 320, T, seed=seed).items()}
+        opt.zero_grad()
+        loss, _, _ = supervised_loss(m(b["images"]), b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+        loss.backward()
+        opt.step()
+
+    m1, o1 = make()
+    step(m1, o1, 1)
+    path = os.path.join(tmp_path, "checkpoint.pth")
+    torch.save({"model": m1.state_dict(), "optimizer": o1.state_dict()}, path)
+    step(m1, o1, 2)
+    ck = torch.load(path)
+    m2, o2 = make()
+    for key in ck:                                   # the reference's resume loop
+        (o2 if key == "optimizer" else m2).load_state_dict(ck[key])
+    step(m2, o2, 2)
+    assert torch.equal(o1.flat_p, o2.flat_p)
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    # Adam layout
+    sd = o1.state_dict()
+    assert set(sd) == {"state", "param_groups"} and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in m1.parameters()], lr=1e-3, weight_decay=5e-4)
+    for p in ref.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    m3, o3 = make()
+    o3.load_state_dict(ref.state_dict())
+    i = 0
+    for p in m3.parameters():
+        assert torch.allclose(o3.state[p]["exp_avg"], ref.state[ref.param_groups[0]["params"][i]]["exp_avg"])
+        i += 1
