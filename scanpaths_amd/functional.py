@@ -117,15 +117,22 @@ def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
 def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree)"""
     scheme = scheme or _scheme_for(x.shape[-1])
+    cached = getattr(x, "_sp_split", None)       # an earlier consumer of the same tensor object already split it
+    if cached is not None and cached.scheme == scheme:
+        return cached
     if scheme == "bf16x3":
-        return SplitOperand(split3(x), None, scheme)
-    hint = getattr(x, "_sp_amax", None)          # left by the kernel that produced x (same tensor object, never modified since)
-    x = x.contiguous()
-    n = x.numel()
-    out = torch.empty(2 * n + 32, dtype=torch.float16, device=x.device)
-    scale = hint if hint is not None else torch.empty(2, dtype=torch.float32, device=x.device)
-    check(hip.lib().sp_split2_f16(ptr(x), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
-    return SplitOperand(out, scale, scheme)
+        op = SplitOperand(split3(x), None, scheme)
+    else:
+        hint = getattr(x, "_sp_amax", None)      # left by the kernel that produced x (same tensor object, never modified since)
+        xc = x.contiguous()
+        n = xc.numel()
+        out = torch.empty(2 * n + 32, dtype=torch.float16, device=x.device)
+        scale = hint if hint is not None else torch.empty(2, dtype=torch.float32, device=x.device)
+        check(hip.lib().sp_split2_f16(ptr(xc), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
+        op = SplitOperand(out, scale, scheme)
+    if getattr(x, "_sp_share_split", False):     # set by producers whose output feeds several GEMMs (the ConvLSTM state h)
+        x._sp_split = op
+    return op
 
 
 def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
@@ -139,18 +146,18 @@ def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     return SplitOperand(out, scale, scheme)
 
 
-def _b3_pays(M, N, K, Kc, nbatch=1, a_elems=None):
+def _b3_pays(M, N, K, Kc, nbatch=1, a_elems=None, free_a=False):
     """cost model: split passes (10-12 B per operand element at ~4 TB/s) + split GEMM (~2.3x / ~4x the fp32 rate) < fp32 GEMM.
     a_elems: elements of the activation-side tensor (the loaders use 32-bit byte offsets into the split operand)"""
     if not USE_BF16X3 or nbatch != 1 or Kc % 16 or N < 64:
         return False
     f16 = _scheme_for(Kc) == "f16x2"
     flops = 2.0 * M * N * K
-    split_bytes = (12.0 if f16 else 10.0) * (M * Kc + N * K)
+    split_bytes = (12.0 if f16 else 10.0) * ((0 if free_a else M * Kc) + N * K)     # free_a: the activation split already exists
     bpe = 4.0 if f16 else 6.0
     if bpe * (a_elems if a_elems is not None else 4.0 * M * Kc) + 64 >= 2 ** 32 or bpe * N * K + 64 >= 2 ** 32:
         return False
-    return flops * (1 / 1.1e14 - 1 / (4.0e14 if f16 else 2.5e14)) > split_bytes / 4e12 and flops > 2e9
+    return flops * (1 / 1.1e14 - 1 / (4.0e14 if f16 else 2.5e14)) > split_bytes / 4e12 and flops > (1e9 if free_a else 2e9)
 
 
 def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
@@ -357,7 +364,8 @@ class _Conv2d(Function):
         Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
         xs = None
-        if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel()):
+        shared = getattr(x, "_sp_share_split", False)
+        if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel(), free_a=shared):
             xs = split_op(x)
             wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
             if wsplit is None:
@@ -791,6 +799,7 @@ class _LstmCellRank1(Function):
                                           ptr(h), _hint_ptr(hint), hip.stream()), "sp_lstm_rank1_fwd")
         if hint is not None:
             h._sp_amax = hint
+        h._sp_share_split = True          # h feeds the saliency tap GEMM of this step and the h-gate conv of the next: split once
         ctx.has = (hg is not None, c_prev is not None)
         ctx.save_for_backward(gates, c_prev, c, spcol, wc)
         return h, c
