@@ -181,6 +181,14 @@ int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* c_prev, con
 int64_t sp_rank1_dwc_workspace(int B, int P, int N3, int KP);
 int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P, int ld, int N3, int KP, void* workspace, float* dwc,
                  void* stream);
+/* get_channel_semantic + ReLU (baseline_attention.py:246-250,284,324): out [B][S][C] = relu(alpha * sum_p a[s][b][p] * vf[b][p][c])
+ * with alpha = 1/P (S <= 2 attention streams, C <= 512); backward returns d a [S][B][P] and d vf [B][P][C] in one pass over vf
+ * (dout is masked by out > 0 inside).  workspace >= sp_sempool_workspace bytes (chunk partials, fixed-order reduce). */
+int64_t sp_sempool_workspace(int S, int B, int P, int C);
+int sp_sempool_fwd(const float* a, const float* vf, int S, int B, int P, int C, float alpha, void* workspace, float* out,
+                   void* stream);
+int sp_sempool_bwd(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C, float alpha,
+                   float* da, float* dvf, void* stream);
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
                           unsigned* dpre_amax /* nullable, as y_amax */, void* stream);

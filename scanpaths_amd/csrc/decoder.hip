@@ -56,6 +56,87 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xg, const fl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// get_channel_semantic + ReLU (baseline_attention.py:246-250,284,324): pooled[s][b][c] = relu(mean_p(a[s][b][p] * vf[b][p][c])).
+// HBM-bound on vf (one read); as a batched GEMM with M = S = 2 rows it ran a 128-row MFMA tile for 2 rows (0.14 ms fwd,
+// 0.22 + 0.06 ms bwd per decode step).  fwd: block = (pixel chunk, sample), a thread owns 4 channels of every second pixel
+// (256 threads = 128 channel quads x 2 pixel lanes; C <= 512), chunk partials reduced in fixed order by the finish kernel.
+// bwd: one wave per pixel: d_a[s][b][p] = <dz[b][s][:], vf[b][p][:]> / P (wave reduction) and the rank-S update
+// d_vf[b][p][:] = sum_s a[s][b][p] * dz[b][s][:] / P of the same row in one pass over vf.  S <= 2.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_PCH = 160;      // pixels per forward block
+__global__ __launch_bounds__(256) void sempool_fwd_kernel(const float* __restrict__ a, const float* __restrict__ vf, int S, int B,
+                                                          int P, int C, float* __restrict__ partial) {
+    __shared__ f32x4 red[2][128];
+    const int ch = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+    const int c4 = threadIdx.x & 127, pl = threadIdx.x >> 7, C4 = C / 4;
+    const int p0 = ch * SP_PCH, p1 = min(P, p0 + SP_PCH);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4)
+        for (int p = p0 + pl; p < p1; p += 2) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vf + ((int64_t)b * P + p) * C + c4 * 4);
+            acc0 += a[((int64_t)0 * B + b) * P + p] * v;
+            if (S > 1) acc1 += a[((int64_t)1 * B + b) * P + p] * v;
+        }
+    if (pl == 1) { red[0][c4] = acc0; red[1][c4] = acc1; }
+    __syncthreads();
+    if (pl == 0 && c4 < C4) {
+        acc0 += red[0][c4];
+        acc1 += red[1][c4];
+        f32x4* dst = reinterpret_cast<f32x4*>(partial + (((int64_t)ch * B + b) * S) * C) + c4;
+        dst[0] = acc0;
+        if (S > 1) dst[C4] = acc1;
+    }
+    (void)nch;
+}
+// out [B][S][C] = relu(alpha * sum_chunks partial)
+__global__ __launch_bounds__(256) void sempool_finish_kernel(const float* __restrict__ partial, int nch, int64_t n, float alpha,
+                                                             float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nch; ++k) s += partial[(int64_t)k * n + i];
+        out[i] = fmaxf(alpha * s, 0.f);
+    }
+}
+// dz [B][S][C] (already masked by the ReLU), a [S][B][P], vf [B][P][C] -> da [S][B][P], dvf [B][P][C]
+__global__ __launch_bounds__(256) void sempool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ out,
+                                                          const float* __restrict__ a, const float* __restrict__ vf, int S,
+                                                          int B, int P, int C, float alpha, float* __restrict__ da,
+                                                          float* __restrict__ dvf) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    const int nq = C / 4;                         // channel quads; lane handles quads lane, lane+64
+    for (int64_t bp = wave; bp < (int64_t)B * P; bp += nwaves) {
+        const int b = (int)(bp / P), p = (int)(bp % P);
+        const float a0 = a[((int64_t)0 * B + b) * P + p], a1 = S > 1 ? a[((int64_t)1 * B + b) * P + p] : 0.f;
+        float d0 = 0.f, d1 = 0.f;
+        for (int q = lane; q < nq; q += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vf + bp * C + q * 4);
+            f32x4 g0 = *reinterpret_cast<const f32x4*>(dz + ((int64_t)b * S + 0) * C + q * 4);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(out + ((int64_t)b * S + 0) * C + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g0[e] = o0[e] > 0.f ? g0[e] : 0.f;
+            d0 += g0[0] * v[0] + g0[1] * v[1] + g0[2] * v[2] + g0[3] * v[3];
+            f32x4 w = a0 * g0;
+            if (S > 1) {
+                f32x4 g1 = *reinterpret_cast<const f32x4*>(dz + ((int64_t)b * S + 1) * C + q * 4);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(out + ((int64_t)b * S + 1) * C + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g1[e] = o1[e] > 0.f ? g1[e] : 0.f;
+                d1 += g1[0] * v[0] + g1[1] * v[1] + g1[2] * v[2] + g1[3] * v[3];
+                w += a1 * g1;
+            }
+            *reinterpret_cast<f32x4*>(dvf + bp * C + q * 4) = alpha * w;
+        }
+        d0 = wave_sum(d0);
+        d1 = wave_sum(d1);
+        if (lane == 0) {
+            da[((int64_t)0 * B + b) * P + p] = alpha * d0;
+            if (S > 1) da[((int64_t)1 * B + b) * P + p] = alpha * d1;
+        }
+    }
+}
+
 // ConvLSTM cell with the rank-1 gate terms fused in (baseline_attention.py:40-50): the i/f/o pre-activations receive
 //   sum_k spcol[b,p,k] * wc[b, g*C + c, k]      (conv3x3(W, spatial (x) semantic) as a 9-tap 1-channel conv per stream with the
 // per-sample contracted filter).  As a separate batched GEMM with beta = 1 this term cost a full read-modify-write of the gate
@@ -594,6 +675,34 @@ extern "C" int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P,
     const int64_t n = (int64_t)B * N3 * KP;
     hipLaunchKernelGGL(rank1_dwc_reduce_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, n,
                        nchunk, dwc);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int64_t sp_sempool_workspace(int S, int B, int P, int C) {
+    return (int64_t)((P + SP_PCH - 1) / SP_PCH) * B * S * C * (int64_t)sizeof(float);
+}
+
+extern "C" int sp_sempool_fwd(const float* a, const float* vf, int S, int B, int P, int C, float alpha, void* workspace,
+                              float* out, void* stream) {
+    if (!a || !vf || !workspace || !out) return SP_ENULL;
+    if (S < 1 || S > 2 || B < 1 || P < 1 || C % 4 || C > 512) return SP_EINVAL;
+    const int nch = (P + SP_PCH - 1) / SP_PCH;
+    hipLaunchKernelGGL(sempool_fwd_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, a, vf, S, B, P, C, (float*)workspace);
+    SP_LAUNCH_CHECK();
+    const int64_t n = (int64_t)B * S * C;
+    hipLaunchKernelGGL(sempool_finish_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nch,
+                       n, alpha, out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_sempool_bwd(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C,
+                              float alpha, float* da, float* dvf, void* stream) {
+    if (!dout || !out || !a || !vf || !da || !dvf) return SP_ENULL;
+    if (S < 1 || S > 2 || B < 1 || P < 1 || C % 4) return SP_EINVAL;
+    hipLaunchKernelGGL(sempool_bwd_kernel, dim3(ew_blocks((int64_t)B * P * 64)), dim3(256), 0, (hipStream_t)stream, dout, out, a,
+                       vf, S, B, P, C, alpha, da, dvf);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -930,6 +930,35 @@ def mul_relu(a, b):
     return _MulRelu.apply(a, b)
 
 
+class _SemPool(Function):
+    """amaps [S,B,P], vf [B,P,C] -> relu(mean_p(amaps * vf)) [B,S,C]   (get_channel_semantic + ReLU)"""
+    @staticmethod
+    def forward(ctx, amaps, vf):
+        amaps, vf = amaps.contiguous(), vf.contiguous()
+        S, B, P = amaps.shape
+        Cc = vf.shape[-1]
+        L = hip.lib()
+        out = torch.empty((B, S, Cc), dtype=torch.float32, device=vf.device)
+        ws = hip.workspace(L.sp_sempool_workspace(S, B, P, Cc), vf.device, slot=0)
+        check(L.sp_sempool_fwd(ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(ws), ptr(out), hip.stream()), "sp_sempool_fwd")
+        ctx.save_for_backward(amaps, vf, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        amaps, vf, out = ctx.saved_tensors
+        S, B, P = amaps.shape
+        Cc = vf.shape[-1]
+        da, dvf = torch.empty_like(amaps), torch.empty_like(vf)
+        check(hip.lib().sp_sempool_bwd(ptr(dout.contiguous()), ptr(out), ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(da), ptr(dvf),
+                                       hip.stream()), "sp_sempool_bwd")
+        return da, dvf
+
+
+def semantic_pool(amaps, vf):
+    return _SemPool.apply(amaps, vf)
+
+
 class _RowMean(Function):
     @staticmethod
     def forward(ctx, x):

@@ -72,6 +72,9 @@ SIGNATURES = {
     "sp_lstm_rank1_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sp_rank1_dwc_workspace": (_L, [_I, _I, _I, _I]),
     "sp_rank1_dwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_sempool_workspace": (_L, [_I, _I, _I, _I]),
+    "sp_sempool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "sp_sempool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "sp_im2col3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_col2im3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

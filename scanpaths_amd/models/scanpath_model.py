@@ -334,7 +334,8 @@ class ScanpathModel(nn.Module):
         def push(amaps):          # amaps [S,B,P]; memory update :277-296 / :317-336
             spf = F.mul_relu(amaps, mvf)
             sp_list.append(F.linear(spf.view(S * B, P), self.spatial_embed.weight, self.spatial_embed.bias))
-            pooled = F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)   # [B,S,C]
+            pooled = F.semantic_pool(amaps, vf3) if (S <= 2 and Cc <= 512) else \
+                F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
             se_list.append(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), self.semantic_embed.weight,
                                     self.semantic_embed.bias))
             sp_mem = F.list_attention(torch.stack(sp_list, 0), u_spa)        # [S*B,P]

@@ -524,3 +524,21 @@ def test_fused_amax_hints_equal_the_separate_pass():
     h, c = F.lstm_cell_rank1(xg, None, None, spcol, wc)
     a = F.split_op(h); b = F.split_op(h.detach().clone())
     assert getattr(h, "_sp_amax", None) is not None and torch.equal(a.buf, b.buf)
+
+
+@pytest.mark.parametrize("S,B,P,C", [(2, 3, 1200, 512), (1, 2, 333, 64), (2, 2, 2560, 512)])
+def test_semantic_pool(S, B, P, C):
+    """relu(mean_p(a * vf)) and both gradients against fp64"""
+    from scanpaths_amd import functional as F
+    a, vf = _rand(S, B, P, seed=1).abs(), _rand(B, P, C, seed=2)
+    g = _rand(B, S, C, seed=3)
+    ar, vr = a.double().requires_grad_(True), vf.double().requires_grad_(True)
+    ref = torch.relu(torch.einsum("sbp,bpc->bsc", ar, vr) / P)
+    (ref * g.double()).sum().backward()
+    dev = _dev()
+    ad, vd = a.to(dev).requires_grad_(True), vf.to(dev).requires_grad_(True)
+    out = F.semantic_pool(ad, vd)
+    (out * g.to(dev)).sum().backward()
+    _close(out, ref, 3e-6, "pooled")
+    _close(ad.grad, ar.grad, 3e-6, "d amaps")
+    _close(vd.grad, vr.grad, 3e-6, "d vf")
