@@ -41,8 +41,9 @@ def main():
             e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.reps
         tf = 2 * gmac * mult / ms / 1e9
-        out[name] = {"ms": ms, "tflops": tf, "frac_of_split_ceiling_416.7": tf / 416.7, "frac_of_fp32_mfma_157.3": tf / 157.3,
-                     "frac_of_bf16_dense_2500": tf / 2500.0}
+        out[name] = {"ms": ms, "tflops": tf, "frac_of_2xfp16_split_ceiling_833.3": tf / 833.3,
+                     "frac_of_3xbf16_split_ceiling_416.7": tf / 416.7, "frac_of_fp32_mfma_157.3": tf / 157.3,
+                     "frac_of_16bit_dense_2500": tf / 2500.0}
     print(json.dumps({"workload": f"dilated ResNet-50 encoder, bs {a.batch}, 320x512, train-mode BN, fp32-faithful", **out}))
 
 
