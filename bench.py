@@ -173,7 +173,7 @@ def main():
     traffic = None      # fabric-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hconv.json")))["kernels"]
-        key = {"h2_fwd": "h2_kernel<0>", "b3_fwd": "b3_kernel<0, 0>", "igemm_fwd": "igemm_kernel<128, 128, 2, 2, 0, false>"}[dom_kind]
+        key = {"h2_fwd": "h2_kernel<0, 0>", "b3_fwd": "b3_kernel<0, 0>", "igemm_fwd": "igemm_kernel<128, 128, 2, 2, 0, false>"}[dom_kind]
         if args.batch == 32 and (args.height, args.width) == (320, 512):
             traffic = round(pmc[key]["hbm_side_bytes_per_launch"])
     except Exception:

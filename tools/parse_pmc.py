@@ -13,6 +13,7 @@ for i in range(1, npass + 1):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         if not name.startswith(KEEP) or int(r["Grid_Size"]) < 100000:
             continue
+        name = {"h2_kernel<0>": "h2_kernel<0, 0>", "h2_kernel<1>": "h2_kernel<1, 0>"}.get(name, name)   # passes taken before the DBG template argument
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 kern = {}
 for name, cs in acc.items():
@@ -20,6 +21,8 @@ for name, cs in acc.items():
     d = {c: sum(v) / len(v) for c, v in cs.items()}
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_side_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:      # rocprofv3's MfmaUtil
+        d["mfma_busy_pct"] = 100.0 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     d["launches_averaged"] = {c: len(v) for c, v in cs.items()}
@@ -30,8 +33,9 @@ try:
 except Exception:
     pass
 prev.update(kern)
-json.dump({"command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 tools/bench_hconv.py  (4 separate passes: FETCH_SIZE | "
-                      "WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES); merged by tools/parse_pmc.py",
+json.dump({"command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 tools/bench_hconv.py  (separate passes: FETCH_SIZE | "
+                      "WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES | "
+                      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE); merged by tools/parse_pmc.py",
            "workload": "h-gate conv3x3 512->2048 at B=32, 40x64 (M=81920, N=2048, K=4608): fwd, dgrad, wgrad; averages per launch",
            "corrections": "FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B for 16 B/lane streams); "
                           "Infinity-Cache hits are included in FETCH_SIZE (guide section HBM) -- fabric-side, not pure HBM, traffic",
