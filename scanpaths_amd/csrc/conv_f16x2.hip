@@ -54,7 +54,8 @@ struct H2Args {
 // staging in a 3-stage ring with counted vmcnt (the structure of b3_kernel, see there for why).  Rows are 128 B = half a
 // 256-byte LDS bank row, so the source-side swizzle is an XOR: chunk c of row r is stored at position c ^ ((r>>1)&7); the 16
 // rows of every ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then hit 16 distinct 16-byte slots.
-// DBG (env SP_H2_DBG, timing experiments only): 1 = no global loads (MFMA + LDS side alone), 2 = no MFMAs (load side alone)
+// DBG (env SP_H2_DBG, timing experiments only): 1 = no global loads (MFMA + LDS side alone), 2 = no MFMAs (load side alone),
+// 3 = MFMAs only (no loads, no fragment reads, no barriers: what the matrix pipe sustains at the clock the chip holds)
 template <int MODE, int DBG>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
-    constexpr bool do_load = DBG != 1, do_mma = DBG != 2;
+    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2, do_lds = DBG != 3;
     int issued = 0;
     if (do_load)
         for (; issued < HNSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
@@ -198,6 +199,20 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         // all 16 fragment reads of the K-tile are issued up front (64 VGPRs): the reads of the second 16-k group then complete
         // behind the MFMAs of the first (with the reads interleaved per group the MFMA+LDS side alone took 3.4 ms)
         f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]
+        if constexpr (!do_lds) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        f16x8 z;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) z[e] = (_Float16)(float)(kt + e + lane);
+                        af[kk][i][pl] = z;
+                        bf[kk][i][pl] = z;
+                    }
+        } else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         if (kt + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (do_lds) __builtin_amdgcn_s_barrier();
         stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
     }
 
@@ -699,6 +714,7 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
     static const int dbg = getenv("SP_H2_DBG") ? atoi(getenv("SP_H2_DBG")) : 0;
     if (dbg == 1) return d->mode == 0 ? launch_h2<0, 1>(a, (hipStream_t)stream) : launch_h2<1, 1>(a, (hipStream_t)stream);
     if (dbg == 2) return d->mode == 0 ? launch_h2<0, 2>(a, (hipStream_t)stream) : launch_h2<1, 2>(a, (hipStream_t)stream);
+    if (dbg == 3) return d->mode == 0 ? launch_h2<0, 3>(a, (hipStream_t)stream) : launch_h2<1, 3>(a, (hipStream_t)stream);
     return d->mode == 0 ? launch_h2<0, 0>(a, (hipStream_t)stream) : launch_h2<1, 0>(a, (hipStream_t)stream);
 }
 
