@@ -101,13 +101,23 @@ def split3_wT(wp: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_HINT_POOL = {}
+
+
 def _amax_hint(device) -> Optional[torch.Tensor]:
     """{scale, amax bits} buffer for a producer kernel that leaves max|output| behind (block max + one guarded atomic per block);
     attached to the produced tensor as ``_sp_amax`` so that split_op can skip its read-only amax pass.  None when the 2xfp16
     back-end is not in use."""
     if not USE_BF16X3 or SPLIT_SCHEME != "f16x2" or not FUSED_AMAX:
         return None
-    return torch.zeros(2, dtype=torch.float32, device=device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _HINT_POOL.get(key)
+    if pool is None or pool[1] >= pool[0].shape[0]:          # one zero-fill per 2048 hints instead of one per hint
+        pool = [torch.zeros((2048, 2), dtype=torch.float32, device=device), 0]
+        _HINT_POOL[key] = pool
+    hint = pool[0][pool[1]]
+    pool[1] += 1
+    return hint
 
 
 def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
