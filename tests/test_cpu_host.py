@@ -33,6 +33,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.sp_abi_version() == 1          # pure host call, no GPU needed
 
 
+def test_ctypes_signatures_match_the_header():
+    """ABI drift guard: for every entry point the ctypes binding (hip.SIGNATURES) has as many arguments as the header declares,
+    8-byte integers / doubles / floats where the header says so, and the return type (int / int64_t)."""
+    from scanpaths_amd import hip
+    txt = open(os.path.join(ROOT, "include", "scanpaths_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    decls = dict()
+    for m in re.finditer(r"\b(int64_t|int)\s+(sp_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        decls[name] = (ret, [] if args in ("", "void") else [a.strip() for a in args.split(",")])
+    assert set(decls) == set(hip.SIGNATURES), set(decls) ^ set(hip.SIGNATURES)
+    for name, (ret, args) in decls.items():
+        cret, cargs = hip.SIGNATURES[name]
+        assert len(cargs) == len(args), (name, len(cargs), args)
+        assert (cret is ctypes.c_int64) == (ret == "int64_t"), (name, ret, cret)
+        for a, c in zip(args, cargs):
+            if "*" in a:
+                assert c is ctypes.c_void_p or issubclass(c, ctypes._Pointer), (name, a, c)      # void* or POINTER(desc struct)
+            elif a.startswith("int64_t"):
+                assert c is ctypes.c_int64, (name, a, c)
+            elif a.startswith("uint64_t"):
+                assert c is ctypes.c_uint64, (name, a, c)
+            elif a.startswith("double"):
+                assert c is ctypes.c_double, (name, a, c)
+            elif a.startswith("float"):
+                assert c is ctypes.c_float, (name, a, c)
+            else:
+                assert a.startswith("int") and c is ctypes.c_int, (name, a, c)
+
+
 @pytest.mark.parametrize("case,task", [("air_train_T4", "AiR"), ("osie_r18_train_T8", "OSIE"), ("coco_train_T6", "COCO_Search18")])
 def test_state_dict_keys_and_parameter_order_match_reference(case, task):
     """parameter registration order == the reference's model.named_parameters() (stored with the goldens): optimizer
