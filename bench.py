@@ -101,6 +101,12 @@ def main():
     torch.cuda.set_device(dev)
 
     from scanpaths_amd import hip
+    if not os.path.exists(hip.LIB_PATH):        # the in-tree .so normally travels with the snapshot; build it if it did not
+        import subprocess                       # (rank 0 builds, the others wait at the barrier of init_process_group's store)
+        if rank == 0:
+            subprocess.run(["make", "-C", os.path.join(ROOT, "scanpaths_amd", "csrc"), "-j8"], check=True, stdout=subprocess.DEVNULL)
+        if world > 1:
+            torch.distributed.barrier()
     from scanpaths_amd.models.baseline_attention import baseline
     from scanpaths_amd.models.loss import supervised_loss
     from scanpaths_amd.optim import FlatAdam
