@@ -542,3 +542,28 @@ def test_semantic_pool(S, B, P, C):
     _close(out, ref, 3e-6, "pooled")
     _close(ad.grad, ar.grad, 3e-6, "d amaps")
     _close(vd.grad, vr.grad, 3e-6, "d vf")
+
+
+def test_c_abi_error_codes():
+    """error behaviour of the C ABI: 0 = ok, SP_EINVAL (-1) for unsupported shapes, SP_ENULL (-2) for missing buffers -- never a
+    crash, never a silent fallback; the Python layer turns them into exceptions (hip.check)"""
+    import ctypes as C
+    from scanpaths_amd import hip
+    L = hip.lib()
+    dev = _dev()
+    x = torch.zeros(64, device=dev)
+    st = hip.stream()
+    assert L.sp_split2_f16(None, 64, hip.ptr(x), hip.ptr(x), 0, st) == -2
+    assert L.sp_split2_f16(hip.ptr(x), 60, hip.ptr(x), hip.ptr(x), 0, st) == -1          # row length not a multiple of 16
+    d = hip.ConvDesc(1, 4, 4, 48, 48, 4, 4, 64, 64, 1, 1, 1, 0, 1, 0, 48, 1.0, 0, 0, 1, 0, 0, 0, 0, None)
+    assert L.sp_conv_igemm_f16x2(C.byref(d), hip.ptr(x), hip.ptr(x), hip.ptr(x), hip.ptr(x), None, hip.ptr(x), st) == -1   # Kc % 32
+    assert L.sp_conv_igemm_f16x2(C.byref(d), None, hip.ptr(x), hip.ptr(x), hip.ptr(x), None, hip.ptr(x), st) == -2
+    assert L.sp_lstm_rank1_fwd(hip.ptr(x), None, None, hip.ptr(x), hip.ptr(x), 1, 4, 48, 12, hip.ptr(x), hip.ptr(x), hip.ptr(x), None,
+                               st) == -1                                                  # C % 64
+    assert L.sp_sempool_fwd(hip.ptr(x), hip.ptr(x), 3, 1, 4, 64, 1.0, hip.ptr(x), hip.ptr(x), st) == -1      # S > 2
+    assert L.sp_scanmatch_submatrix(0, 3, 3.5, hip.ptr(x), hip.ptr(x), st) == -1
+    assert L.sp_head_num_classes(3, 3) >= 1 and L.sp_head_num_classes(100000, 8) == -1
+    with pytest.raises(hip.HipError):
+        hip.check(-1, "demo")
+    with pytest.raises(hip.HipError):
+        hip.ptr(torch.zeros(4))                                                            # CPU tensor: no CPU path
