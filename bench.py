@@ -4,15 +4,23 @@
   python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1]: AiR, ResNet-50 encoder, 16-step decode, bs=32 per GPU, synthetic 320x512 images
+Default workload = BASELINE.json configs[1]: AiR, ResNet-50 encoder, 16-step decode, bs=32 per GPU, synthetic 320x512 images
 (attention map 40x64 instead of the reference's hard-coded 30x40; "14-token questions" reach the model only as the
 attention map).  A "step" is one pass of the hot path over one synthetic batch already resident in HBM.
-Weak scaling: every rank processes its own bs=32 shard; the only exchange is the gradient all-reduce of ONE flat
-buffer inside FlatAdam.step().  Rank 0 prints ONE JSON line.
+Weak scaling: every rank processes its own bs=32 shard; the only data-path exchange is the bucketed gradient all-reduce of
+the flat buffer inside FlatAdam (overlapped with backward) plus two mask-sum scalars.  Rank 0 prints ONE JSON line.
+
+Other BASELINE.json configurations through flags (not the headline line; same JSON schema, own metric string):
+  --task osie --arch resnet18 --T 8 --batch 4 --height 240 --width 320     config 1 (the reference's CPU-runnable case)
+  --task coco --batch 16 --T 6                                             config 4's per-GPU shard (bs 64 over 4 GPUs)
+  --mode infer --batch 128                                                  config 5: eval forward + 10 sampled scanpaths/head
+  --precision f16x1                                                         throughput mode (single fp16 plane, 1 MFMA product):
+                                                                            separately labelled, NOT the fp32-faithful headline
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,12 +29,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, dense bf16 MFMA
-# 3xbf16-split kernels spend 6 bf16 MFMA products per algorithmic (fp32-faithful) multiply-add -> their ceiling in
-# algorithmic FLOP/s is the bf16 peak / 6
-PEAK_SPLIT3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-PEAK_SPLIT2_TFLOPS = 2500.0 / 3.0       # 2xfp16 split: 3 MFMA products per algorithmic FMA
+# /opt/skills/guides/MI355X_MICROARCH.md §Matrix cores: dense peaks
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
+PRODUCTS = {"h2": 3, "b3": 6, "h1": 1, "igemm": None, "wgrad": None}      # MFMA products per algorithmic multiply-add
+KERNEL_NAMES = {
+    "h2_fwd": "h2_kernel<fwd> (2xfp16 split, 3 MFMA products)", "h2_dgrad": "h2_kernel<dgrad> (2xfp16 split, 3 MFMA products)",
+    "h2_wgrad": "hw_kernel (2xfp16 split weight gradient, 3 MFMA products)",
+    "h1_fwd": "h2_kernel<fwd, 1 plane> (fp16 in / fp32 acc, 1 product)", "h1_dgrad": "h2_kernel<dgrad, 1 plane>",
+    "h1_wgrad": "hw_kernel<1 plane>",
+    "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)", "b3_dgrad": "b3_kernel<dgrad>", "b3_wgrad": "w3_kernel",
+    "igemm_fwd": "igemm_kernel<fwd> (fp32 MFMA)", "igemm_dgrad": "igemm_kernel<dgrad> (fp32 MFMA)", "wgrad": "wgrad_kernel (fp32 MFMA)"}
+PMC_KEYS = {"h2_fwd": "h2_kernel<0, 0>", "h2_dgrad": "h2_kernel<1, 0>", "h2_wgrad": "hw_kernel"}
 
 
 def parse():
@@ -34,6 +48,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--task", type=str, default="air", choices=["air", "osie", "coco"])
+    ap.add_argument("--mode", type=str, default="train", choices=["train", "infer"])
+    ap.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x1"],
+                    help="f32: fp32-faithful split GEMMs (headline); f16x1: single fp16 plane, fp32 accumulate (throughput mode)")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=512)
@@ -42,47 +60,113 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="threads for the CPU baseline (oneDNN convs stop scaling / thrash beyond ~32 on the 256-thread host)")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="images per CPU-baseline step (BASELINE.md §4 names 4; 2 keeps "
+                                                             "the default run short -- every step is MEASURED at the full T)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
 
 
+def reduced_fwd_gmac(arch, H, W, T, task="air"):
+    """SURVEY.md §8(d) / BASELINE.md §3, 'reduced' column (necessary work after the exact hoistings), scaled to the config:
+    every term is proportional to the map area; decoder terms other than the hoisted x-gate conv are proportional to T."""
+    s = H * W / (320.0 * 512.0)
+    enc = {"resnet50": 71.35, "resnet18": 34.11}[arch] * s
+    sal = 24.16 * s * (1.0 if arch == "resnet50" else 0.25)
+    per_step_other = (1.36 + 4.18 + 0.4) / 16.0 * s * (1.0 if task == "air" else 0.5)
+    return enc + sal + 24.16 * s + (T - 1) * 24.16 * s + T * per_step_other
+
+
+def host_info():
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in out.splitlines() if ":" in l}
+        info["model"] = kv.get("Model name", "?")
+        sockets, cps = int(kv.get("Socket(s)", "1")), int(kv.get("Core(s) per socket", "0") or 0)
+        info["sockets"], info["physical_cores"] = sockets, sockets * cps if cps else None
+    except Exception as e:      # lscpu missing: keep going with what os reports
+        info["model"] = f"unknown ({type(e).__name__})"
+    return info
+
+
 def cpu_baseline(args):
-    """Oracle (literal CPU restatement of the reference, kind "port") timed on the host cores on a bounded sample:
-    two images, full train steps (fwd + loss + bwd + clip + Adam) with T=2 and T=8 decode steps after one untimed warm-up
-    (thread-pool / oneDNN primitive creation); the cost is affine in T (encoder + T identical decoder steps), so it is
-    extrapolated to T=16."""
+    """The oracle (literal CPU restatement of the reference, kind "port", pinned to the real reference by tests/golden) timed on
+    the host cores, BASELINE.md §4 protocol on a bounded sample: the SAME workload (task, image size, full T) at a small batch,
+    one untimed warm-up step (thread pool / oneDNN primitive creation) then --cpu-steps MEASURED steps, median, with the
+    forward / backward / clip+Adam split.  Nothing is extrapolated."""
     from oracle import scanpath_oracle as O
     from scanpaths_amd.procedural import procedural_state_dict
-    from scanpaths_amd.spec import model_spec, is_buffer
+    from scanpaths_amd.spec import is_buffer, model_spec
     from scanpaths_amd.synth import make_batch
+    hi = host_info()
     cores = min(args.cpu_threads or os.cpu_count(), os.cpu_count())
     torch.set_num_threads(cores)
+    task = {"air": "AiR", "osie": "OSIE", "coco": "COCO_Search18"}[args.task]
     Hm, Wm = args.height // 8, args.width // 8
-    sd = procedural_state_dict(model_spec("AiR", args.arch, Hm, Wm), seed=0)
-    times = {}
-    NB = 2                   # images in the sample
-    for T in (1, 2, 8):      # T=1 is the untimed warm-up
-        batch = make_batch("AiR", NB, args.height, args.width, T, seed=0)
-        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not is_buffer(k)}
-        full = dict(sd)
-        full.update(params)
+    sd = procedural_state_dict(model_spec(task, args.arch, Hm, Wm), seed=0)
+    NB, T = args.cpu_batch, args.T
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not is_buffer(k)}
+    full = dict(sd)
+    full.update(params)
+    state = {}
+    rows = []
+    for it in range(1 + args.cpu_steps):
+        batch = make_batch(task, NB, args.height, args.width, T, seed=it)
+        for p in params.values():
+            p.grad = None
         t0 = time.perf_counter()
-        pred = O.forward(full, "AiR", batch["images"], batch["attention_maps"], batch["performances"], training=True, T=T,
-                         arch=args.arch)
+        pred = O.forward(full, task, batch["images"], batch["attention_maps"], batch["performances"], batch["tasks"],
+                         training=True, T=T, arch=args.arch)
         loss, _, _ = O.supervised_loss(pred, batch)
+        t1 = time.perf_counter()
         loss.backward()
-        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+        t2 = time.perf_counter()
+        grads = {k: p.grad for k, p in params.items()}
         with torch.no_grad():
-            O.clip_and_adam({k: p.data for k, p in params.items()}, grads, {}, lr=1e-4, clip=12.5, weight_decay=5e-5)
-        times[T] = time.perf_counter() - t0
-    per_step = max((times[8] - times[2]) / 6.0, 0.0)
-    t16 = times[2] + (args.T - 2) * per_step
-    return {"value": NB / t16, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle train step, {NB} images {args.height}x{args.width}, T=2 ({times[2]:.1f}s) and T=8 ({times[8]:.1f}s) after "
-                      f"a warm-up, extrapolated affinely to T={args.T} ({t16:.1f}s per {NB} images)"}
+            O.clip_and_adam({k: p.data for k, p in params.items()}, grads, state, lr=1e-4, clip=12.5,
+                            weight_decay=5e-5 if task == "AiR" else 5e-4)
+        t3 = time.perf_counter()
+        if it > 0:
+            rows.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+    rows.sort()
+    med = rows[len(rows) // 2]
+    return {"value": NB / med[0], "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle {task} train step (fwd+loss+bwd+clip+Adam), {NB} images {args.height}x{args.width}, {args.arch}, "
+                      f"T={T} measured (no extrapolation): 1 warm-up + {len(rows)} timed steps, median {med[0]:.1f} s/step "
+                      f"(fwd {med[1]:.1f} s, bwd {med[2]:.1f} s, clip+Adam {med[3]:.2f} s); all steps: "
+                      + ", ".join(f"{r[0]:.1f}" for r in rows),
+            "s_per_step": round(med[0], 2), "fwd_s": round(med[1], 2), "bwd_s": round(med[2], 2), "opt_s": round(med[3], 3),
+            "threads_used": cores, "host": hi}
+
+
+def build_model(args, dev):
+    from scanpaths_amd.procedural import fill_module
+    Hm, Wm = args.height // 8, args.width // 8
+    if args.task == "air":
+        from scanpaths_amd.models.baseline_attention import baseline
+        model = baseline(convLSTM_length=args.T, map_width=Wm, map_height=Hm, arch=args.arch)
+    elif args.task == "osie":
+        from scanpaths_amd.models.baseline_attention import baseline_osie
+        model = baseline_osie(convLSTM_length=args.T, map_width=Wm, map_height=Hm, arch=args.arch)
+    else:
+        from scanpaths_amd.models.baseline_attention_multihead import baseline
+        model = baseline(convLSTM_length=args.T, map_width=Wm, map_height=Hm, arch=args.arch)
+    fill_module(model, seed=0)                     # identical replicas on every rank (FlatAdam broadcasts rank 0's anyway)
+    return model.to(dev)
+
+
+def call_model(model, args, b, training):
+    if args.task == "air":
+        return model(b["images"], b["attention_maps"], b["performances"] if training else None)
+    if args.task == "osie":
+        return model(b["images"])
+    return model(b["images"], b["attention_maps"], b["tasks"])
 
 
 def main():
     args = parse()
+    if args.precision == "f16x1":
+        os.environ["SP_SPLIT_SCHEME"] = "f16x1"          # read by scanpaths_amd.functional at import
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,38 +186,59 @@ def main():
 
     from scanpaths_amd import hip
     if not os.path.exists(hip.LIB_PATH):        # the in-tree .so normally travels with the snapshot; build it if it did not
-        import subprocess                       # (rank 0 builds, the others wait at the barrier of init_process_group's store)
-        if rank == 0:
+        if rank == 0:                           # (rank 0 builds, the others wait at the barrier)
             subprocess.run(["make", "-C", os.path.join(ROOT, "scanpaths_amd", "csrc"), "-j8"], check=True, stdout=subprocess.DEVNULL)
         if world > 1:
             torch.distributed.barrier()
-    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd import functional as F
     from scanpaths_amd.models.loss import supervised_loss
     from scanpaths_amd.optim import FlatAdam
-    from scanpaths_amd.procedural import fill_module
     from scanpaths_amd.synth import make_batch
 
+    task = {"air": "AiR", "osie": "OSIE", "coco": "COCO_Search18"}[args.task]
     Hm, Wm = args.height // 8, args.width // 8
-    model = baseline(convLSTM_length=args.T, map_width=Wm, map_height=Hm, arch=args.arch)
-    fill_module(model, seed=0)                     # identical replicas on every rank
-    model = model.to(dev).train()
-    opt = FlatAdam(model.parameters(), lr=1e-4, weight_decay=5e-5, clip=12.5)
-    b = {k: v.to(dev) for k, v in make_batch("AiR", args.batch, args.height, args.width, args.T, seed=0, rank=rank).items()}
+    model = build_model(args, dev)
+    b = {k: v.to(dev) for k, v in make_batch(task, args.batch, args.height, args.width, args.T, seed=0, rank=rank).items()}
 
-    def step():
-        opt.zero_grad()
-        pred = model(b["images"], b["attention_maps"], b["performances"])
-        mask_sums = None
-        if world > 1:   # loss normalised by the GLOBAL mask sums, as DataParallel's gathered loss (AiR/train.py:190-197)
-            from scanpaths_amd import functional as F
-            from scanpaths_amd.ddp import global_mask_normaliser
-            mask_sums = global_mask_normaliser(torch.cat([F.device_sum(b["action_masks"]),
-                                                          F.device_sum(b["duration_masks"])]))
-        loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0,
-                                     mask_sums)
-        loss.backward()
-        opt.step()
-        return loss
+    if args.mode == "train":
+        model.train()
+        if world > 1:
+            from scanpaths_amd.ddp import broadcast_module_state_
+            broadcast_module_state_(model)      # BatchNorm buffers; FlatAdam broadcasts the flat parameter buffer itself
+        opt = FlatAdam(model.parameters(), lr=1e-4, weight_decay=5e-5 if args.task == "air" else 5e-4, clip=12.5,
+                       conditional_params=model.has_conditional_params)
+
+        def step():
+            opt.zero_grad()
+            pred = call_model(model, args, b, True)
+            mask_sums = None
+            if world > 1:   # loss normalised by the GLOBAL mask sums, as DataParallel's gathered loss (AiR/train.py:190-197)
+                from scanpaths_amd.ddp import global_mask_normaliser
+                mask_sums = global_mask_normaliser(torch.cat([F.device_sum(b["action_masks"]),
+                                                              F.device_sum(b["duration_masks"])]))
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0,
+                                         mask_sums)
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        # config 5: eval-mode forward + the reference's test loop sampling (AiR/test.py:140-193: eval_repeat_num = 10 sampled
+        # scanpaths per head), all on device; one D2H at the end of the timed region is NOT taken (results stay in HBM)
+        from scanpaths_amd.models.sampling import Sampling
+        model.eval()
+        sampler = Sampling(convLSTM_length=args.T, min_length=1, map_width=Wm, map_height=Hm, width=args.width, height=args.height)
+        heads = ("good", "poor") if args.task == "air" else ("",)
+
+        def step():
+            with torch.no_grad():
+                pred = call_model(model, args, b, False)
+                last = None
+                for hd in heads:
+                    pre = hd + "_" if hd else ""
+                    for _ in range(10):
+                        last = sampler.random_sample(pred[pre + "all_actions_prob"], pred[pre + "log_normal_mu"],
+                                                     pred[pre + "log_normal_sigma2"])
+            return last["durations"].sum()
 
     for _ in range(args.warmup):
         step()
@@ -164,56 +269,82 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
     summ = timer.summary()
-    # dominant kernel = the per-step h-gate conv: implicit GEMM  M = B*P, N = 2048, K = 9*512 (forward flavour)
-    P = Hm * Wm
-    dom, dom_kind = None, None
-    for kind in ("h2_fwd", "b3_fwd", "igemm_fwd"):
-        if dom is None and (kind, args.batch * P, 2048, 9 * 512, "3x3", 1) in summ:
-            dom, dom_kind = summ[(kind, args.batch * P, 2048, 9 * 512, "3x3", 1)], kind
-    if dom is None:
-        dom, dom_kind = max(summ.values(), key=lambda d: d["ms"]), "igemm_fwd"
-    dom_kernel = {"h2_fwd": "h2_kernel<fwd> (2xfp16 split, 3 MFMA products)",
-                  "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)",
-                  "igemm_fwd": "igemm_kernel<128,128,2,2,fwd> (fp32 MFMA)"}[dom_kind]
-    total_timed_ms = sum(d["ms"] for d in summ.values()) / args.steps
-    traffic = None      # fabric-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hconv.json")))["kernels"]
-        key = {"h2_fwd": "h2_kernel<0, 0>", "b3_fwd": "b3_kernel<0, 0>", "igemm_fwd": "igemm_kernel<128, 128, 2, 2, 0, false>"}[dom_kind]
-        if args.batch == 32 and (args.height, args.width) == (320, 512):
-            traffic = round(pmc[key]["hbm_side_bytes_per_launch"])
-    except Exception:
-        traffic = None
-    peak = {"h2_fwd": PEAK_SPLIT2_TFLOPS, "b3_fwd": PEAK_SPLIT3_TFLOPS, "igemm_fwd": PEAK_FP32_MFMA_TFLOPS}[dom_kind]
-    peak_note = {"h2_fwd": "2500 TFLOP/s dense fp16 MFMA peak / 3 MFMA products per algorithmic fp32-faithful FMA (2xfp16 split with "
-                           "a per-tensor power-of-two scale); the fp32 MFMA pipe peaks at 157.3",
-                 "b3_fwd": "2500 TFLOP/s dense bf16 MFMA peak / 6 MFMA products per algorithmic fp32-faithful FMA (3xbf16 split); "
-                           "the fp32 MFMA pipe peaks at 157.3",
-                 "igemm_fwd": "fp32 MFMA peak"}[dom_kind]
-    roofline = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(dom["tflops"] / peak, 4), "traffic": traffic,
-                "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes (profiles/r01_pmc_hconv.json); "
-                                "includes Infinity-Cache hits; algorithmic bytes/launch = operands once + output = 0.98e9",
-                "kernel": dom_kernel + ": h-gate conv3x3 512->2048, implicit GEMM M=B*P N=2048 K=4608",
-                "peak_note": peak_note,
-                "flops_per_launch": dom["flops_per_launch"], "avg_launch_ms": round(dom["avg_ms"], 4),
-                "launches_timed": dom["launches"],
-                "all_big_gemms_ms_per_step": round(total_timed_ms, 2),
-                "all_big_gemms_tflops": round(sum(d["flops_per_launch"] * d["launches"] for d in summ.values())
-                                              / max(sum(d["ms"] for d in summ.values()), 1e-9) / 1e9, 2)}
-    out = {"metric": "images/sec/GPU (AiR train step, bs=32, 320x512) at 1/2/4/8 MI355X", "value": round(value, 3),
+    # ---- roofline of the dominant kernel = the timed GEMM kind + shape with the largest total time -------------
+    roofline = None
+    if summ:
+        dom_key, dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        kind = dom_key[0]
+        fam = kind.split("_")[0]
+        nprod = PRODUCTS.get(fam)
+        peak = PEAK_F16_MFMA_TFLOPS if nprod else PEAK_FP32_MFMA_TFLOPS
+        traffic, traffic_src = None, None
+        if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_KEYS:
+            for fn in ("r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
+                    traffic, traffic_src = round(pmc[PMC_KEYS[kind]]["hbm_side_bytes_per_launch"]), fn
+                    break
+                except Exception:
+                    continue
+        M, N, K = dom_key[1], dom_key[2], dom_key[3]
+        total_timed_ms = sum(d["ms"] for d in summ.values()) / args.steps
+        by_kind = []
+        for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:6]:
+            f = k[0].split("_")[0]
+            by_kind.append({"kernel": KERNEL_NAMES.get(k[0], k[0]), "M": k[1], "N": k[2], "K": k[3],
+                            "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
+                            "ms_per_step": round(d["ms"] / args.steps, 2), "tflops": round(d["tflops"], 1),
+                            "frac_of_2500": round(d["tflops"] / PEAK_F16_MFMA_TFLOPS, 4) if PRODUCTS.get(f) else None})
+        roofline = {
+            "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(dom["tflops"] / peak, 4),
+            "traffic": traffic,
+            "traffic_note": (f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{traffic_src}); "
+                             "includes Infinity-Cache hits") if traffic else "no committed PMC pass for this kernel/shape",
+            "kernel": f"{KERNEL_NAMES.get(kind, kind)}: implicit GEMM M={M} N={N} K={K} ({dom_key[4]} taps) -- the timed GEMM "
+                      "kind+shape with the largest total time",
+            "achieved_note": "ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMM the reference computes) / HIP-event launch time on the "
+                             "launch stream; peak = dense MFMA peak of the dtype the kernel ISSUES (fp16: 2500 TFLOP/s)",
+            "flops_per_launch": dom["flops_per_launch"], "avg_launch_ms": round(dom["avg_ms"], 4),
+            "launches_timed": dom["launches"],
+            "mfma_products_per_fma": nprod,
+            "mfma_pipe_frac": round(dom["tflops"] * nprod / peak, 4) if nprod else None,
+            "mfma_pipe_note": "issued MFMA FLOPs / peak = frac x products per algorithmic FMA (matrix-pipe occupancy of the scheme)",
+            "timed_gemms": by_kind,
+            "all_big_gemms_ms_per_step": round(total_timed_ms, 2),
+            "all_big_gemms_tflops": round(sum(d["flops_per_launch"] * d["launches"] for d in summ.values())
+                                          / max(sum(d["ms"] for d in summ.values()), 1e-9) / 1e9, 2)}
+        # end to end: reduced (necessary) FLOPs per image x images/s, SURVEY.md §8(d) line "roofline.achieved"
+        gmac = reduced_fwd_gmac(args.arch, args.height, args.width, args.T, args.task)
+        tflop_per_img = gmac * 2e9 * (3.0 if args.mode == "train" else 1.0) / 1e12
+        roofline["end_to_end"] = {"reduced_tflop_per_image": round(tflop_per_img, 3),
+                                  "achieved_tflops": round(tflop_per_img * value / world, 1),
+                                  "frac_of_2500": round(tflop_per_img * value / world / PEAK_F16_MFMA_TFLOPS, 4),
+                                  "note": "reduced-column FLOPs/img (BASELINE.md §3; train = 3x forward) x measured img/s per GPU"}
+
+    headline = args.task == "air" and args.mode == "train" and args.precision == "f32"
+    if headline:
+        metric = "images/sec/GPU (AiR train step, bs=32, 320x512) at 1/2/4/8 MI355X"
+    else:
+        metric = (f"images/sec/GPU ({task} {'train step' if args.mode == 'train' else 'inference: eval forward + 10 sampled scanpaths per head'}"
+                  f", bs={args.batch}, {args.height}x{args.width}{', THROUGHPUT MODE f16x1' if args.precision == 'f16x1' else ''})")
+    arith = ("fp32 in / fp32 out / fp32 accumulation; GEMM operands as exact-scaled 2xfp16 splits with 3 MFMA products (error vs fp64 "
+             "below a CPU fp32 GEMM, tools/gemm_error.py); no reduced-precision storage") if args.precision == "f32" else \
+            ("THROUGHPUT MODE: large GEMM operands rounded to ONE fp16 plane (per-tensor power-of-two scale), 1 MFMA product, fp32 "
+             "accumulation, fp32 storage everywhere else; does NOT meet the 1e-4 parity bar (see DESIGN.md §6)")
+    out = {"metric": metric, "value": round(value, 3),
            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": "f32" if args.precision == "f32" else "f16-in/f32-acc", "data": "synthetic",
            "value_per_gpu": round(value / world, 3),
-           "config": {"workload": f"AiR supervised train step (fwd+loss+bwd+clip+Adam), {args.arch}, T={args.T}, "
-                                  f"{args.height}x{args.width}, per-GPU batch {args.batch}",
-                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 5),
+           "config": {"workload": f"{task} {'supervised train step (fwd+loss+bwd+clip+Adam)' if args.mode == 'train' else 'eval forward + sampling'}"
+                                  f", {args.arch}, T={args.T}, {args.height}x{args.width}, per-GPU batch {args.batch}",
+                      "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                      "loss": round(float(loss.detach()), 5) if args.mode == "train" else None,
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
-                      "arithmetic": "fp32 in / fp32 out / fp32 accumulation; GEMM operands as exact-scaled 2xfp16 splits with 3 MFMA "
-                                    "products (error vs fp64 below a CPU fp32 GEMM, tools/gemm_error.py); no reduced-precision storage"},
+                      "arithmetic": arith},
            "roofline": roofline}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.mode == "train":
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))
     if world > 1:

@@ -31,6 +31,12 @@ extern "C" {
 #define SP_ABI_VERSION 1
 int sp_abi_version(void);
 
+/* Kernel-schedule selectors for A/B timing (tools/bench_h2_variants.py) -- the ONE piece of process-wide state in the library.
+ * A selector picks between schedules of the same kernel that compute bit-identical results (same MFMA order per accumulator);
+ * it never changes numerics.  Names: "h2_variant", "hw_variant" (csrc/conv_f16x2.hip).  value < 0 restores the built-in default.
+ * Returns SP_EINVAL for an unknown name.  Not thread-safe against concurrent launches (set it before launching). */
+int sp_set_tuning(const char* name, int value);
+
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.
  * One descriptor serves forward conv, data-gradient, dense/batched GEMM (KH=KW=1, H=W=1).
@@ -313,6 +319,13 @@ int sp_scanmatch_sequences(const double* fix, int ncol, const int64_t* start, co
                            int* seq_len, void* stream);
 int sp_scanmatch_score(const int* seqA, const int* lenA, int ldA, const int* seqB, const int* lenB, int ldB, const int* pairs,
                        int npairs, const double* sub, int nb, const double* maxsub, double gap, double* scores, void* stream);
+/* score_long: the same scores for sequences longer than sp_scanmatch_max_len() (heavy-tailed sampled durations in the RL
+ * phase, AiR/train.py:256-275 -- the reference's python DP has no length limit): the strip column lives in
+ * workspace [npairs][ldA + 1] doubles (sp_scanmatch_score_long_workspace bytes) instead of LDS. */
+int64_t sp_scanmatch_score_long_workspace(int ldA, int npairs);
+int sp_scanmatch_score_long(const int* seqA, const int* lenA, int ldA, const int* seqB, const int* lenB, int ldB,
+                            const int* pairs, int npairs, const double* sub, int nb, const double* maxsub, double gap,
+                            double* scores, void* workspace, void* stream);
 int sp_scanmatch_align(const int* A, int n, const int* B, int m, const double* sub, int nb, const double* maxsub, double gap,
                        double* F_work /* [(n+1)*(m+1)] scratch */, double* Ft, double* align /* [(n+m)][2] */, int* nalign,
                        double* score, void* stream);

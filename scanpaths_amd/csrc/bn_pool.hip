@@ -420,6 +420,7 @@ extern "C" int sp_bn_apply(const float* x, const float* mean, const float* invst
     if (!x || !mean || !invstd || !gamma || !beta || !y) return SP_ENULL;
     if (C % 4) return SP_EINVAL;
     const int64_t n4 = M * C / 4;
+    SP_RESET_AMAX(y_amax, stream);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma,
                        beta, residual, relu, n4, C, y, y_amax);
     SP_LAUNCH_CHECK();
@@ -443,6 +444,7 @@ extern "C" int sp_bn_backward(const float* dy, const float* x, const float* y, c
                        coef);
     SP_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
+    SP_RESET_AMAX(dx_amax, s);
     hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, relu,
                        training, n4, C, dx, dres, dx_amax);
     SP_LAUNCH_CHECK();

@@ -13,6 +13,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// A producer's fused-amax slot is zeroed IN STREAM ORDER by the producer's own launcher (a captured memset node under HIP-graph
+// capture), so every launch -- eager or a graph replay on new inputs -- starts from 0 instead of max(old, new).
+#define SP_RESET_AMAX(ptr, stream)                                                                     \
+    do {                                                                                               \
+        if (ptr) {                                                                                     \
+            hipError_t e__ = hipMemsetAsync((void*)(ptr), 0, sizeof(unsigned), (hipStream_t)(stream)); \
+            if (e__ != hipSuccess) return (int)e__;                                                    \
+        }                                                                                              \
+    } while (0)
+
+// process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default
+enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_COUNT = 2 };
+extern int sp_tuning_values[SP_TUNE_COUNT];
+static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }
+
 static inline int64_t sp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float wave_sum(float v) {

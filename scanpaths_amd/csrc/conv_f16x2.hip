@@ -31,6 +31,8 @@ constexpr int HB_BYTES = HBN * 128;              // 16384
 constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
 constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
+constexpr int H2_DEFAULT_VARIANT = 0;            // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
+constexpr int HW_DEFAULT_VARIANT = 0;            // schedule variant of hw_kernel
 
 struct H2Args {
     const uint16_t* X;    // [pixels][Kc/16][2][16]
@@ -56,7 +58,17 @@ struct H2Args {
 // rows of every ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then hit 16 distinct 16-byte slots.
 // DBG (env SP_H2_DBG, timing experiments only): 1 = no global loads (MFMA + LDS side alone), 2 = no MFMAs (load side alone),
 // 3 = MFMAs only (no loads, no fragment reads, no barriers: what the matrix pipe sustains at the clock the chip holds)
-template <int MODE, int DBG>
+// VAR (schedule of the two waves that share a SIMD, waves w and w+4; MI355X_MICROARCH.md "Two waves per SIMD" items 1, 9):
+//   0  both run the same program in lockstep: fragment reads, then 24 MFMAs, then 6 LDS-DMA issues, wait, barrier -- the
+//      matrix pipe idles while BOTH waves read / issue loads / wait (round-1 kernel);
+//   1  half-tile stagger: waves 4-7 defer the second 16-k group's 12 MFMAs past the barrier (fragments stay in registers),
+//      so their MFMAs cover the read phase of waves 0-3;
+//   2  full ping-pong with ONE barrier per K-tile: waves 0-3 run  [issue loads(t+2)] [read(t)] [24 MFMA(t)] [wait] [barrier],
+//      waves 4-7 run  [24 MFMA(t-1)] [read(t)] [issue loads(t+2)] [wait] [barrier]  -- at any time one wave of a SIMD is in
+//      its matrix segment while its partner is in its LDS / DMA segment; waves 4-7 finish tile nkt-1 after the loop;
+//   3  = 2 with s_setprio 1 on waves 4-7 (the second-dispatched half loses VALU/issue arbitration otherwise).
+// All variants compute bit-identical results (same per-accumulator MFMA order, same fold points).
+template <int MODE, int DBG, int VAR>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -192,13 +204,11 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    int stage = 0;
-    for (int kt = 0; kt < p.nkt; ++kt) {
-        const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
-        const unsigned char* st = smem + stage * HSTAGE;
-        // all 16 fragment reads of the K-tile are issued up front (64 VGPRs): the reads of the second 16-k group then complete
-        // behind the MFMAs of the first (with the reads interleaved per group the MFMA+LDS side alone took 3.4 ms)
-        f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]
+    f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]: all 16 fragments of a K-tile (64 VGPRs)
+    // all 16 fragment reads of the K-tile are issued up front: the reads of the second 16-k group then complete behind the
+    // MFMAs of the first (with the reads interleaved per group the MFMA+LDS side alone took 3.4 ms)
+    auto read_frags = [&](int stage_, int kt_) {
+        const unsigned char* st = smem + stage_ * HSTAGE;
         if constexpr (!do_lds) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -208,45 +218,45 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     for (int pl = 0; pl < 2; ++pl) {
                         f16x8 z;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) z[e] = (_Float16)(float)(kt + e + lane);
+                        for (int e = 0; e < 8; ++e) z[e] = (_Float16)(float)(kt_ + e + lane);
                         af[kk][i][pl] = z;
                         bf[kk][i][pl] = z;
                     }
-        } else
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
-                    bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
-                }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if constexpr (do_mma) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        // three products, the two cross terms (~2^-11 of the main one) first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
-                    }
-            } else {
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
-                        const f16x8 x0 = af[kk][i][pl], x1 = bf[kk][i][pl];
-                        asm volatile("" ::"v"(x0), "v"(x1));
+                        af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
+                        bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
                     }
-            }
         }
-        // prefetch of tile kt+2 behind the MFMAs in program order (see b3_kernel), into the stage read in iteration kt-1
-        if (pre) issue_tile(stage == 0 ? HNSTAGE - 1 : stage - 1);
-        if ((kt & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+    };
+    auto mma_group = [&](int kk) {
+        if constexpr (do_mma) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // three products, the two cross terms (~2^-11 of the main one) first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const f16x8 x0 = af[kk][i][pl], x1 = bf[kk][i][pl];
+                    asm volatile("" ::"v"(x0), "v"(x1));
+                }
+        }
+    };
+    auto fold = [&](int kt_) {           // two-level accumulation: fold the chunk accumulator into the total every 256 k
+        if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -256,13 +266,66 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
         }
+    };
+    auto wait_barrier = [&](int kt_) {
         // tile kt+1 must have landed: everything but the one younger tile (if it was issued)
-        if (kt + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (do_lds) __builtin_amdgcn_s_barrier();
-        stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+    };
+    auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
+
+    int stage = 0;
+    const bool late = VAR != 0 && wave >= 4;            // the half of the workgroup that runs behind (scalar: uniform branch)
+    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(1);
+    if (!late) {
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
+            // prefetch of tile kt+2 into the stage read in iteration kt-1: VAR >= 2 issues it FIRST (its partner wave is in its
+            // matrix segment now), the lockstep / half-stagger variants behind the MFMAs in program order (see b3_kernel)
+            if (VAR >= 2 && pre) issue_tile(prev_stage(stage));
+            read_frags(stage, kt);
+            mma_group(0);
+            mma_group(1);
+            if (VAR < 2 && pre) issue_tile(prev_stage(stage));
+            fold(kt);
+            wait_barrier(kt);
+            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+        }
+    } else if (VAR == 1) {
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
+            if (kt > 0) {
+                mma_group(1);                           // second half of tile kt-1, fragments kept across the barrier
+                fold(kt - 1);
+            }
+            read_frags(stage, kt);
+            mma_group(0);
+            if (pre) issue_tile(prev_stage(stage));
+            wait_barrier(kt);
+            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+        }
+        mma_group(1);
+        fold(p.nkt - 1);
+    } else {
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
+            if (kt > 0) {
+                mma_group(0);                           // tile kt-1: its 16 fragments were read before the last barrier
+                mma_group(1);
+                fold(kt - 1);
+            }
+            read_frags(stage, kt);
+            if (pre) issue_tile(prev_stage(stage));
+            wait_barrier(kt);
+            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+        }
+        mma_group(0);
+        mma_group(1);
+        fold(p.nkt - 1);
     }
+    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(0);
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
@@ -328,6 +391,9 @@ __device__ __forceinline__ f16x8 tr_pair_h(const unsigned char* base, int off0, 
 
 __device__ __forceinline__ int rot4(int q) { return 2 * (q & 1) + 8 * (q >> 1); }
 
+// VAR: schedule of the two waves sharing a SIMD, as h2_kernel: 0 lockstep (round 1), 2 ping-pong with one barrier per K-tile
+// (waves 0-3: [issue loads(t+2)] [read(t)] [24 MFMA(t)]; waves 4-7: [24 MFMA(t-1)] [read(t)] [issue loads(t+2)]), 3 = 2 + s_setprio.
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -447,31 +513,29 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     }
     __builtin_amdgcn_s_barrier();
 
-    int stage = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool pre = kt + HNSTAGE - 1 < nkt;
-        const unsigned char* st = smem + stage * HWSTAGE;
+    f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]
+    auto read_group = [&](int stage_, int kk) {
+        const unsigned char* st = smem + stage_ * HWSTAGE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 af[2][2], bf[2][2];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int pl = 0; pl < 2; ++pl) {
+                af[kk][i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
+                bf[kk][i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
+            }
+    };
+    auto mma_group = [&](int kk) {
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    af[i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
-                    bf[i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
-                }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (pre) issue_tile(stage == 0 ? HNSTAGE - 1 : stage - 1);
-        if ((kt & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    auto fold = [&](int kt_) {
+        if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -481,12 +545,59 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
                 }
         }
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
+    auto wait_barrier = [&](int kt_) {
+        if (kt_ + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+    };
+    auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
+
+    int stage = 0;
+    const bool late = VAR != 0 && wave >= 4;
+    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(1);
+    if (!late) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool pre = kt + HNSTAGE - 1 < nkt;
+            if (VAR >= 2 && pre) issue_tile(prev_stage(stage));
+            if (VAR == 0) {                 // round-1 order: reads of a 16-pixel group right before its MFMAs
+                read_group(stage, 0);
+                mma_group(0);
+                read_group(stage, 1);
+                mma_group(1);
+            } else {
+                read_group(stage, 0);
+                read_group(stage, 1);
+                mma_group(0);
+                mma_group(1);
+            }
+            if (VAR < 2 && pre) issue_tile(prev_stage(stage));
+            fold(kt);
+            wait_barrier(kt);
+            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool pre = kt + HNSTAGE - 1 < nkt;
+            if (kt > 0) {
+                mma_group(0);
+                mma_group(1);
+                fold(kt - 1);
+            }
+            read_group(stage, 0);
+            read_group(stage, 1);
+            if (pre) issue_tile(prev_stage(stage));
+            wait_barrier(kt);
+            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+        }
+        if (nkt > 0) {
+            mma_group(0);
+            mma_group(1);
+            fold(nkt - 1);
+        }
     }
+    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(0);
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
@@ -630,9 +741,9 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
-template <int MODE, int DBG>
+template <int MODE, int DBG, int VAR>
 int launch_h2(const H2Args& a, hipStream_t s) {
-    auto kern = h2_kernel<MODE, DBG>;
+    auto kern = h2_kernel<MODE, DBG, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HSTAGE);
@@ -641,6 +752,20 @@ int launch_h2(const H2Args& a, hipStream_t s) {
     const int64_t grid = sp_cdiv(a.M, HBM) * a.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), HNSTAGE * HSTAGE, s, a);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+template <int VAR>
+int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
+    auto kern = hw_kernel<VAR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HWSTAGE);
+        attr_set = true;
+    }
+    const int64_t grid = sp_cdiv(Co, 256) * a.tiles_n;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -712,10 +837,17 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
     static const int dbg = getenv("SP_H2_DBG") ? atoi(getenv("SP_H2_DBG")) : 0;
-    if (dbg == 1) return d->mode == 0 ? launch_h2<0, 1>(a, (hipStream_t)stream) : launch_h2<1, 1>(a, (hipStream_t)stream);
-    if (dbg == 2) return d->mode == 0 ? launch_h2<0, 2>(a, (hipStream_t)stream) : launch_h2<1, 2>(a, (hipStream_t)stream);
-    if (dbg == 3) return d->mode == 0 ? launch_h2<0, 3>(a, (hipStream_t)stream) : launch_h2<1, 3>(a, (hipStream_t)stream);
-    return d->mode == 0 ? launch_h2<0, 0>(a, (hipStream_t)stream) : launch_h2<1, 0>(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const bool f = d->mode == 0;
+    if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
+    if (dbg == 2) return f ? launch_h2<0, 2, 0>(a, st) : launch_h2<1, 2, 0>(a, st);
+    if (dbg == 3) return f ? launch_h2<0, 3, 0>(a, st) : launch_h2<1, 3, 0>(a, st);
+    switch (sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT)) {
+        case 0: return f ? launch_h2<0, 0, 0>(a, st) : launch_h2<1, 0, 0>(a, st);
+        case 1: return f ? launch_h2<0, 0, 1>(a, st) : launch_h2<1, 0, 1>(a, st);
+        case 2: return f ? launch_h2<0, 0, 2>(a, st) : launch_h2<1, 0, 2>(a, st);
+        default: return f ? launch_h2<0, 0, 3>(a, st) : launch_h2<1, 0, 3>(a, st);
+    }
 }
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
@@ -749,15 +881,13 @@ extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, c
     if (xb + 64 >= (1LL << 32) || yb + 64 >= (1LL << 32) || d->Ho * d->Wo < 1) return SP_EINVAL;
     a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  HNSTAGE * HWSTAGE);
-        attr_set = true;
+    int rc;
+    switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
+        case 0: rc = launch_hw<0>(a, d->Co, s); break;
+        case 2: rc = launch_hw<2>(a, d->Co, s); break;
+        default: rc = launch_hw<3>(a, d->Co, s); break;
     }
-    const int64_t grid = sp_cdiv(d->Co, 256) * a.tiles_n;
-    hipLaunchKernelGGL(hw_kernel, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
-    SP_LAUNCH_CHECK();
+    if (rc != SP_OK) return rc;
     if (a.splits > 1) {
         const int64_t total = (int64_t)d->Co * a.Ntot;
         const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);

@@ -654,6 +654,7 @@ extern "C" int sp_lstm_rank1_fwd(const float* xg, const float* hg, const float* 
     if (!xg || !spcol || !wc || !gates || !c_out || !h_out) return SP_ENULL;
     if (C % 64 || B < 1 || P < 1 || KP < 1 || KP > 64) return SP_EINVAL;
     const size_t lds = (size_t)KP * (192 + 64) * sizeof(float);
+    SP_RESET_AMAX(h_amax, stream);
     hipLaunchKernelGGL(lstm_rank1_fwd_kernel, dim3(C / 64, (P + R1_RB - 1) / R1_RB, B), dim3(256), lds, (hipStream_t)stream, xg, hg,
                        c_prev, spcol, wc, P, C, KP, gates, c_out, h_out, h_amax);
     SP_LAUNCH_CHECK();
@@ -712,6 +713,7 @@ extern "C" int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const flo
                                      void* stream) {
     if (!gates || !c_out || !dpre || !dc_prev) return SP_ENULL;
     if (C % 4) return SP_EINVAL;
+    SP_RESET_AMAX(dpre_amax, stream);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
                        c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax);
     SP_LAUNCH_CHECK();

@@ -193,6 +193,22 @@ extern "C" int sp_scale_by(const float* x, const float* scale, int64_t n, float*
 
 extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
 
+int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1};
+
+extern "C" int sp_set_tuning(const char* name, int value) {
+    if (!name) return SP_ENULL;
+    const char* names[SP_TUNE_COUNT] = {"h2_variant", "hw_variant"};
+    for (int i = 0; i < SP_TUNE_COUNT; ++i) {
+        const char *a = names[i], *b = name;
+        while (*a && *a == *b) { ++a; ++b; }
+        if (!*a && !*b) {
+            sp_tuning_values[i] = value;
+            return SP_OK;
+        }
+    }
+    return SP_EINVAL;
+}
+
 extern "C" int64_t sp_scanpath_loss_workspace(int B, int T) { return 2 * (int64_t)B * T * (int64_t)sizeof(float); }
 
 extern "C" int sp_scanpath_loss(const float* z, const float* gt, const float* amask, const float* mu, const float* sigma2,

@@ -76,18 +76,27 @@ __global__ __launch_bounds__(64) void sequences_kernel(const double* __restrict_
     seq_len[sp] = len;
 }
 
+// LONG = false: strip column and the A symbols live in LDS (sequences up to SM_MAXLEN symbols, every validation-shaped pair).
+// LONG = true : the strip column lives in a per-pair global scratch row (colws [npairs][ldA + 1], volatile accesses: the
+//               cross-lane hand-over goes through memory) and A is read in place -- no length limit beyond the workspace; used
+//               for the rare heavy-tailed sampled durations of the RL phase (the reference's python DP just gets slower).
+template <bool LONG>
 __global__ __launch_bounds__(64) void nw_score_kernel(const int* __restrict__ seqA, const int* __restrict__ lenA, int ldA,
                                                       const int* __restrict__ seqB, const int* __restrict__ lenB, int ldB,
                                                       const int* __restrict__ pairs, const double* __restrict__ sub, int nb,
-                                                      const double* __restrict__ maxsub, double gap, double* __restrict__ scores) {
-    __shared__ double col[SM_MAXLEN + 1];
-    __shared__ int asym[SM_MAXLEN];
+                                                      const double* __restrict__ maxsub, double gap, double* __restrict__ scores,
+                                                      double* colws) {
+    __shared__ double col_s[LONG ? 1 : SM_MAXLEN + 1];
+    __shared__ int asym_s[LONG ? 1 : SM_MAXLEN];
     const int p = blockIdx.x, lane = threadIdx.x;
     const int ia = pairs ? pairs[2 * p] : p, ib = pairs ? pairs[2 * p + 1] : p;
     const int n = lenA[ia], m = lenB[ib];
     const int* A = seqA + (int64_t)ia * ldA;
     const int* B = seqB + (int64_t)ib * ldB;
-    for (int i = lane; i < n; i += 64) asym[i] = A[i];
+    volatile double* col = LONG ? colws + (int64_t)p * (ldA + 1) : col_s;
+    const int* asym = LONG ? A : asym_s;
+    if (!LONG)
+        for (int i = lane; i < n; i += 64) asym_s[i] = A[i];
     for (int i = lane; i <= n; i += 64) col[i] = gap * (double)(i + 1);      // F[i][0]
     __syncthreads();
     // borders: F[i][0] = gap*(i+1), F[0][j] = gap*(j+1) -- monotone, so their maximum sits at an end
@@ -200,8 +209,23 @@ extern "C" int sp_scanmatch_score(const int* seqA, const int* lenA, int ldA, con
                                   double* scores, void* stream) {
     if (!seqA || !lenA || !seqB || !lenB || !sub || !maxsub || !scores) return SP_ENULL;
     if (npairs < 1 || nb < 1 || ldA < 1 || ldB < 1 || ldA > SM_MAXLEN || ldB > SM_MAXLEN) return SP_EINVAL;
-    hipLaunchKernelGGL(nw_score_kernel, dim3(npairs), dim3(64), 0, (hipStream_t)stream, seqA, lenA, ldA, seqB, lenB, ldB, pairs,
-                       sub, nb, maxsub, gap, scores);
+    hipLaunchKernelGGL(nw_score_kernel<false>, dim3(npairs), dim3(64), 0, (hipStream_t)stream, seqA, lenA, ldA, seqB, lenB, ldB,
+                       pairs, sub, nb, maxsub, gap, scores, (double*)nullptr);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int64_t sp_scanmatch_score_long_workspace(int ldA, int npairs) {
+    return (ldA < 1 || npairs < 1) ? 0 : (int64_t)npairs * ((int64_t)ldA + 1) * (int64_t)sizeof(double);
+}
+
+extern "C" int sp_scanmatch_score_long(const int* seqA, const int* lenA, int ldA, const int* seqB, const int* lenB, int ldB,
+                                       const int* pairs, int npairs, const double* sub, int nb, const double* maxsub, double gap,
+                                       double* scores, void* workspace, void* stream) {
+    if (!seqA || !lenA || !seqB || !lenB || !sub || !maxsub || !scores || !workspace) return SP_ENULL;
+    if (npairs < 1 || nb < 1 || ldA < 1 || ldB < 1) return SP_EINVAL;
+    hipLaunchKernelGGL(nw_score_kernel<true>, dim3(npairs), dim3(64), 0, (hipStream_t)stream, seqA, lenA, ldA, seqB, lenB, ldB,
+                       pairs, sub, nb, maxsub, gap, scores, (double*)workspace);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

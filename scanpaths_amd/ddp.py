@@ -39,11 +39,62 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
     return w
 
 
+class GradBucketer:
+    """Overlaps the gradient all-reduce with backward: the ONE flat gradient buffer is cut into contiguous buckets of
+    ~bucket_bytes (whole parameters; parameters are registered in forward order, so gradients become ready from the LAST
+    bucket backwards).  ``mark_ready(i)`` is called from parameter i's post-accumulate-grad hook; when every parameter of a
+    bucket has reported, its slice is all-reduced asynchronously (RCCL runs it on its own stream beside the remaining backward
+    kernels).  ``finish()`` launches whatever is still pending (parameters that received no gradient this step never report)
+    and waits for all handles.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound:
+    25-50 MB buckets keep each collective bandwidth-bound (>= 0.3 ms) without leaving a long un-overlapped tail (the first
+    bucket of the encoder is the last to become ready).  Pure torch.distributed: runs on CPU tensors over gloo in the tests."""
+
+    def __init__(self, flat: torch.Tensor, offsets, numel: int, bucket_bytes: int = 32 << 20, group=None):
+        self.flat, self.group = flat, group
+        n = len(offsets)
+        ends = list(offsets[1:]) + [numel]
+        self.bucket_of = [0] * n
+        self.ranges = []                 # (lo, hi) element ranges, in parameter order
+        lo, cur = 0, 0
+        for i in range(n):
+            self.bucket_of[i] = len(self.ranges)
+            cur = ends[i]
+            if (cur - lo) * flat.element_size() >= bucket_bytes or i == n - 1:
+                self.ranges.append((lo, cur))
+                lo = cur
+        self.members = [0] * len(self.ranges)
+        for b in self.bucket_of:
+            self.members[b] += 1
+        self.reset()
+
+    def reset(self):
+        self.pending = list(self.members)
+        self.next_b = len(self.ranges) - 1      # buckets are launched in strictly DESCENDING order on every rank: the sequence
+        self.handles = []                       # of collectives is identical even when ranks' autograd graphs differ (COCO heads)
+
+    def _launch_ready(self, force: bool = False):
+        while self.next_b >= 0 and (force or self.pending[self.next_b] == 0):
+            lo, hi = self.ranges[self.next_b]
+            self.handles.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+            self.next_b -= 1
+
+    def mark_ready(self, i: int):
+        self.pending[self.bucket_of[i]] -= 1
+        self._launch_ready()
+
+    def finish(self):
+        self._launch_ready(force=True)
+        for h in self.handles:
+            h.wait()
+        self.reset()
+
+
 def union_flags(flags, device, group=None):
     """Element-wise OR across ranks of a list of booleans (which parameters received a gradient this step).  Under the
     reference's DataParallel one optimizer sees the reduce-added gradients, so a parameter is updated when ANY replica used
     it (COCO_Search18: the per-category heads of the categories present anywhere in the global batch); every rank must take
-    the same decision or the replicas drift apart."""
+    the same decision or the replicas drift apart.  Only models with conditionally-used parameters need this exchange
+    (FlatAdam(conditional_params=True)); it costs one small all-reduce and one host sync per step."""
     if world_size(group) == 1:
         return list(flags)
     t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
@@ -51,11 +102,47 @@ def union_flags(flags, device, group=None):
     return [bool(v) for v in t.tolist()]
 
 
+def broadcast_module_state_(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """nn.DataParallel replicates replica 0's parameters AND buffers on every forward (AiR/train.py:169-170); with one
+    process per GPU the replicas must START identical instead: broadcast every parameter and buffer (BatchNorm running
+    statistics, num_batches_tracked) from ``src``.  FlatAdam broadcasts its flat parameter buffer itself; call this for the
+    buffers (or after loading a checkpoint on rank 0 only)."""
+    if world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+def assert_replicas_identical(flat: torch.Tensor, group=None) -> None:
+    """cheap drift check: the (sum, sum of squares) fingerprint of the flat parameter buffer must agree on all ranks"""
+    w = world_size(group)
+    if w == 1:
+        return
+    fp = torch.stack([flat.double().sum(), (flat.double() ** 2).sum()])
+    lo, hi = fp.clone(), fp.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("data-parallel replicas hold different parameters (seed / checkpoint not shared by all ranks?)")
+
+
+def _slice0(v, lo, hi):
+    return v[lo:hi]
+
+
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
-    """DataParallel-style scatter along dim 0 (AiR/train.py:170): every tensor input splits the same way."""
+    """DataParallel-style scatter along dim 0 (AiR/train.py:170): every per-sample input splits the same way -- tensors,
+    numpy arrays and the python lists the RL batches carry (fix_vectors, performances; AiR/train.py:223-228).  Raises when the
+    batch is smaller than the world (an empty shard would launch zero-size kernels)."""
     out = {}
     for k, v in batch.items():
-        n = v.shape[0]
+        n = v.shape[0] if hasattr(v, "shape") else len(v)
+        if n < world:
+            raise ValueError(f"shard_batch: '{k}' has {n} samples for {world} ranks")
         per = (n + world - 1) // world
-        out[k] = v[rank * per:min(n, (rank + 1) * per)]
+        lo, hi = rank * per, min(n, (rank + 1) * per)
+        if hi <= lo:
+            raise ValueError(f"shard_batch: rank {rank} of {world} receives no sample of '{k}' (n = {n})")
+        out[k] = _slice0(v, lo, hi)
     return out

@@ -39,6 +39,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> (restype, argtypes); must list every symbol include/scanpaths_amd.h declares
 SIGNATURES = {
     "sp_abi_version": (_I, []),
+    "sp_set_tuning": (_I, [C.c_char_p, _I]),
     "sp_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_split3_bf16": (_I, [_P, _L, _P, _P]),
     "sp_split3_bf16_wT": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -100,6 +101,8 @@ SIGNATURES = {
     "sp_scanmatch_submatrix": (_I, [_I, _I, C.c_double, _P, _P, _P]),
     "sp_scanmatch_sequences": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, C.c_double, C.c_double, C.c_double, _P, _I, _P, _P, _P]),
     "sp_scanmatch_score": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, C.c_double, _P, _P]),
+    "sp_scanmatch_score_long_workspace": (_L, [_I, _I]),
+    "sp_scanmatch_score_long": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, C.c_double, _P, _P, _P]),
     "sp_scanmatch_align": (_I, [_P, _I, _P, _I, _P, _I, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
     "sp_scan_max_fixations": (_I, []),
     "sp_scan_sed_stde": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),

@@ -48,7 +48,10 @@ class Sampling():
         aprob = torch.empty((B, T), dtype=torch.float32, device=dev)
         dur = torch.empty((B, T), dtype=torch.float32, device=dev)
         self._calls += 1
-        seed = (int(self.seed) * 0x9E3779B97F4A7C15 + self._calls) & 0xFFFFFFFFFFFFFFFF
+        # one process per GPU: every rank must draw its own stream (the Philox counter is the LOCAL row index), so the rank
+        # enters the key; single-process runs (rank 0) keep the key of earlier versions
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        seed = (int(self.seed) * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + self._calls) & 0xFFFFFFFFFFFFFFFF
         check(hip.lib().sp_sample_actions(ptr(probs), ptr(mu), ptr(s2), B, T, A, int(self.min_length), seed, ptr(actions),
                                           ptr(aprob), ptr(dur), hip.stream()), "sp_sample_actions")
         length, _, _, _, _ = self._scan(actions, dur)

@@ -158,6 +158,8 @@ class ScanpathModel(nn.Module):
         self.downsampling_rate = 8
         self.map_width, self.map_height = map_width, map_height
         self.streams = ["_pos", "_neg"] if task == "AiR" else [""]
+        # per-category heads only receive gradients for the categories present in a batch -> FlatAdam(conditional_params=True)
+        self.has_conditional_params = task == "COCO_Search18"
         Hm, Wm = map_height, map_width
         P = Hm * Wm
         self.resnet = _make_encoder(arch)

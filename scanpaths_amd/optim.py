@@ -26,8 +26,23 @@ ALIGN = 4  # elements (16 bytes)
 
 
 class FlatAdam(torch.optim.Optimizer):
+    """clip: max total gradient norm (0 = no clipping).  Data parallel (torch.distributed initialised, process_group not
+    False): the flat parameter buffer is broadcast from rank 0 at construction (nn.DataParallel replicates replica 0's weights,
+    AiR/train.py:169-170 -- replicas that start different would silently stay different), the flat gradient buffer is
+    all-reduced in ~bucket_mb buckets launched from the post-accumulate-grad hooks so the exchange overlaps backward
+    (ddp.GradBucketer), and the average is folded into the Adam kernel.
+    conditional_params: the model has parameters that only some batches use (COCO_Search18 per-category heads).  True: the
+    "received a gradient" flags are OR-ed across ranks every step (one small all-reduce + host sync).  False (AiR / OSIE):
+    no exchange; a parameter without a gradient under data parallelism then raises instead of letting the replicas drift.
+    Which parameters are stepped -- torch.optim.Adam skips ``p.grad is None``:
+      * ``zero_grad()`` / ``zero_grad(set_to_none=True)`` (torch >= 2.0 default, the torch installed here): a parameter that
+        received no gradient in THIS backward is skipped (no decay, no moment update, no step increment);
+      * ``zero_grad(set_to_none=False)`` (the only behaviour of the reference's pinned torch==1.6.0, sp_baseline.yml:116):
+        gradients are zeroed, not dropped, so a parameter that has EVER received a gradient keeps being decayed and
+        momentum-stepped with a zero gradient (a COCO head whose category is absent from later batches)."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 clip: float = 0.0, process_group=None):
+                 clip: float = 0.0, process_group=None, conditional_params: bool = False, bucket_mb: float = 32.0):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip=clip))
         assert len(self.param_groups) == 1
@@ -47,7 +62,9 @@ class FlatAdam(torch.optim.Optimizer):
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._steps = [0] * len(params)          # per-parameter Adam step (torch.optim.Adam keeps it per parameter)
         self._touched = [False] * len(params)    # did this backward produce a gradient for the parameter?
+        self._sticky = False                     # zero_grad(set_to_none=False) semantics, see the class docstring
         self.process_group = process_group
+        self.conditional_params = bool(conditional_params)
         with torch.no_grad():
             for p, o in zip(params, offs):
                 st = self._dense_strides(p)
@@ -58,8 +75,20 @@ class FlatAdam(torch.optim.Optimizer):
                 self.state[p] = {"step": torch.zeros((), dtype=torch.float32),
                                  "exp_avg": torch.as_strided(self.flat_m, p.shape, st, o),
                                  "exp_avg_sq": torch.as_strided(self.flat_v, p.shape, st, o)}
+        self._bucketer = None
+        if process_group is not False:
+            from .ddp import GradBucketer, world_size
+            if world_size(process_group) > 1:
+                torch.distributed.broadcast(self.flat_p, src=0, group=process_group)      # replicas start identical
+                if bucket_mb > 0:
+                    self._bucketer = GradBucketer(self.flat_g, offs, total, int(bucket_mb * (1 << 20)), process_group)
         for i, p in enumerate(params):
-            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touched.__setitem__(i, True))
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+
+    def _on_grad(self, i: int):
+        self._touched[i] = True
+        if self._bucketer is not None and self._params[i].grad.data_ptr() == self.flat_g.data_ptr() + 4 * self._offs[i]:
+            self._bucketer.mark_ready(i)      # (a foreign .grad tensor is copied into the flat buffer in step(): no early launch)
 
     @staticmethod
     def _dense_strides(p):
@@ -68,36 +97,62 @@ class FlatAdam(torch.optim.Optimizer):
             return torch.empty(p.shape).stride()
         return torch.empty(p.shape).contiguous(memory_format=torch.channels_last).stride()
 
-    def zero_grad(self, set_to_none: bool = False):   # noqa: D401  (views must survive)
+    def zero_grad(self, set_to_none: bool = True):
+        """one memset of the flat buffer; the .grad views always survive (set_to_none only selects WHICH parameters the next
+        step() updates, see the class docstring)"""
+        self._sticky = not set_to_none
         self.flat_g.zero_()
         self._touched = [False] * len(self._params)
         for p, o in zip(self._params, self._offs):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = torch.as_strided(self.flat_g, p.shape, self._dense_strides(p), o)
 
-    def _gather_foreign_grads(self):
-        """If a caller replaced p.grad (e.g. the reference's optimizer.zero_grad(set_to_none=True)), copy it back."""
+    def _gather_foreign_grads(self) -> bool:
+        """If a caller replaced p.grad (e.g. the stock ``for p in params: p.grad = None`` idiom), copy it back.  Returns whether
+        any gradient had to be copied (the bucketed early all-reduce then cannot be used for this step)."""
+        foreign = False
         for i, (p, o) in enumerate(zip(self._params, self._offs)):
             g = p.grad
+            if g is not None and g.data_ptr() == self.flat_g.data_ptr() + 4 * o:
+                continue
             view = torch.as_strided(self.flat_g, p.shape, self._dense_strides(p), o)
             if g is None:
                 view.zero_()
                 self._touched[i] = False
-            elif g.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+            else:
                 view.copy_(g)
                 self._touched[i] = True
+                foreign = True
             p.grad = view
+        return foreign
 
     @torch.no_grad()
     def step(self, closure=None):
-        self._gather_foreign_grads()
+        foreign = self._gather_foreign_grads()
         g = self.param_groups[0]
         world = 1
-        if self.process_group is not False:   # RCCL sum over xGMI of ONE flat buffer; averaged inside the Adam kernel
-            from .ddp import allreduce_sum_, union_flags
-            world = allreduce_sum_(self.flat_g, self.process_group)
-            if world > 1:      # e.g. COCO heads of categories absent from this rank's shard; unconditional: a collective
-                self._touched = union_flags(self._touched, self.flat_g.device, self.process_group)
+        if self.process_group is not False:   # RCCL sum over xGMI of the flat buffer (bucketed, overlapped); averaged in the Adam kernel
+            from .ddp import allreduce_sum_, union_flags, world_size
+            world = world_size(self.process_group)
+            if world > 1:
+                if self._bucketer is None:
+                    allreduce_sum_(self.flat_g, self.process_group)
+                elif foreign:
+                    raise RuntimeError("FlatAdam: a parameter's .grad was replaced by a foreign tensor while the bucketed, "
+                                       "overlapped gradient all-reduce is active; use FlatAdam.zero_grad() (views survive) or "
+                                       "construct FlatAdam(bucket_mb=0) for one un-overlapped all-reduce in step()")
+                else:
+                    self._bucketer.finish()                   # launch what is still pending, wait for every bucket
+                if self.conditional_params:   # COCO heads of categories absent from this rank's shard: same decision on every rank
+                    self._touched = union_flags(self._touched, self.flat_g.device, self.process_group)
+                elif not all(self._touched):
+                    missing = sum(1 for t in self._touched if not t)
+                    raise RuntimeError(
+                        f"FlatAdam: {missing} parameter(s) received no gradient on this rank under data parallelism; construct "
+                        "FlatAdam(conditional_params=True) for models with conditionally-used parameters (COCO_Search18 "
+                        "per-category heads) so that every rank takes the same decision")
+        if self._sticky:
+            self._touched = [t or s > 0 for t, s in zip(self._touched, self._steps)]
         L = hip.lib()
         ws = hip.workspace(L.sp_sumsq_workspace(self.numel), self.flat_g.device, slot=1)
         check(L.sp_sumsq(ptr(self.flat_g), self.numel, ptr(self._sumsq), ptr(ws), hip.stream()), "sp_sumsq")

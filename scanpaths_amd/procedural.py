@@ -28,8 +28,32 @@ def _rng(key: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
 
 
-def procedural_tensor(key: str, shape: Tuple[int, ...], bn_keys: Iterable[str], seed: int = 0) -> torch.Tensor:
-    """Value for one state_dict entry. ``bn_keys`` = set of module prefixes that are BatchNorm."""
+FAMILIES = ("default", "tame")
+TAME_LAST_BN_GAIN = 0.25
+
+
+def _is_last_bn_of_block(prefix: str, bn_keys) -> bool:
+    """resnet.<4..7>.<i>.bn3 (Bottleneck) or .bn2 of a BasicBlock (no bn3 sibling): the BatchNorm that closes the residual branch"""
+    head, _, leaf = prefix.rpartition(".")
+    if not prefix.startswith("resnet.") or leaf not in ("bn2", "bn3"):
+        return False
+    return leaf == "bn3" or (head + ".bn3") not in bn_keys
+
+
+def procedural_tensor(key: str, shape: Tuple[int, ...], bn_keys: Iterable[str], seed: int = 0,
+                      family: str = "default") -> torch.Tensor:
+    """Value for one state_dict entry. ``bn_keys`` = set of module prefixes that are BatchNorm.
+
+    family "default": the round-1 distributions (below).  In eval mode its random BatchNorm statistics do not normalise, every
+    residual block doubles the variance, the encoder output reaches rms ~1e4 and the decoder gates become step functions: the
+    16-step recurrence is chaotic (the reference's own fp32 run leaves its fp64 run by 1 % after 3 steps), so only the first
+    decode steps carry a tight parity bar.
+    family "tame": identical draws, except that the BatchNorm closing each residual branch has its weight scaled by
+    TAME_LAST_BN_GAIN (the usual small-gamma residual initialisation).  Activations stay O(1-10) in both BN modes, the decoder
+    works in its smooth regime, and the reference's fp32-vs-fp64 drift stays ~1e-5 of scale over all 16 steps -- so every step
+    can be held to the north-star bar (1e-4 on logits, exact argmax)."""
+    if family not in FAMILIES:
+        raise ValueError(f"unknown weight family {family!r}")
     rng = _rng(key, seed)
     prefix, _, leaf = key.rpartition(".")
     if leaf == "num_batches_tracked":
@@ -40,7 +64,10 @@ def procedural_tensor(key: str, shape: Tuple[int, ...], bn_keys: Iterable[str], 
         return torch.from_numpy(rng.uniform(0.5, 1.5, shape)).to(torch.float32)
     if prefix in bn_keys:
         if leaf == "weight":
-            return torch.from_numpy(rng.uniform(0.5, 1.5, shape)).to(torch.float32)
+            w = rng.uniform(0.5, 1.5, shape)
+            if family == "tame" and _is_last_bn_of_block(prefix, bn_keys):
+                w = w * TAME_LAST_BN_GAIN
+            return torch.from_numpy(w).to(torch.float32)
         return torch.from_numpy(rng.normal(0.0, 0.1, shape)).to(torch.float32)
     if len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))
@@ -49,14 +76,14 @@ def procedural_tensor(key: str, shape: Tuple[int, ...], bn_keys: Iterable[str], 
     return torch.from_numpy(rng.normal(0.0, 0.05, shape)).to(torch.float32)
 
 
-def procedural_state_dict(spec: Mapping[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:
+def procedural_state_dict(spec: Mapping[str, Tuple[int, ...]], seed: int = 0, family: str = "default") -> Dict[str, torch.Tensor]:
     """``spec`` maps state_dict key -> shape (e.g. ``{k: tuple(v.shape) for k, v in model.state_dict().items()}``)."""
     bn = {k.rpartition(".")[0] for k in spec if k.endswith(".running_mean")}
-    return {k: procedural_tensor(k, tuple(s), bn, seed) for k, s in spec.items()}
+    return {k: procedural_tensor(k, tuple(s), bn, seed, family) for k, s in spec.items()}
 
 
-def fill_module(module: torch.nn.Module, seed: int = 0) -> None:
+def fill_module(module: torch.nn.Module, seed: int = 0, family: str = "default") -> None:
     """Load procedural values into any module exposing the reference state_dict keys."""
     sd = module.state_dict()
-    new = procedural_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed)
+    new = procedural_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed, family)
     module.load_state_dict({k: v.to(sd[k].dtype) for k, v in new.items()})

@@ -22,6 +22,7 @@ import torch
 
 from . import functional as F
 from .models.loss import LogAction, LogDuration
+from .utils.evaltools.scanmatch import SequenceTooLong
 from .utils.evaluation import gtpairs_eval_scanmatch_performance_related, pairs_eval_scanmatch_performance_related
 
 
@@ -101,9 +102,17 @@ def rl_step(model, sampling, optimizer, images, attention_maps, gt_fix_vectors, 
         samples = sampling.random_sample(prob, mu, s2)
         fix, action_masks, duration_masks = sampling.generate_scanpath(images, samples["selected_actions_probs"],
                                                                        samples["durations"], samples["selected_actions"])
-        same, diff, accept = pairs_eval_scanmatch_performance_related(gt_fix_vectors, fix, ScanMatchwithDuration,
-                                                                      ScanMatchwithoutDuration, performances,
-                                                                      given_performance[trial])
+        # a heavy-tailed duration draw (exp(eps*sigma2 + mu)) can be inf or map to more symbols than the scorer's buffers hold
+        # (utils/evaltools/scanmatch.py MAX_SYMBOLS): the reference's int(round(inf)) raises there; here the sample is redrawn
+        finite = all(np.isfinite(np.asarray(f["duration"], dtype=np.float64)).all() for f in fix)
+        try:
+            if not finite:
+                raise SequenceTooLong("non-finite sampled duration")
+            same, diff, accept = pairs_eval_scanmatch_performance_related(gt_fix_vectors, fix, ScanMatchwithDuration,
+                                                                          ScanMatchwithoutDuration, performances,
+                                                                          given_performance[trial])
+        except SequenceTooLong:
+            accept = False
         if not accept:
             resamples += 1
             if resamples > max_resamples:

@@ -23,6 +23,13 @@ from ... import hip
 from ...hip import check, ptr
 
 
+MAX_SYMBOLS = 1 << 18      # hard cap per sequence (3.6 h of fixation at TempBin = 50 ms): bounds the symbol / scratch buffers
+
+
+class SequenceTooLong(ValueError):
+    """a scanpath maps to more than MAX_SYMBOLS symbols (or to a non-finite count)"""
+
+
 class ScanMatch(object):
     def __init__(self, **kw):
         self.Xres = 1024
@@ -103,8 +110,8 @@ class ScanMatch(object):
             check(L.sp_scanmatch_sequences(ptr(fix), ncol, ptr(start), ptr(count), nsp, *args, 0, None, ptr(lens), hip.stream()),
                   "sp_scanmatch_sequences")
             ld = max(1, int(lens.max().item()))
-        if ld > L.sp_scanmatch_max_len():
-            raise ValueError(f"sequence of {ld} symbols exceeds the kernel limit {L.sp_scanmatch_max_len()}")
+        if ld > MAX_SYMBOLS or ld < 0:      # longer than the LDS kernel's sp_scanmatch_max_len() is fine: match_pairs switches kernels
+            raise SequenceTooLong(f"sequence of {ld} symbols exceeds the cap of {MAX_SYMBOLS}")
         seq = torch.zeros((nsp, ld), dtype=torch.int32, device=self.device)
         check(L.sp_scanmatch_sequences(ptr(fix), ncol, ptr(start), ptr(count), nsp, *args, ld, ptr(seq), ptr(lens), hip.stream()),
               "sp_scanmatch_sequences")
@@ -145,9 +152,16 @@ class ScanMatch(object):
         scores = torch.empty(npairs, dtype=torch.float64, device=self.device)
         if npairs == 0:
             return scores
-        check(hip.lib().sp_scanmatch_score(ptr(seqA), ptr(lenA), seqA.shape[1], ptr(seqB), ptr(lenB), seqB.shape[1], ptr(pairs),
-                                           npairs, ptr(self._sub), self._sub.shape[0], ptr(self._maxsub), float(self.GapValue),
-                                           ptr(scores), hip.stream()), "sp_scanmatch_score")
+        L = hip.lib()
+        if max(seqA.shape[1], seqB.shape[1]) <= L.sp_scanmatch_max_len():
+            check(L.sp_scanmatch_score(ptr(seqA), ptr(lenA), seqA.shape[1], ptr(seqB), ptr(lenB), seqB.shape[1], ptr(pairs),
+                                       npairs, ptr(self._sub), self._sub.shape[0], ptr(self._maxsub), float(self.GapValue),
+                                       ptr(scores), hip.stream()), "sp_scanmatch_score")
+        else:       # rare: a heavy-tailed sampled duration; the strip column moves from LDS to a global scratch row per pair
+            ws = torch.empty(L.sp_scanmatch_score_long_workspace(seqA.shape[1], npairs), dtype=torch.uint8, device=self.device)
+            check(L.sp_scanmatch_score_long(ptr(seqA), ptr(lenA), seqA.shape[1], ptr(seqB), ptr(lenB), seqB.shape[1], ptr(pairs),
+                                            npairs, ptr(self._sub), self._sub.shape[0], ptr(self._maxsub), float(self.GapValue),
+                                            ptr(scores), ptr(ws), hip.stream()), "sp_scanmatch_score_long")
         return scores
 
     def match_all(self, scanpaths_a: Sequence[np.ndarray], scanpaths_b: Sequence[np.ndarray]) -> np.ndarray:

@@ -15,10 +15,10 @@ def load_golden(name):
     return meta, data
 
 
-def oracle_state(task, arch, seed, Hm=30, Wm=40, dtype=torch.float64):
+def oracle_state(task, arch, seed, Hm=30, Wm=40, dtype=torch.float64, family="default"):
     from scanpaths_amd.procedural import procedural_state_dict
     from scanpaths_amd.spec import model_spec
-    sd = procedural_state_dict(model_spec(task, arch, Hm, Wm), seed)
+    sd = procedural_state_dict(model_spec(task, arch, Hm, Wm), seed, family)
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
 
 

@@ -50,7 +50,7 @@ def test_ctypes_signatures_match_the_header():
         assert (cret is ctypes.c_int64) == (ret == "int64_t"), (name, ret, cret)
         for a, c in zip(args, cargs):
             if "*" in a:
-                assert c is ctypes.c_void_p or issubclass(c, ctypes._Pointer), (name, a, c)      # void* or POINTER(desc struct)
+                assert c in (ctypes.c_void_p, ctypes.c_char_p) or issubclass(c, ctypes._Pointer), (name, a, c)      # void* or POINTER(desc struct)
             elif a.startswith("int64_t"):
                 assert c is ctypes.c_int64, (name, a, c)
             elif a.startswith("uint64_t"):
@@ -134,3 +134,52 @@ def test_synth_and_procedural_are_deterministic():
     spec = {k: v for k, v in list(model_spec("OSIE", "resnet18").items())[:40]}
     s1, s2 = procedural_state_dict(spec, 3), procedural_state_dict(dict(reversed(list(spec.items()))), 3)
     assert all(torch.equal(s1[k], s2[k]) for k in spec)          # value depends on key/shape/seed, not on order
+
+
+def test_init_weights_match_reference_distributions():
+    """ScanpathModel.init_weights against (i) the analytic laws of the reference's initialisers
+    (models/resnet.py:112-118: N(0, sqrt(2/(k*k*Cout))), BN 1/0; mmcv xavier_init(distribution='normal') for decoder convs:
+    N(0, sqrt(2/(fan_in+fan_out))), bias 0; normal_init(std=0.01) for Linears -- AiR/models/baseline_attention.py:58-65,
+    90-97,126-133,176-185,495-504) and (ii) the statistics of the REAL reference's freshly built models
+    (tests/golden/init_stats.json from make_golden_init.py).  Tolerances are ~6 sigma of the sampling error of a std estimate
+    (std * sqrt(1/(2n))) and of a mean estimate (std/sqrt(n)) for BOTH samples."""
+    import json
+    import math
+    import os
+
+    import torch
+
+    from scanpaths_amd.models.scanpath_model import ScanpathModel
+    with open(os.path.join(os.path.dirname(__file__), "golden", "init_stats.json")) as f:
+        ref_all = json.load(f)
+    for task in ("AiR", "OSIE", "COCO_Search18"):
+        torch.manual_seed(1)
+        m = ScanpathModel(task)
+        ref = ref_all[task]
+        names = [k for k, _ in m.named_parameters()]
+        assert names == list(ref.keys())                       # same parameters, same registration order
+        mods = dict(m.named_modules())
+        for k, p in m.named_parameters():
+            v = p.detach().double()
+            n = v.numel()
+            rmean, rstd, rmax, rn = ref[k]
+            assert rn == n, k
+            owner = mods[k.rpartition(".")[0]]
+            is_bn = hasattr(owner, "running_mean")
+            if k.endswith(".bias") or is_bn:
+                want = 1.0 if (is_bn and k.endswith(".weight")) else 0.0      # constants in the reference too
+                assert float((v - want).abs().max()) == 0.0 and rstd == 0.0 and abs(rmean - want) == 0.0, k
+                continue
+            if v.dim() == 4:
+                co, ci, kh, kw = v.shape
+                std = math.sqrt(2.0 / (kh * kw * co)) if k.startswith("resnet.") else math.sqrt(2.0 / ((ci + co) * kh * kw))
+            else:
+                std = 0.01
+            tol_std = 6.0 * std * math.sqrt(1.0 / (2 * n)) + 1e-12
+            tol_mean = 6.0 * std / math.sqrt(n)
+            got_std = float(v.std()) if n > 1 else None
+            if n >= 64:          # tiny tensors (1x1x3x3 attention convs) carry no distributional information
+                assert abs(got_std - std) <= tol_std, (k, got_std, std)
+                assert abs(rstd - std) <= tol_std, ("reference", k, rstd, std)
+                assert abs(float(v.mean())) <= tol_mean and abs(rmean) <= tol_mean, k
+            assert float(v.abs().max()) <= 7.0 * std and rmax <= 7.0 * std, k

@@ -36,7 +36,7 @@ def _one_step(world, rank, port, q):
     m = ScanpathModel("OSIE", convLSTM_length=2, arch="resnet18")
     fill_module(m, seed=8)
     m = m.to(dev).train()
-    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5)
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5, bucket_mb=4)     # several buckets, overlapped
     b = {k: v.to(dev) for k, v in make_batch("OSIE", 2, 240, 320, 2, seed=8).items()}     # same shard on every rank
     opt.zero_grad()
     pred = m(b["images"])
@@ -87,11 +87,15 @@ def _coco_step(world, rank, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     m = ScanpathModel("COCO_Search18", convLSTM_length=2, arch="resnet18")
-    fill_module(m, seed=5)
+    fill_module(m, seed=5 + 100 * rank)        # replicas start DIFFERENT: FlatAdam must broadcast rank 0's parameters
     m = m.to(dev).train()
-    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5)
+    from scanpaths_amd.ddp import assert_replicas_identical, broadcast_module_state_
+    broadcast_module_state_(m)                 # BatchNorm buffers too (what nn.DataParallel's per-forward replication does)
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5, conditional_params=m.has_conditional_params,
+                   bucket_mb=8)
     b = {k: v.to(dev) for k, v in make_batch("COCO_Search18", 2, 240, 320, 2, seed=5, rank=rank).items()}
     b["tasks"] = torch.tensor([1, 7] if rank == 0 else [7, 12], device=dev)
+    assert_replicas_identical(opt.flat_p)
     opt.zero_grad()
     pred = m(b["images"], b["attention_maps"], b["tasks"])
     sums = torch.cat([F.device_sum(b["action_masks"]), F.device_sum(b["duration_masks"])])

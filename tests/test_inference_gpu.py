@@ -91,6 +91,44 @@ def test_eval_forward_hip_graph_replay_is_bit_identical():
     assert not torch.equal(ref["good_all_actions_prob"], ref2["good_all_actions_prob"])
 
 
+def test_hip_graph_replays_with_different_amplitudes_are_bit_identical_to_eager():
+    """The fused-amax slots of the 2xfp16 operand scale (functional._amax_hint) are reset in stream order by the producing
+    launcher (common.h SP_RESET_AMAX: a memset node inside the captured graph), so a replay never sees max(old, new): three
+    replays on different inputs -- ordinary, x100 amplitude, then x0.01 (the case a stale maximum would ruin: a too-small
+    scale loses the low plane) -- are each bit-identical to an eager forward on the same input."""
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    T = 3
+    m = baseline(convLSTM_length=T)
+    fill_module(m, 2)
+    m = m.to(DEV).eval()
+    b = make_batch("AiR", 2, 240, 320, T, seed=2)
+    img, att = b["images"].to(DEV), b["attention_maps"].to(DEV)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(img, att)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(img, att)
+    base = make_batch("AiR", 2, 240, 320, T, seed=7)["images"].to(DEV)
+    seen = []
+    for amp in (1.0, 100.0, 0.01):
+        img.copy_(base * amp)
+        g.replay()
+        torch.cuda.synchronize()
+        got = {k: v.clone() for k, v in out.items()}
+        with torch.no_grad():
+            ref = m(img, att)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (amp, k)
+        seen.append(got["good_all_actions_prob"])
+    assert not torch.equal(seen[0], seen[1])
+
+
 def test_full_size_eval_is_independent_of_batch_mates_and_normalised():
     """BASELINE.json config 5 shape (AiR eval, 320x512, per-GPU batch 32; 2 decode steps keep it short): size-independent
     properties instead of a golden file --

@@ -5,12 +5,16 @@
   * against the oracle (oracle/scanpath_oracle.py, fp64 on the host CPU) at 320x512, the size BASELINE.json names and
     the reference itself cannot run (map size hard-coded).
 
-Tolerance (north_star: 1e-4 fp32 on logits, bit-exact argmax): the reference's OWN fp32 run differs from its fp64
-run by the "noise floor" stored beside each golden (up to 8e-4 on train-mode logits, SURVEY.md §7 hard part 2), so
-the bar is, per decode step,   err(hip32, ref64) <= max(1e-4 * scale, NOISE_X * err(ref32, ref64))   (NOISE_X = 20, see _check)
-(the recurrence amplifies rounding noise: with random weights the reference's fp32 run drifts from its fp64 run by
-O(1) after ~10 eval-mode steps, so only the early steps carry a tight bar -- that is the reference's property).
-Argmax must match wherever the fp64 top-2 margin exceeds that error bar."""
+Two weight families (scanpaths_amd/procedural.py):
+  * "tame"    -- non-chaotic recurrence; the reference's own fp32 run stays ~1e-5 of scale from its fp64 run over ALL decode
+                 steps.  Bar, EVERY step, EVERY GEMM back-end:  err(hip32, ref64) <= max(1e-4 * scale, 5 * err(ref32, ref64))
+                 (north_star: 1e-4 fp32 on logits) and the argmax fixation index exact at every (b, t) whose fp64 top-2 margin
+                 exceeds twice that bar (the reference's own fp32 run cannot resolve less).  test_tame_* below; the per-step
+                 numbers are written to gpurun_out/parity/r02_parity_errors.json (committed copy: profiles/).
+  * "default" -- round-1 goldens; eval-mode BN does not normalise, the decoder gates saturate and the recurrence is chaotic
+                 (the reference's fp32 run leaves its fp64 run by 1 % after ~3 steps).  Bar per step
+                 max(1e-4 * scale, NOISE_X * running max of err(ref32, ref64)), compared while the reference's own drift is
+                 below 1 %; these cases exercise saturated gates, ReLU kinks and the loss / gradient / Adam goldens."""
 import math
 import os
 
@@ -28,11 +32,41 @@ def _build(meta, Hm=30, Wm=40):
     from scanpaths_amd.models.scanpath_model import ScanpathModel
     from scanpaths_amd.procedural import fill_module
     m = ScanpathModel(meta["task"], convLSTM_length=meta["T"], map_width=Wm, map_height=Hm, arch=meta["arch"])
-    fill_module(m, seed=meta["weight_seed"])
+    fill_module(m, seed=meta["weight_seed"], family=meta.get("weight_family", "default"))
     return m.to(DEV)
 
 
-NOISE_X = 20.0      # see _check
+NOISE_X = 10.0      # chaotic "default" cases, see _check
+TAME_X = 5.0        # "tame" cases: the north-star bar
+BACKENDS = ["f16x2", "bf16x3", "fp32"]
+
+
+@pytest.fixture
+def backend(request):
+    """select the GEMM back-end of scanpaths_amd.functional for one test: 2xfp16 split (default build), 3xbf16 split, fp32 MFMA"""
+    from scanpaths_amd import functional as F
+    saved = (F.USE_BF16X3, F.SPLIT_SCHEME)
+    name = request.param
+    F.USE_BF16X3, F.SPLIT_SCHEME = (False, saved[1]) if name == "fp32" else (True, name)
+    yield name
+    F.USE_BF16X3, F.SPLIT_SCHEME = saved
+
+
+def _record(rows):
+    """append per-step parity numbers to gpurun_out/parity/r02_parity_errors.json (merged back by gpurun; committed under profiles/)"""
+    import json
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "parity")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "r02_parity_errors.json")
+        old = json.load(open(path)) if os.path.exists(path) else []
+        keyf = lambda r: (r["case"], r["backend"], r["key"], r["step"])
+        have = {keyf(r): r for r in old}
+        for r in rows:
+            have[keyf(r)] = r
+        json.dump(sorted(have.values(), key=keyf), open(path, "w"), indent=0)
+    except OSError:
+        pass
 
 
 def _call(model, meta, b):
@@ -61,15 +95,14 @@ def _informative_steps(g, keys, T):
     return tmax
 
 
-def _check(name, key, got, g, report, T=None, tmax=None):
+def _check(name, key, got, g, report, T=None, tmax=None, noise_x=None, rows=None, backend="f16x2"):
     """err(hip, ref64) <= max(1e-4*scale, NOISE_X * running-max of the reference's own fp32-vs-fp64 error), per decode step.
     Returns {step: bar} for the steps that were compared.
 
-    Why a multiple of the reference's fp32 noise: the decoder is a chaotic recurrence under random weights (the reference's own
-    fp32 run leaves 1e-4 of its fp64 run after 2-3 steps), so per-step errors are one random draw of amplified rounding noise.
-    The three independent HIP GEMM back-ends (fp32 MFMA, 3xbf16 split, 2xfp16 split) -- each at or below the GEMM error of the
-    CPU fp32 path, tests/test_ops_gpu.py::test_split_gemms_are_as_accurate_as_cpu_fp32 -- land between 1x and 16x of the single
-    ref32 draw on the same case (osie_r18_eval_T8 step 1: 2.0x, 2.9x, 6.5x), hence 20x."""
+    Why a multiple of the reference's fp32 noise on the chaotic "default" cases: the decoder is a chaotic recurrence under those
+    weights (the reference's own fp32 run leaves 1e-4 of its fp64 run after 2-3 steps), so a per-step error is ONE random draw of
+    amplified rounding noise and so is the reference's own fp32 error it is compared with.  The "tame" cases (noise_x = TAME_X = 5)
+    carry the north-star bar on every step."""
     ref = torch.as_tensor(g["ref64/" + key])
     r32 = torch.as_tensor(g["ref32/" + key])
     got = got.detach().cpu().double()
@@ -89,10 +122,16 @@ def _check(name, key, got, g, report, T=None, tmax=None):
             report.append(f"{name}:{key}[t={t}]: reference fp32 noise {floor_run:.2e} > 1% of scale -- later steps not compared")
             break
         err = max_err(got[sl], ref[sl])
-        bar = max(1e-4 * scale, NOISE_X * floor_run)
+        bar = max(1e-4 * scale, (NOISE_X if noise_x is None else noise_x) * floor_run)
+        if rows is not None:
+            rows.append({"case": name, "backend": backend, "key": key, "step": -1 if t is None else int(t), "err": err,
+                         "ref32_noise": floor_run, "scale": scale, "bar": bar, "err_over_ref32": err / max(floor_run, 1e-300)})
         line = f"{name}:{key}[t={t}]: hip-ref64 {err:.2e}  ref32-ref64(run max) {floor_run:.2e}  scale {scale:.2e}  bar {bar:.2e}"
         report.append(line)
-        assert err <= bar, line
+        if rows is None:
+            assert err <= bar, line
+        elif err > bar:                  # recording mode: the caller asserts after the table has been written
+            rows[-1]["failed"] = True
         bars[t] = bar
     return bars
 
@@ -118,18 +157,63 @@ def test_eval_forward_matches_reference(name):
     model = _build(meta).eval()
     with torch.no_grad():
         pred = _call(model, meta, b)
-    report = []
+    report, rows = [], []
     tmax = _informative_steps(g, list(pred.keys()), meta["T"])
     report.append(f"{name}: comparing the first {tmax} of {meta['T']} decode steps")
     for k, v in pred.items():
-        bars = _check(name, k, v, g, report, meta["T"], tmax)
+        bars = _check(name, k, v, g, report, meta["T"], tmax, rows=rows)
         if k.endswith("all_actions_prob"):
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
+    _record(rows)
     print("\n".join(report))
+    bad = [r for r in rows if r.get("failed")]
+    assert not bad, bad[:3]
 
 
-@pytest.mark.parametrize("name", ["air_train_T4", "osie_r18_train_T8", "coco_train_T6"])
+TAME_EVAL = ["air_tame_eval_T16", "coco_tame_eval_T6", "osie_r18_tame_eval_T8"]
+TAME_TRAIN = ["air_tame_train_T16", "coco_tame_train_T6", "osie_r18_tame_train_T8"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS, indirect=True)
+@pytest.mark.parametrize("name", TAME_EVAL + TAME_TRAIN)
+def test_tame_all_steps_meet_the_north_star_bar(name, backend):
+    """north_star: "within 1e-4 fp32 for logits and bit-exact for argmax fixation indices" -- on the non-chaotic weight family
+    EVERY decode step of EVERY output is compared (16/16 for AiR), for each of the three GEMM back-ends:
+        err(hip, ref64) <= max(1e-4 * scale, 5 * running max err(ref32, ref64))
+    and the argmax fixation index is exact at every (b, t) whose fp64 top-2 margin exceeds 2x that bar.  AiR/models/
+    baseline_attention.py:303-336 (train loop), :385-493 (inference)."""
+    meta, g = load_golden(name)
+    assert meta["weight_family"] == "tame"
+    b = case_inputs(meta, torch.float32)
+    train = meta["mode"] == "train"
+    model = _build(meta)
+    model.train(train)
+    with torch.no_grad():
+        pred = _call(model, meta, b)
+    report, rows = [], []
+    T = meta["T"]
+    nargmax = ntot = nfull = 0
+    for k, v in pred.items():
+        bars = _check(name, k, v, g, report, T, None, noise_x=TAME_X, rows=rows, backend=backend)
+        assert len(bars) == T, (k, len(bars))          # no step was skipped as "chaotic"
+        if k.endswith("all_actions_prob") or k == "actions":
+            n, tot = _check_argmax(v, g["ref64/" + k], bars)
+            nargmax, ntot = nargmax + n, ntot + tot
+            nfull += int((v.detach().cpu().argmax(-1) == torch.as_tensor(g["ref64/" + k]).argmax(-1)).sum())
+    for r in rows:
+        r["argmax_exact_decisive"], r["argmax_positions"], r["argmax_exact_all"] = nargmax, ntot, nfull
+    _record(rows)
+    worst = max(rows, key=lambda r: r["err"] / r["bar"])
+    print(f"{name} [{backend}]: {len(rows)} (output, step) pairs within the bar; worst err/bar {worst['err'] / worst['bar']:.2f} "
+          f"({worst['key']} t={worst['step']}: err {worst['err']:.2e}, ref32 noise {worst['ref32_noise']:.2e}, scale {worst['scale']:.2e}); "
+          f"argmax exact on {nargmax}/{ntot} decisive positions, {nfull}/{ntot} of all")
+    bad = [r for r in rows if r.get("failed")]
+    assert not bad, bad[:3]
+    assert nargmax >= 0.5 * ntot, (nargmax, ntot)      # the argmax check must not be vacuous
+
+
+@pytest.mark.parametrize("name", ["air_train_T4", "osie_r18_train_T8", "coco_train_T6", "air_tame_train_T16"])
 def test_train_step_matches_reference(name):
     from scanpaths_amd.models.loss import supervised_loss
     from scanpaths_amd.optim import FlatAdam
@@ -141,9 +225,10 @@ def test_train_step_matches_reference(name):
     opt.zero_grad()
     pred = _call(model, meta, b)
     report = []
+    tame = meta.get("weight_family") == "tame"
     tmax = _informative_steps(g, list(pred.keys()), meta["T"])
     for k, v in pred.items():
-        bars = _check(name, k, v, g, report, meta["T"], tmax)
+        bars = _check(name, k, v, g, report, meta["T"], tmax, noise_x=TAME_X if tame else None)
         if k in ("all_actions_prob", "actions"):
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
@@ -306,7 +391,7 @@ def test_state_dict_roundtrip_and_no_cpu_path():
 
 
 def test_full_size_train_step_is_reproducible_and_finite():
-    """BASELINE.json config 2 shape (AiR train step, 320x512, per-GPU batch 32; 4 decode steps keep it short): two steps from the
+    """BASELINE.json config 2 EXACTLY (AiR train step, 320x512, per-GPU batch 32, T = 16 decode steps): two steps from the
     same initial state give BIT-IDENTICAL losses, gradient norms and parameters (every reduction in the path has a fixed order,
     split-K / split-pixel slabs are reduced in order, no float atomics), the clipped update respects the clip norm, and one
     more step lowers nothing to NaN/Inf."""
@@ -315,7 +400,7 @@ def test_full_size_train_step_is_reproducible_and_finite():
     from scanpaths_amd.optim import FlatAdam
     from scanpaths_amd.procedural import fill_module
     from scanpaths_amd.synth import make_batch
-    T = 4
+    T = 16
     b = {k: v.to(DEV) for k, v in make_batch("AiR", 32, 320, 512, T, seed=11).items()}
 
     def run():

@@ -567,3 +567,81 @@ def test_c_abi_error_codes():
         hip.check(-1, "demo")
     with pytest.raises(hip.HipError):
         hip.ptr(torch.zeros(4))                                                            # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize("path", ["f16x2", "bf16x3", "fp32_mfma"])
+def test_hgate_conv_at_benchmark_size_vs_fp64(path, monkeypatch):
+    """The dominant GEMM of the bench line AT ITS SIZE (BASELINE.json config 2: bs 32, 40x64 map): h-gate conv 3x3 512->2048,
+    implicit GEMM M = 81 920, N = 2048, K = 4608 -- forward, data gradient and weight gradient of every back-end against a
+    row-/entry-subsampled fp64 reference on the host (AiR/models/baseline_attention.py:44-50 as hoisted in scanpath_model.py).
+    Bars (rms error relative to rms of the exact result; a CPU fp32 GEMM of such data sits at 2.4e-7 / 2.9e-7 / 8.4e-7,
+    DESIGN.md §5c): 1e-6 forward / data gradient, 2e-6 weight gradient (81 920-term sums); max error <= 8x the rms bar."""
+    import json
+    import os
+    from scanpaths_amd import functional as F
+    monkeypatch.setattr(F, "USE_BF16X3", path != "fp32_mfma")
+    monkeypatch.setattr(F, "SPLIT_SCHEME", path if path != "fp32_mfma" else "f16x2")
+    B, Hm, Wm, Ci, Co = 32, 40, 64, 512, 2048
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # decoder-shaped data: h = o * c in (-T, T) with many small entries, weights fan-in scaled, gate gradients heavy-tailed
+    h = (torch.randn(B, Hm, Wm, Ci, generator=g) * torch.rand(B, Hm, Wm, Ci, generator=g)).float()
+    w = (torch.randn(Co, 3, 3, Ci, generator=g) / math.sqrt(9 * Ci)).float()               # physical [Co][KH][KW][Ci]
+    dy = (torch.randn(B, Hm, Wm, Co, generator=g) * torch.rand(B, Hm, Wm, 1, generator=g) ** 4 * 1e-3).float()
+    hg = h.to(dev).requires_grad_(True)
+    wg = w.to(dev).permute(0, 3, 1, 2).requires_grad_(True)                               # logical OIHW, channels_last memory
+    y = F.conv2d(hg, wg, None, pad=1)
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    y_c, dx_c, dw_c = y.detach().cpu(), hg.grad.cpu(), wg.grad.permute(0, 2, 3, 1).contiguous().cpu()      # dw as [Co][KH][KW][Ci]
+
+    rs = np.random.Generator(np.random.PCG64(9))
+    pix = [(int(rs.integers(B)), int(rs.integers(Hm)), int(rs.integers(Wm))) for _ in range(96)]
+    pix += [(0, 0, 0), (B - 1, Hm - 1, Wm - 1), (3, 0, Wm - 1), (7, Hm - 1, 0)]            # zero-padding corners
+    hd, wd, dyd = h.double(), w.double(), dy.double()
+
+    def patch(src, b, yy, xx, sign):        # [3,3,C] window around (yy, xx) with zero padding; sign=-1 mirrors for the data gradient
+        out = torch.zeros(3, 3, src.shape[-1], dtype=torch.float64)
+        for ky in range(3):
+            for kx in range(3):
+                iy, ix = yy + sign * (ky - 1), xx + sign * (kx - 1)
+                if 0 <= iy < Hm and 0 <= ix < Wm:
+                    out[ky, kx] = src[b, iy, ix]
+        return out
+
+    res = {}
+    # forward: y[b,y,x,co] = sum_{ky,kx,ci} h[b,y+ky-1,x+kx-1,ci] w[co,ky,kx,ci]
+    ref = torch.stack([torch.einsum("yxc,oyxc->o", patch(hd, *p, 1), wd) for p in pix])
+    got = torch.stack([y_c[p] for p in pix]).double()
+    res["fwd"] = ((got - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item(),
+                  (got - ref).abs().max().item() / ref.pow(2).mean().sqrt().item())
+    # data gradient: dx[b,y,x,ci] = sum_{ky,kx,co} dy[b,y-(ky-1),x-(kx-1),co] w[co,ky,kx,ci]
+    ref = torch.stack([torch.einsum("yxo,oyxc->c", patch(dyd, *p, -1), wd) for p in pix])
+    got = torch.stack([dx_c[p] for p in pix]).double()
+    res["dgrad"] = ((got - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item(),
+                    (got - ref).abs().max().item() / ref.pow(2).mean().sqrt().item())
+    # weight gradient on a 48 x 48 block of (co, ci) for all 9 taps: dw[co,ky,kx,ci] = sum_p dy[p,co] h[p+(ky-1,kx-1),ci]
+    cos = torch.from_numpy(rs.choice(Co, 48, replace=False)).long()
+    cis = torch.from_numpy(rs.choice(Ci, 48, replace=False)).long()
+    dys = dyd[..., cos]                                                    # [B,Hm,Wm,48]
+    hp = torch.nn.functional.pad(hd[..., cis], (0, 0, 1, 1, 1, 1))         # zero-pad W and H by 1
+    ref = torch.empty(48, 3, 3, 48, dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            ref[:, ky, kx, :] = torch.einsum("bhwo,bhwc->oc", dys, hp[:, ky:ky + Hm, kx:kx + Wm])
+    got = dw_c[cos][..., cis].double()
+    res["wgrad"] = ((got - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item(),
+                    (got - ref).abs().max().item() / ref.pow(2).mean().sqrt().item())
+    print(f"h-gate conv M=81920 N=2048 K=4608 [{path}]: " + "  ".join(f"{k}: rms {v[0]:.2e} max {v[1]:.2e}" for k, v in res.items()))
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        d = os.path.join(root, "gpurun_out", "parity")
+        os.makedirs(d, exist_ok=True)
+        fn = os.path.join(d, "r02_hgate_fullsize_errors.json")
+        old = json.load(open(fn)) if os.path.exists(fn) else {}
+        old[path] = {k: {"rms_rel": v[0], "max_rel": v[1]} for k, v in res.items()}
+        json.dump(old, open(fn, "w"), indent=1)
+    except OSError:
+        pass
+    for k, bar in (("fwd", 1e-6), ("dgrad", 1e-6), ("wgrad", 2e-6)):
+        assert res[k][0] <= bar and res[k][1] <= 8 * bar, (path, k, res[k])
