@@ -119,6 +119,14 @@ int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xsplit, const float* 
 int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d);
 int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                         const float* y_scale, float* dW, void* workspace, void* stream);
+/* THROUGHPUT MODE (SURVEY.md §7 hard part 1 / BASELINE.md §4 "bf16-MFMA mode", reported separately from the fp32-faithful
+ * headline): the same kernels on the same split-2 operands with only the main product a1*b1, i.e. both operands rounded to ONE
+ * fp16 plane (per-tensor power-of-two scale), fp32 accumulation, a third of the MFMA work.  Does NOT meet the 1e-4 parity bar
+ * (relative GEMM error ~2^-11); never selected unless SP_SPLIT_SCHEME=f16x1. */
+int sp_conv_igemm_f16x1(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit, const float* w_scale,
+                        const float* bias, float* out, void* stream);
+int sp_conv_wgrad_f16x1(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
+                        const float* y_scale, float* dW, void* workspace, void* stream);
 
 
 /* column sums of a row-major [M][C] matrix (ld = row stride): out[c] = beta*out[c] + sum_m x[m][c]
@@ -351,6 +359,19 @@ int sp_sample_actions(const float* probs, const float* mu, const float* sigma2, 
                       uint64_t seed, int64_t* actions, float* action_probs, float* durations, void* stream);
 int sp_generate_scanpath(const int64_t* actions, const float* durations, int B, int T, int map_w, int map_h, int width, int height,
                          float* length, float* action_masks, float* duration_masks, float* fix, int* nfix, void* stream);
+/* Beam search of width K (<= 8) over the per-step action distributions probs [B][T][A] (eval-mode outputs) -- BASELINE.json
+ * config 5 "beam-4 scanpath sampling"; build-side decoder, the reference only samples (models/sampling.py:16-46).
+ * score = sum_t log p_t(a_t); action 0 (terminate) ends a sequence and is allowed from t >= min_length; actions [B][K][T]
+ * (0 after termination), scores [B][K] float64, best first.  T <= 64, A <= 32767. */
+int sp_beam_search(const float* probs, int B, int T, int A, int min_length, int K, int64_t* actions, double* scores, void* stream);
+/* Training targets of one batch from ragged fixation lists (AiR/dataset/dataset.py:111-147 with blur_sigma = None;
+ * collate_func :168-211 stacks them): sample b owns fixations start[b] .. start[b]+count[b]-1 of X / Y (pixels of the
+ * origin_w x origin_h image) / T_start / T_end (ms).  target [B][T][1 + map_h*map_w] soft one-hot (index 0 = terminate),
+ * duration [B][T] seconds, action_mask, duration_mask [B][T].  f64_div: evaluate the cell index in float64 (numpy 1.x) instead
+ * of float32 (numpy >= 2). */
+int sp_collate_targets(const float* X, const float* Y, const float* T_start, const float* T_end, const int64_t* start,
+                       const int* count, const double* origin_w, const double* origin_h, int B, int T, int map_h, int map_w,
+                       int f64_div, float* target, float* duration, float* action_mask, float* duration_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ + Adam (L2 folded into the gradient) over one flat fp32 buffer.  AiR/train.py:116-117,200-202.

@@ -68,7 +68,13 @@ struct H2Args {
 //      its matrix segment while its partner is in its LDS / DMA segment; waves 4-7 finish tile nkt-1 after the loop;
 //   3  = 2 with s_setprio 1 on waves 4-7 (the second-dispatched half loses VALU/issue arbitration otherwise).
 // All variants compute bit-identical results (same per-accumulator MFMA order, same fold points).
-template <int MODE, int DBG, int VAR>
+// NPROD: 3 = fp32-faithful (the two cross terms, then the main product); 1 = THROUGHPUT MODE: only the main product a1*b1, i.e.
+// both operands rounded to ONE fp16 plane (fp16 in / fp32 accumulate) -- same operand storage, a third of the MFMA work.
+// M16: issue v_mfma_f32_16x16x32_f16 (4x4 tiles of 16x16 per wave, one 32-k block per K-tile) instead of 32x32x16 (2x2 tiles,
+// two 16-k groups): same fragments-per-FLOP from LDS, same cycles per FLOP, but the chip holds a higher clock on this shape
+// under MFMA load (MI355X_MICROARCH.md "DVFS give-back" item 7).  Per-accumulator summation order differs from the 32x32 build
+// (a 32-k block per MFMA instead of 16), so results agree to rounding, not bitwise.
+template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -173,18 +179,27 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     };
 
     // fragment read offsets: row r, chunk c = kk*4 + plane*2 + h stored at position c ^ ((r>>1)&7)
-    const int rot = (l32 >> 1) & 7;
-    int offA[2][2], offB[2][2];      // [kk][plane]
+    //   32x32x16: lane = (row l32, k-half h) of 16-k group kk;   16x16x32: lane = (row l16, k-group g4 = 2*kk + h) of the 32-k block
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int rot = M16 ? ((l16 >> 1) & 7) : ((l32 >> 1) & 7);
+    int offA[2][2], offB[2][2];      // M32: [kk][plane];  M16: [0][plane] only (+ i * 16 rows)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            const int pos = (kk * 4 + pl * 2 + h) ^ rot;
-            offA[kk][pl] = (wm * 64 + l32) * 128 + pos * 16;
-            offB[kk][pl] = HA_BYTES + (wn * 64 + l32) * 128 + pos * 16;
+            if constexpr (M16) {
+                const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+                offA[kk][pl] = (wm * 64 + l16) * 128 + pos * 16;
+                offB[kk][pl] = HA_BYTES + (wn * 64 + l16) * 128 + pos * 16;
+            } else {
+                const int pos = (kk * 4 + pl * 2 + h) ^ rot;
+                offA[kk][pl] = (wm * 64 + l32) * 128 + pos * 16;
+                offB[kk][pl] = HA_BYTES + (wn * 64 + l32) * 128 + pos * 16;
+            }
         }
 
-    f32x16 tot[2][2], acc[2][2];
+    f32x16 tot[2][2], acc[2][2];         // M32 accumulators (unused registers are dropped by the compiler in the M16 build)
+    f32x4 tot4[4][4], acc4[4][4];        // M16 accumulators
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -193,6 +208,15 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             for (int r = 0; r < 16; ++r) {
                 tot[i][j][r] = 0.f;
                 acc[i][j][r] = 0.f;
+            }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                tot4[i][j][r] = 0.f;
+                acc4[i][j][r] = 0.f;
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
@@ -222,27 +246,53 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                         af[kk][i][pl] = z;
                         bf[kk][i][pl] = z;
                     }
+        } else if constexpr (M16) {
+            // af[kk][i][pl] holds row tile 2*kk + i (16 rows each) of the ONE 32-k block; bf likewise for column tiles
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
+                        af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[0][pl] + (2 * kk + i) * 16 * 128);
+                        bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[0][pl] + (2 * kk + i) * 16 * 128);
+                    }
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
+                    for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
                         af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
                         bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
                     }
         }
     };
     auto mma_group = [&](int kk) {
-        if constexpr (do_mma) {
+        if constexpr (do_mma && M16) {
+            // group kk = row tiles 2kk, 2kk+1 against all four column tiles (24 of the K-tile's 48 MFMAs)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4& a4 = acc4[2 * kk + i][j];
+                    if constexpr (NPROD == 3) {
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                    }
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                }
+        } else if constexpr (do_mma) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     // three products, the two cross terms (~2^-11 of the main one) first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                    if constexpr (NPROD == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
                 }
         } else {
@@ -256,6 +306,19 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
     };
     auto fold = [&](int kt_) {           // two-level accumulation: fold the chunk accumulator into the total every 256 k
+        if constexpr (M16) {
+            if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tot4[i][j] += acc4[i][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
+                    }
+            }
+            return;
+        }
         if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -330,6 +393,29 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
     const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
+    if constexpr (M16) {
+        // C/D layout of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l16;
+            if (n >= p.Nout) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                    if (m < p.M) {
+                        float* dst = p.C + m * p.ldc + n;
+                        float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
+                        if (p.beta) v += *dst;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        *dst = v;
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l32;
@@ -393,7 +479,7 @@ __device__ __forceinline__ int rot4(int q) { return 2 * (q & 1) + 8 * (q >> 1); 
 
 // VAR: schedule of the two waves sharing a SIMD, as h2_kernel: 0 lockstep (round 1), 2 ping-pong with one barrier per K-tile
 // (waves 0-3: [issue loads(t+2)] [read(t)] [24 MFMA(t)]; waves 4-7: [24 MFMA(t-1)] [read(t)] [issue loads(t+2)]), 3 = 2 + s_setprio.
-template <int VAR>
+template <int VAR, int NPROD = 3>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -519,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
+            for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
                 af[kk][i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
                 bf[kk][i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
             }
@@ -529,8 +615,10 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                if constexpr (NPROD == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
             }
     };
@@ -741,9 +829,9 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
-template <int MODE, int DBG, int VAR>
+template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false>
 int launch_h2(const H2Args& a, hipStream_t s) {
-    auto kern = h2_kernel<MODE, DBG, VAR>;
+    auto kern = h2_kernel<MODE, DBG, VAR, NPROD, M16>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HSTAGE);
@@ -756,9 +844,9 @@ int launch_h2(const H2Args& a, hipStream_t s) {
     return SP_OK;
 }
 
-template <int VAR>
+template <int VAR, int NPROD = 3>
 int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
-    auto kern = hw_kernel<VAR>;
+    auto kern = hw_kernel<VAR, NPROD>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HWSTAGE);
@@ -813,8 +901,8 @@ extern "C" int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* 
     return SP_OK;
 }
 
-extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
-                                   const float* w_scale, const float* bias, float* out, void* stream) {
+static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws, const float* w_scale,
+                          const float* bias, float* out, void* stream, int nprod) {
     if (!d || !Xs || !Ws || !x_scale || !w_scale || !out) return SP_ENULL;
     if (d->mode != 0 && d->mode != 1) return SP_EINVAL;
     if (d->Kc % 32 || d->ldx != d->Kc) return SP_EINVAL;      // a 32-k K-tile must lie inside one filter tap
@@ -842,12 +930,28 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
     if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
     if (dbg == 2) return f ? launch_h2<0, 2, 0>(a, st) : launch_h2<1, 2, 0>(a, st);
     if (dbg == 3) return f ? launch_h2<0, 3, 0>(a, st) : launch_h2<1, 3, 0>(a, st);
+    if (nprod == 1)      // throughput mode: load-bound, the ping-pong schedule
+        return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
     switch (sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT)) {
         case 0: return f ? launch_h2<0, 0, 0>(a, st) : launch_h2<1, 0, 0>(a, st);
         case 1: return f ? launch_h2<0, 0, 1>(a, st) : launch_h2<1, 0, 1>(a, st);
         case 2: return f ? launch_h2<0, 0, 2>(a, st) : launch_h2<1, 0, 2>(a, st);
-        default: return f ? launch_h2<0, 0, 3>(a, st) : launch_h2<1, 0, 3>(a, st);
+        case 3: return f ? launch_h2<0, 0, 3>(a, st) : launch_h2<1, 0, 3>(a, st);
+        case 4: return f ? launch_h2<0, 0, 0, 3, true>(a, st) : launch_h2<1, 0, 0, 3, true>(a, st);      // 16x16x32, lockstep
+        case 5: return f ? launch_h2<0, 0, 1, 3, true>(a, st) : launch_h2<1, 0, 1, 3, true>(a, st);      // 16x16x32, half stagger
+        case 6: return f ? launch_h2<0, 0, 2, 3, true>(a, st) : launch_h2<1, 0, 2, 3, true>(a, st);      // 16x16x32, ping-pong
+        default: return f ? launch_h2<0, 0, 3, 3, true>(a, st) : launch_h2<1, 0, 3, 3, true>(a, st);
     }
+}
+
+extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
+                                   const float* w_scale, const float* bias, float* out, void* stream) {
+    return conv_igemm_f16(d, Xs, x_scale, Ws, w_scale, bias, out, stream, 3);
+}
+
+extern "C" int sp_conv_igemm_f16x1(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
+                                   const float* w_scale, const float* bias, float* out, void* stream) {
+    return conv_igemm_f16(d, Xs, x_scale, Ws, w_scale, bias, out, stream, 1);
 }
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
@@ -856,8 +960,8 @@ extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
     return sp <= 1 ? 0 : (int64_t)sp * d->Co * d->ldo * (int64_t)sizeof(float);
 }
 
-extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
-                                   const float* y_scale, float* dW, void* workspace, void* stream) {
+static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
+                          const float* y_scale, float* dW, void* workspace, void* stream, int nprod) {
     if (!d || !Xsplit || !dYsplit || !x_scale || !y_scale || !dW) return SP_ENULL;
     if (d->Ci % 16 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
     if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
@@ -882,7 +986,8 @@ extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, c
     a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
+    if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);
+    else switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
         case 0: rc = launch_hw<0>(a, d->Co, s); break;
         case 2: rc = launch_hw<2>(a, d->Co, s); break;
         default: rc = launch_hw<3>(a, d->Co, s); break;
@@ -896,4 +1001,14 @@ extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, c
         SP_LAUNCH_CHECK();
     }
     return SP_OK;
+}
+
+extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
+                                   const float* y_scale, float* dW, void* workspace, void* stream) {
+    return conv_wgrad_f16(d, Xsplit, x_scale, dYsplit, y_scale, dW, workspace, stream, 3);
+}
+
+extern "C" int sp_conv_wgrad_f16x1(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
+                                   const float* y_scale, float* dW, void* workspace, void* stream) {
+    return conv_wgrad_f16(d, Xsplit, x_scale, dYsplit, y_scale, dW, workspace, stream, 1);
 }

@@ -112,7 +112,182 @@ __global__ void scanpath_kernel(const int64_t* actions, const float* durations, 
     nfix[b] = n;
 }
 
+// ---- beam search over the per-step action distributions (BASELINE.json config 5: "beam-4 scanpath sampling") -------------
+// The reference only samples (models/sampling.py:16-46); beam search is a build-side decoder over the SAME eval-mode outputs.
+// The per-step distributions do not depend on earlier choices (the decoder is not conditioned on sampled actions), so the K
+// best sequences under  score = sum_t log p_t(a_t)  with "terminate (action 0) ends the sequence, allowed from t >= min_length"
+// are found exactly by a width-K beam: at step t every live beam is extended by the step's K most probable allowed actions,
+// finished beams compete with their final score, the best K survive.  Ties: higher score, then the earlier candidate in the
+// order (beam 0..K-1; finished beam itself, else actions by descending probability then ascending index).
+// One 256-thread block per sample.  Scores are accumulated in float64.
+constexpr int BEAM_MAX = 8;
+
+__global__ __launch_bounds__(256) void beam_kernel(const float* __restrict__ probs, int T, int A, int min_length, int K,
+                                                   int64_t* __restrict__ actions /* [B][K][T] */, double* __restrict__ scores) {
+    __shared__ float tv[BEAM_MAX];
+    __shared__ int ti[BEAM_MAX];
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    __shared__ double bscore[BEAM_MAX];
+    __shared__ int bdone[BEAM_MAX];
+    __shared__ int nlive;
+    __shared__ int16_t seq[2][BEAM_MAX][64];                 // T <= 64
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* P = probs + (int64_t)b * T * A;
+    if (tid == 0) {
+        nlive = 1;                                           // one empty beam
+        bscore[0] = 0.0;
+        bdone[0] = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        const float* p = P + (int64_t)t * A;
+        const int a_lo = t < min_length ? 1 : 0;
+        // K rounds of block arg-max (largest probability, lowest index on ties), skipping the already chosen entries
+        for (int k = 0; k < K; ++k) {
+            float bv = -1.f;
+            int bi = 0x7fffffff;
+            for (int a = a_lo + tid; a < A; a += 256) {
+                bool used = false;
+                for (int q = 0; q < k; ++q) used |= (ti[q] == a);
+                const float v = p[a];
+                if (!used && (v > bv || (v == bv && a < bi))) { bv = v; bi = a; }
+            }
+            rv[tid] = bv;
+            ri[tid] = bi;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) {
+                    const float v2 = rv[tid + o];
+                    const int i2 = ri[tid + o];
+                    if (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid])) { rv[tid] = v2; ri[tid] = i2; }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) { tv[k] = rv[0]; ti[k] = ri[0]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            // candidates in tie-break order
+            double cs[BEAM_MAX * (BEAM_MAX + 1)];
+            int cb[BEAM_MAX * (BEAM_MAX + 1)], ca[BEAM_MAX * (BEAM_MAX + 1)];
+            int nc = 0;
+            for (int q = 0; q < nlive; ++q) {
+                if (bdone[q]) { cs[nc] = bscore[q]; cb[nc] = q; ca[nc] = -1; ++nc; continue; }
+                for (int k = 0; k < K; ++k) {
+                    if (ti[k] == 0x7fffffff || !(tv[k] > 0.f)) continue;          // fewer than K positive entries
+                    cs[nc] = bscore[q] + log((double)tv[k]);
+                    cb[nc] = q;
+                    ca[nc] = ti[k];
+                    ++nc;
+                }
+            }
+            const int nxt = cur ^ 1;
+            int taken[BEAM_MAX];
+            int nn = 0;
+            for (; nn < K && nn < nc; ++nn) {
+                int best = -1;
+                for (int c = 0; c < nc; ++c) {
+                    bool used = false;
+                    for (int q = 0; q < nn; ++q) used |= (taken[q] == c);
+                    if (!used && (best < 0 || cs[c] > cs[best])) best = c;
+                }
+                taken[nn] = best;
+            }
+            double ns[BEAM_MAX];
+            int nd[BEAM_MAX];
+            for (int q = 0; q < nn; ++q) {
+                const int c = taken[q];
+                for (int u = 0; u < t; ++u) seq[nxt][q][u] = seq[cur][cb[c]][u];
+                if (ca[c] < 0) {                                  // finished earlier: stays finished, padded with terminate
+                    seq[nxt][q][t] = 0;
+                    nd[q] = 1;
+                } else {
+                    seq[nxt][q][t] = (int16_t)ca[c];
+                    nd[q] = ca[c] == 0;
+                }
+                ns[q] = cs[c];
+            }
+            for (int q = 0; q < nn; ++q) { bscore[q] = ns[q]; bdone[q] = nd[q]; }
+            nlive = nn;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int i = tid; i < K * T; i += 256) {
+        const int q = i / T, t = i % T;
+        actions[((int64_t)b * K + q) * T + t] = q < nlive ? (int64_t)seq[cur][q][t] : 0;
+    }
+    if (tid < K) scores[(int64_t)b * K + tid] = tid < nlive ? bscore[tid] : -INFINITY;
+}
+
+// ---- dataset targets (AiR/dataset/dataset.py:111-147, blur_sigma = None): ragged fixations -> soft one-hot targets, masks ----
+// one thread per (sample, step).  Arithmetic as numpy >= 2 evaluates the reference's expressions (float32 scalars with weak
+// python floats): cell = int32(float32(x) / float32(origin / map)), duration = (float32(T_end) - float32(T_start)) / 1000f.
+// f64_div = 1 evaluates the cell divisions in float64 instead (what numpy 1.x -- the reference's pinned environment -- does).
+__global__ void collate_kernel(const float* X, const float* Y, const float* Ts, const float* Te, const int64_t* start,
+                               const int* count, const double* origin_w, const double* origin_h, int B, int T, int map_h, int map_w,
+                               int f64_div, float* target /* [B][T][1+map_h*map_w], pre-zeroed */, float* duration, float* amask,
+                               float* dmask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i % T;
+    const int n = min(count[b], T);
+    const int A = 1 + map_h * map_w;
+    float d = 0.f, am = 0.f, dm = 0.f;
+    int px = -1, py = -1;
+    if (t < n) {
+        const int64_t s = start[b] + t;
+        const double dsx = origin_w[b] / (double)map_w, dsy = origin_h[b] / (double)map_h;
+        if (f64_div) {
+            px = (int)((double)X[s] / dsx);
+            py = (int)((double)Y[s] / dsy);
+        } else {
+            px = (int)(X[s] / (float)dsx);
+            py = (int)(Y[s] / (float)dsy);
+        }
+        d = (Te[s] - Ts[s]) / 1000.0f;
+        am = 1.f;
+        dm = 1.f;
+    } else if (t == n) {
+        am = 1.f;                                           // the step after the last fixation (:136-137)
+    }
+    duration[i] = d;
+    amask[i] = am;
+    dmask[i] = dm;
+    float* row = target + (int64_t)i * A;
+    if (px == -1 || py == -1) row[0] = 1.f;                  // terminate target (:141-142)
+    else row[1 + py * map_w + px] = 1.f;                     // (:144-147); indices outside the map are the caller's error there too
+}
+
 }  // namespace
+
+extern "C" int sp_beam_search(const float* probs, int B, int T, int A, int min_length, int K, int64_t* actions, double* scores,
+                              void* stream) {
+    if (!probs || !actions || !scores) return SP_ENULL;
+    if (B < 1 || T < 1 || T > 64 || A < 2 || A > 32767 || K < 1 || K > BEAM_MAX) return SP_EINVAL;
+    hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, T, A, min_length, K, actions, scores);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_collate_targets(const float* X, const float* Y, const float* T_start, const float* T_end, const int64_t* start,
+                                  const int* count, const double* origin_w, const double* origin_h, int B, int T, int map_h,
+                                  int map_w, int f64_div, float* target, float* duration, float* action_mask,
+                                  float* duration_mask, void* stream) {
+    if (!X || !Y || !T_start || !T_end || !start || !count || !origin_w || !origin_h || !target || !duration || !action_mask ||
+        !duration_mask)
+        return SP_ENULL;
+    if (B < 1 || T < 1 || map_h < 1 || map_w < 1) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(target, 0, sizeof(float) * (size_t)B * T * (1 + (size_t)map_h * map_w), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(collate_kernel, dim3((B * T + 127) / 128), dim3(128), 0, s, X, Y, T_start, T_end, start, count, origin_w,
+                       origin_h, B, T, map_h, map_w, f64_div, target, duration, action_mask, duration_mask);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
 
 extern "C" int sp_sample_actions(const float* probs, const float* mu, const float* sigma2, int B, int T, int A, int min_length,
                                  uint64_t seed, int64_t* actions, float* action_probs, float* durations, void* stream) {

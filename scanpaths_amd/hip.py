@@ -48,6 +48,8 @@ SIGNATURES = {
     "sp_conv_igemm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x2_workspace": (_L, [_P]),
     "sp_conv_wgrad_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_conv_igemm_f16x1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_conv_wgrad_f16x1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_igemm_bf16x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_bf16x3_workspace": (_L, [C.POINTER(WgradDesc)]),
     "sp_conv_wgrad_bf16x3": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),
@@ -108,6 +110,8 @@ SIGNATURES = {
     "sp_scan_sed_stde": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),
     "sp_sample_actions": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_uint64, _P, _P, _P, _P]),
     "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "sp_beam_search": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_collate_targets": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sp_scanpath_loss_workspace": (_L, [_I, _I]),
     "sp_scanpath_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sp_log_action": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),

@@ -73,3 +73,21 @@ class Sampling():
             fv["start_x"], fv["start_y"], fv["duration"] = fix_h[b, :n_h[b], 0], fix_h[b, :n_h[b], 1], fix_h[b, :n_h[b], 2]
             out.append(fv)
         return out, am.to(images.dtype), dm.to(images.dtype)
+
+    def beam_search(self, all_actions_prob, log_normal_mu, log_normal_sigma2, beam=4):
+        """BASELINE.json config 5 ("beam-4 scanpath sampling"); build-side decoder, the reference only samples (:16-46).
+        The ``beam`` most probable action sequences per sample under sum_t log p_t(a_t) (terminate ends a sequence, allowed
+        from t >= min_length) by csrc/sampling.hip ``beam_kernel``; durations are the medians of the predicted log-normals,
+        exp(mu) (random_sample's exp(eps*sigma2 + mu) at eps = 0).  Returns {"selected_actions" [B,beam,T] int64,
+        "scores" [B,beam] float64 (log-probability, best first), "durations" [B,beam,T], "scanpath_length" [B,beam]}; feed
+        ``selected_actions[:, k]`` / ``durations[:, k]`` to ``generate_scanpath`` for fixation vectors."""
+        probs = all_actions_prob.detach().contiguous().float()
+        B, T, A = probs.shape
+        dev = probs.device
+        actions = torch.empty((B, beam, T), dtype=torch.int64, device=dev)
+        scores = torch.empty((B, beam), dtype=torch.float64, device=dev)
+        check(hip.lib().sp_beam_search(ptr(probs), B, T, A, int(self.min_length), int(beam), ptr(actions), ptr(scores),
+                                       hip.stream()), "sp_beam_search")
+        dur = torch.exp(log_normal_mu.detach().float()).unsqueeze(1).expand(B, beam, T).contiguous()
+        length, _, _, _, _ = self._scan(actions.view(B * beam, T), dur.view(B * beam, T))
+        return {"selected_actions": actions, "scores": scores, "durations": dur, "scanpath_length": length.view(B, beam)}

@@ -1,0 +1,170 @@
+"""SURVEY.md §8 "next" rows on the device: dataset targets (f4), beam search + the test loop (f1), validation metrics (f2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+_FV = {"names": ("start_x", "start_y", "duration"), "formats": ("f8", "f8", "f8")}
+
+
+def test_collate_targets_match_reference_collate_func():
+    """HIP collate kernel vs the reference's AiR.__getitem__ + collate_func outputs (tests/golden/collate.npz): bit-exact"""
+    from scanpaths_amd.dataset import collate_targets
+    g = np.load(os.path.join(GOLDEN, "collate.npz"))
+    recs = json.loads(bytes(g["records"]).decode())
+    out = collate_targets(recs, 16, (30, 40))
+    for k in ("scanpaths", "durations", "action_masks", "duration_masks"):
+        assert np.array_equal(out[k].cpu().numpy(), g[k]), k
+    # numpy-1.x (float64 division) semantics vs the oracle restatement, on cell-boundary-rich inputs at 320x512 -> 40x64
+    from oracle import sampling_oracle as SO
+    rng = np.random.Generator(np.random.PCG64(2))
+    recs2 = [{"X": list((rng.integers(0, 64, 12) * 8.0).astype(float)), "Y": list((rng.integers(0, 40, 12) * 8.0).astype(float)),
+              "T_start": list(np.arange(12) * 100.0), "T_end": list(np.arange(12) * 100.0 + 77.0), "height": 320, "width": 512}
+             for _ in range(5)]
+    for f64 in (False, True):
+        got = collate_targets(recs2, 16, (40, 64), f64_div=f64)
+        want = SO.collate_targets(recs2, 16, (40, 64), f64_div=f64)
+        for k, w in zip(("scanpaths", "durations", "action_masks", "duration_masks"), want):
+            assert np.array_equal(got[k].cpu().numpy(), w), (k, f64)
+
+
+def test_collate_func_keys_and_performance_rule():
+    from scanpaths_amd.dataset import collate_func, normalise_attention
+    g = np.load(os.path.join(GOLDEN, "collate.npz"))
+    recs = json.loads(bytes(g["records"]).decode())
+    samples = [{"image": torch.zeros(3, 8, 8), "fixation": r, "attention_map": np.full((1, 30, 40), 0.5, np.float32),
+                "img_name": r["image_id"], "question_id": r["question_id"]} for r in recs]
+    data = collate_func(samples, 16, (30, 40))
+    assert set(data) == {"images", "scanpaths", "durations", "action_masks", "duration_masks", "attention_maps", "img_names",
+                         "question_ids", "performances"}
+    assert np.array_equal(data["performances"].cpu().numpy(), g["performances"])
+    att = torch.rand(3, 1, 30, 40, device=DEV) * 7
+    n = normalise_attention(att)
+    assert torch.allclose(n.flatten(1).max(1).values, torch.ones(3, device=DEV))
+
+
+def test_beam_search_matches_oracle_and_is_optimal():
+    """HIP beam kernel == the numpy restatement (itself exhaustively checked on small cases, tests/test_sampling_oracle.py);
+    at the bs-128 / 320x512 inference shape: beam 0 is the greedy path, scores are sorted, sequences distinct."""
+    from oracle import sampling_oracle as SO
+    from scanpaths_amd.models.sampling import Sampling
+    rng = np.random.Generator(np.random.PCG64(6))
+    B, T, A, K = 6, 16, 1201, 4
+    p = rng.random((B, T, A)).astype(np.float32) ** 8
+    p[0, 3, 0] = 50.0                  # an early terminate
+    p[1, :, 5] = 0.0                   # exact zeros
+    p[2, 7, 10] = p[2, 7, 20] = p[2, 7].max() * 2     # an exact tie between two actions
+    p /= p.sum(-1, keepdims=True)
+    probs = torch.from_numpy(p).to(DEV)
+    mu = torch.zeros(B, T, device=DEV)
+    for ml in (1, 2):
+        s = Sampling(convLSTM_length=T, min_length=ml)
+        out = s.beam_search(probs, mu, mu + 1, beam=K)
+        acts, scores = out["selected_actions"].cpu().numpy(), out["scores"].cpu().numpy()
+        for b in range(B):
+            wa, ws = SO.beam_search(p[b], ml, K)
+            assert np.array_equal(acts[b], wa), (ml, b)
+            assert np.allclose(scores[b], ws, rtol=0, atol=1e-9)
+        assert torch.equal(out["durations"], torch.ones(B, K, T, device=DEV))          # exp(mu) with mu = 0
+    # full inference shape
+    B, T, A = 128, 16, 1 + 40 * 64
+    probs = torch.softmax(torch.randn(B, T, A, device=DEV) * 3, -1)
+    s = Sampling(convLSTM_length=T, min_length=1, map_width=64, map_height=40, width=512, height=320)
+    out = s.beam_search(probs, torch.zeros(B, T, device=DEV), torch.ones(B, T, device=DEV), beam=4)
+    acts, sc = out["selected_actions"], out["scores"]
+    assert (sc[:, :-1] >= sc[:, 1:]).all()
+    pm = probs.clone()
+    pm[:, 0, 0] = 0                    # terminate masked at t < min_length
+    greedy = pm.argmax(-1)
+    first0 = (greedy == 0).float().cumsum(1)
+    greedy = torch.where((first0 - (greedy == 0).float()) > 0, torch.zeros_like(greedy), greedy)     # zero after the first terminate
+    assert torch.equal(acts[:, 0], greedy)
+    assert (acts[:, 0] != acts[:, 1]).any(1).all()
+    fix, am, dm = s.generate_scanpath(torch.zeros(B, 3, 2, 2, device=DEV), None, out["durations"][:, 0], acts[:, 0])
+    assert len(fix) == B and am.shape == (B, T)
+
+
+def _fv(n, rng):
+    a = np.zeros(n, dtype=_FV)
+    a["start_x"], a["start_y"], a["duration"] = rng.uniform(0, 320, n), rng.uniform(0, 240, n), rng.uniform(0.1, 0.6, n)
+    return a
+
+
+def test_evaluation_performance_related_matches_literal_restatement():
+    """batched device scoring + the reference's grouping == the reference's nested loops on the CPU oracles
+    (oracle/eval_oracle.py, utils/evaluation.py:188-359).  ScanMatch and SED columns are bit-exact, STDE <= 4 ulp; MultiMatch is
+    the same restated callable on both sides (third-party package absent: that column is unpinned)."""
+    from oracle import eval_oracle as EO
+    from scanpaths_amd.utils.evaltools.multimatch import docomparison
+    from scanpaths_amd.utils.evaluation import evaluation_performance_related
+    rng = np.random.Generator(np.random.PCG64(12))
+    n_img = 7
+    gt = [[_fv(int(rng.integers(2, 12)), rng) for _ in range(int(rng.integers(2, 6)))] for _ in range(n_img)]
+    perf = [[bool(rng.random() < 0.5) for _ in g] for g in gt]
+    perf[0] = [True] * len(perf[0])
+    perf[1] = [False] * len(perf[1])
+    pred = [_fv(int(rng.integers(3, 14)), rng) for _ in range(n_img)]
+    pred[2] = _fv(2, rng)                    # too short for MultiMatch: every pair of this image is dropped
+    alloc = [True, False, True, True, False, True, False]
+    cur, cur_std, scores = evaluation_performance_related(gt, pred, perf, alloc, multimatch=docomparison)
+    mean_ref, std_ref, scores_ref = EO.evaluation_performance_related(gt, pred, perf, alloc, docomparison)
+    names = [("MultiMatch", k) for k in ("vector", "direction", "length", "position", "duration")] + \
+            [("ScanMatch", "w/o duration"), ("ScanMatch", "with duration"), ("VAME", "SED"), ("VAME", "STDE"),
+             ("VAME", "SED_best"), ("VAME", "STDE_best")]
+    for ci, cat in enumerate(("all", "right_answer", "wrong_answer")):
+        for col, (grp, key) in enumerate(names):
+            assert abs(float(cur[cat][grp][key]) - float(mean_ref[ci][col])) <= 1e-6, (cat, grp, key)
+            assert abs(float(cur_std[cat][grp][key]) - float(std_ref[ci][col])) <= 1e-6, (cat, grp, key)
+    assert len(scores) == n_img
+    for a, b in zip(scores, scores_ref):
+        assert np.allclose(a, b, rtol=0, atol=1e-9)
+    assert scores[2] == list(np.zeros(9))
+
+
+def test_run_test_loop_order_and_single_copy():
+    """the reference's test loop (AiR/test.py:111-193) on the device: record order (per trial: N good, then N poor), counts,
+    finite metrics; fixation vectors equal what generate_scanpath returns for the same draws"""
+    from scanpaths_amd.inference import run_test_loop, sample_batch, to_fix_vectors
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.sampling import Sampling
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    from scanpaths_amd.utils.evaltools.multimatch import docomparison
+    T, N, R = 6, 3, 2
+    m = baseline(convLSTM_length=T, arch="resnet18")
+    fill_module(m, 3, family="tame")
+    m = m.to(DEV).eval()
+    rng = np.random.Generator(np.random.PCG64(5))
+    b = make_batch("AiR", N, 240, 320, T, seed=3)
+    batch = {"images": b["images"], "attention_maps": b["attention_maps"],
+             "fix_vectors": [[_fv(int(rng.integers(3, 9)), rng) for _ in range(3)] for _ in range(N)],
+             "performances": [[True, False, True] for _ in range(N)], "question_ids": [f"q{i}" for i in range(N)],
+             "img_names": [f"i{i}.jpg" for i in range(N)]}
+    samp = Sampling(convLSTM_length=T, min_length=1, seed=9)
+    cur, cur_std, scores, results = run_test_loop(m, samp, [batch], repeat_num=R, multimatch=docomparison)
+    assert len(results) == 2 * R * N and len(scores) == 2 * R * N
+    assert [r["performance"] for r in results] == ([True] * N + [False] * N) * R
+    assert [r["repeat_id"] for r in results] == [1] * (2 * N) + [2] * (2 * N)
+    assert all(r["length"] == len(r["X"]) == len(r["T"]) for r in results)
+    for cat in cur:
+        for grp in cur[cat]:
+            for k, v in cur[cat][grp].items():
+                assert np.isfinite(v), (cat, grp, k)
+    # same seed -> the loop's fixation vectors equal generate_scanpath's for the same draws
+    with torch.no_grad():
+        pred = m(batch["images"].to(DEV), batch["attention_maps"].to(DEV))
+    s2 = Sampling(convLSTM_length=T, min_length=1, seed=9)
+    fix, nfix = sample_batch(pred, s2, 1)
+    fv = to_fix_vectors(fix[0, 0].cpu().numpy().astype(np.float64), nfix[0, 0].cpu().numpy())
+    s3 = Sampling(convLSTM_length=T, min_length=1, seed=9)
+    d = s3.random_sample(pred["good_all_actions_prob"], pred["good_log_normal_mu"], pred["good_log_normal_sigma2"])
+    ref, _, _ = s3.generate_scanpath(batch["images"].to(DEV), d["selected_actions_probs"], d["durations"], d["selected_actions"])
+    for a, r in zip(fv, ref):
+        assert np.array_equal(a["start_x"], r["start_x"]) and np.array_equal(a["duration"], r["duration"])
+    assert results[0]["X"] == list(fv[0]["start_x"])
