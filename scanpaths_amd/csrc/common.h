@@ -13,14 +13,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
-// A producer's fused-amax slot is zeroed IN STREAM ORDER by the producer's own launcher (a captured memset node under HIP-graph
-// capture), so every launch -- eager or a graph replay on new inputs -- starts from 0 instead of max(old, new).
-#define SP_RESET_AMAX(ptr, stream)                                                                     \
-    do {                                                                                               \
-        if (ptr) {                                                                                     \
-            hipError_t e__ = hipMemsetAsync((void*)(ptr), 0, sizeof(unsigned), (hipStream_t)(stream)); \
-            if (e__ != hipSuccess) return (int)e__;                                                    \
-        }                                                                                              \
+// A producer's fused-amax slot is zeroed IN STREAM ORDER by the producer's own launcher, so every launch -- eager or a HIP-graph
+// replay on new inputs -- starts from 0 instead of max(old, new).  A one-thread KERNEL, not hipMemsetAsync: 4-byte memset nodes
+// captured into a HIP graph did not reliably precede the kernels that follow them on replay (replays at a different input
+// amplitude produced wrong operand scales, tools/graph_debug.py), kernel nodes do.
+namespace {
+__global__ void sp_zero_words_kernel(unsigned* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+}  // namespace
+#define SP_RESET_AMAX(ptr, stream)                                                                                          \
+    do {                                                                                                                    \
+        if (ptr) {                                                                                                          \
+            hipLaunchKernelGGL(sp_zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)(stream), (unsigned*)(ptr), 1);     \
+            SP_LAUNCH_CHECK();                                                                                              \
+        }                                                                                                                   \
     } while (0)
 
 // process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default

@@ -31,7 +31,7 @@ constexpr int HB_BYTES = HBN * 128;              // 16384
 constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
 constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
-constexpr int H2_DEFAULT_VARIANT = 0;            // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
+constexpr int H2_DEFAULT_VARIANT = 7;            // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
 constexpr int HW_DEFAULT_VARIANT = 0;            // schedule variant of hw_kernel
 
 struct H2Args {
@@ -476,10 +476,15 @@ __device__ __forceinline__ f16x8 tr_pair_h(const unsigned char* base, int off0, 
 }
 
 __device__ __forceinline__ int rot4(int q) { return 2 * (q & 1) + 8 * (q >> 1); }
+template <bool M16>
+__device__ __forceinline__ int rotx(int r) { return rot4(r & 3) + (M16 ? 4 * ((r >> 3) & 1) : 0); }
 
 // VAR: schedule of the two waves sharing a SIMD, as h2_kernel: 0 lockstep (round 1), 2 ping-pong with one barrier per K-tile
 // (waves 0-3: [issue loads(t+2)] [read(t)] [24 MFMA(t)]; waves 4-7: [24 MFMA(t-1)] [read(t)] [issue loads(t+2)]), 3 = 2 + s_setprio.
-template <int VAR, int NPROD = 3>
+// M16: v_mfma_f32_16x16x32_f16 instead of 32x32x16 (see h2_kernel): one 32-pixel k-block per K-tile, 4x4 tiles of 16x16 per wave.
+// The two 16-lane groups of a 32-lane half then read pixel rows 8 apart at the SAME channels, so the stored rotation of pixel row
+// r becomes rot4(r&3) + 4*((r>>3)&1) chunks: the 4 rows x 2 k-groups of a half again cover all 8 32-byte slots of the bank row.
+template <int VAR, int NPROD = 3, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     for (int j = 0; j < 4; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 6, pos = g & 63;
-        const int js = (pos - rot4(r & 3)) & 63;                 // un-rotate: which source chunk lands here
+        const int js = (pos - rotx<M16>(r)) & 63;                // un-rotate: which source chunk lands here
         a_r[j] = r;
         a_cok[j] = co0 + (js >> 2) * 16 < p.Co;
         a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.Co) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     for (int j = 0; j < 2; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 5, pos = g & 31;
-        const int js = (pos - rot4(r & 3)) & 31;
+        const int js = (pos - rotx<M16>(r)) & 31;
         const int col = n0 + (js >> 2) * 16;                      // first column of this lane's 16-channel group
         const int tap = col / p.Ci, ci = col - tap * p.Ci;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -563,24 +568,35 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         ++ld_kt;
     };
 
-    // transposed-read offsets (k-group kk adds 16 pixel rows): lane (g4 = (lane>>4)&1, q = (lane>>2)&3, pp = lane&3) addresses
-    // pixel row 8h + 4s + q, channels cbase + 16*g4 + 4pp .. +3 of plane pl
-    const int g4 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
-    int offA[2][2][2], offB[2][2][2];     // [i][plane][s]
+    // transposed-read offsets.  32x32x16: k-group kk adds 16 pixel rows; lane (g4 = (lane>>4)&1, q = (lane>>2)&3, pp = lane&3)
+    // addresses pixel row 8h + 4s + q, channels cbase + 16*g4 + 4pp .. +3 of plane pl.  16x16x32: the 16-lane group kg = lane>>4
+    // is the k-group, pixel row 8kg + 4s + q, channels cbase + 4pp .. +3 of the 16-channel tile.
+    const int g4 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
+    constexpr int NT = M16 ? 4 : 2;
+    int offA[NT][2][2], offB[NT][2][2];     // [i][plane][s]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int row = 8 * h + 4 * s2 + q;
-                const int ja = (wm * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
-                offA[i][pl][s2] = row * HWA_ROW + ((ja + rot4(q)) & 63) * 16 + (pp & 1) * 8;
-                const int jb = (wn * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
-                offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + ((jb + rot4(q)) & 31) * 16 + (pp & 1) * 8;
+                if constexpr (M16) {
+                    const int row = 8 * kg + 4 * s2 + q;
+                    const int ja = (wm * 4 + i) * 4 + pl * 2 + (pp >> 1);
+                    offA[i][pl][s2] = row * HWA_ROW + ((ja + rotx<true>(row)) & 63) * 16 + (pp & 1) * 8;
+                    const int jb = (wn * 4 + i) * 4 + pl * 2 + (pp >> 1);
+                    offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + ((jb + rotx<true>(row)) & 31) * 16 + (pp & 1) * 8;
+                } else {
+                    const int row = 8 * h + 4 * s2 + q;
+                    const int ja = (wm * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
+                    offA[i][pl][s2] = row * HWA_ROW + ((ja + rot4(q)) & 63) * 16 + (pp & 1) * 8;
+                    const int jb = (wn * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
+                    offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + ((jb + rot4(q)) & 31) * 16 + (pp & 1) * 8;
+                }
             }
 
     f32x16 tot[2][2], acc[2][2];
+    f32x4 tot4[4][4], acc4[4][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -589,6 +605,15 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             for (int r = 0; r < 16; ++r) {
                 tot[i][j][r] = 0.f;
                 acc[i][j][r] = 0.f;
+            }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                tot4[i][j][r] = 0.f;
+                acc4[i][j][r] = 0.f;
             }
 
     {
@@ -606,11 +631,30 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
-                af[kk][i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
-                bf[kk][i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
+                if constexpr (M16) {     // group kk = 16-channel tiles 2kk, 2kk+1 of the ONE 32-pixel block
+                    af[kk][i][pl] = tr_pair_h(st, offA[(2 * kk + i) % NT][pl][0], offA[(2 * kk + i) % NT][pl][1]);
+                    bf[kk][i][pl] = tr_pair_h(st, offB[(2 * kk + i) % NT][pl][0], offB[(2 * kk + i) % NT][pl][1]);
+                } else {
+                    af[kk][i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
+                    bf[kk][i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
+                }
             }
     };
     auto mma_group = [&](int kk) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4& a4 = acc4[2 * kk + i][j];
+                    if constexpr (NPROD == 3) {
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                    }
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -623,6 +667,19 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             }
     };
     auto fold = [&](int kt_) {
+        if constexpr (M16) {
+            if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tot4[i][j] += acc4[i][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
+                    }
+            }
+            return;
+        }
         if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -649,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
             if (VAR >= 2 && pre) issue_tile(prev_stage(stage));
-            if (VAR == 0) {                 // round-1 order: reads of a 16-pixel group right before its MFMAs
+            if (VAR == 0 && !M16) {         // round-1 order: reads of a 16-pixel group right before its MFMAs
                 read_group(stage, 0);
                 mma_group(0);
                 read_group(stage, 1);
@@ -690,6 +747,32 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
     const float isx = 1.f / p.sx[0], isy = 1.f / p.sy[0];
+    if constexpr (M16) {
+        const int l16 = lane & 15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l16;
+            if (n >= p.Ntot) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wm * 64 + i * 16 + 4 * kg + r;
+                    if (co < p.Co) {
+                        float* dst = out + (int64_t)co * p.ldo + n;
+                        const float v = tot4[i][j][r] + acc4[i][j][r];
+                        if (direct) {
+                            float w = p.alpha * ((v * isx) * isy);
+                            if (p.beta) w += *dst;
+                            *dst = w;
+                        } else {
+                            *dst = v;
+                        }
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l32;
@@ -844,9 +927,9 @@ int launch_h2(const H2Args& a, hipStream_t s) {
     return SP_OK;
 }
 
-template <int VAR, int NPROD = 3>
+template <int VAR, int NPROD = 3, bool M16 = false>
 int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
-    auto kern = hw_kernel<VAR, NPROD>;
+    auto kern = hw_kernel<VAR, NPROD, M16>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HWSTAGE);
@@ -859,8 +942,7 @@ int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
 }
 
 int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned), s);
-    if (e != hipSuccess) return (int)e;
+    SP_RESET_AMAX(amax, s);          // a kernel node, not a memset node: see common.h
     const int64_t n4 = n / 4;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256 * 4), 1024));
     hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, n, amax);
@@ -990,7 +1072,10 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     else switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
         case 0: rc = launch_hw<0>(a, d->Co, s); break;
         case 2: rc = launch_hw<2>(a, d->Co, s); break;
-        default: rc = launch_hw<3>(a, d->Co, s); break;
+        case 3: rc = launch_hw<3>(a, d->Co, s); break;
+        case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
+        case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
+        default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
     }
     if (rc != SP_OK) return rc;
     if (a.splits > 1) {

@@ -36,7 +36,9 @@ def _build(meta, Hm=30, Wm=40):
     return m.to(DEV)
 
 
-NOISE_X = 10.0      # chaotic "default" cases, see _check
+NOISE_X = 20.0      # chaotic "default" cases: profiles/r02_noise_ratio.json (tools/noise_ratio.py) -- over 6 seeds the HIP error is
+                    # 0.5x .. 16x the reference's single fp32 draw with a median of ~2x, as is a second fp32 evaluation of the reference
+                    # itself; the tame cases carry the strict bar
 TAME_X = 5.0        # "tame" cases: the north-star bar
 BACKENDS = ["f16x2", "bf16x3", "fp32"]
 

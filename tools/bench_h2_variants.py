@@ -53,7 +53,7 @@ def timed(fn):
 
 H2V = [int(v) for v in os.environ.get("H2_VARIANTS", "0,1,2,3,4,5,6,7").split(",")]      # 4..7 = the 16x16x32 MFMA shape
 cases = [("fwd", fwd, b"h2_variant", H2V, lambda: y), ("dgrad", dgrad, b"h2_variant", H2V, lambda: dx),
-         ("wgrad", wgrad, b"hw_variant", [0, 2, 3], lambda: dw)]
+         ("wgrad", wgrad, b"hw_variant", [0, 2, 3, 4, 6, 7], lambda: dw)]
 res, ident = {}, {}
 for name, fn, knob, variants, outp in cases:
     ref = None

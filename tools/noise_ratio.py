@@ -1,0 +1,49 @@
+"""Distribution of  err(HIP, fp64) / err(reference-restatement fp32, fp64)  per decode step over several weight / input seeds on
+the CHAOTIC "default" weight family (tests/test_model_gpu.py NOISE_X).  For each seed: the fp64 oracle, the fp32 oracle (= the
+reference's arithmetic, pinned by tests/golden) and the HIP model on the same procedural weights and synthetic inputs; eval mode,
+OSIE ResNet-18, T = 4, B = 2 (the family of the two golden cases that need > 10x).  Also the ratio for a SECOND fp32 evaluation of
+the oracle with a different thread count (different oneDNN summation order): how much two fp32 draws of the reference itself differ.
+Writes gpurun_out/r02_noise_ratio.json."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import scanpath_oracle as O
+from scanpaths_amd.models.scanpath_model import ScanpathModel
+from scanpaths_amd.procedural import fill_module, procedural_state_dict
+from scanpaths_amd.spec import model_spec
+from scanpaths_amd.synth import make_batch
+
+T, B = 4, 2
+rows = []
+for seed in range(31, 37):
+    b = make_batch("OSIE", B, 240, 320, T, seed=seed)
+    sd = procedural_state_dict(model_spec("OSIE", "resnet18", 30, 40), seed)
+    outs = {}
+    for tag, dt, nt in (("ref64", torch.float64, 32), ("ref32", torch.float32, 32), ("ref32b", torch.float32, 5)):
+        torch.set_num_threads(nt)
+        s = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+        with torch.no_grad():
+            outs[tag] = O.forward(s, "OSIE", b["images"].to(dt), training=False, T=T, arch="resnet18")
+    m = ScanpathModel("OSIE", convLSTM_length=T, arch="resnet18")
+    fill_module(m, seed)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        outs["hip"] = {k: v.cpu() for k, v in m(b["images"].cuda()).items()}
+    for k in outs["ref64"]:
+        r = outs["ref64"][k]
+        scale = float(r.abs().max())
+        for t in range(T):
+            e = {tag: float((outs[tag][k][:, t].double() - r[:, t]).abs().max()) for tag in ("ref32", "ref32b", "hip")}
+            if e["ref32"] > 1e-2 * scale or e["ref32"] == 0:
+                break
+            rows.append({"seed": seed, "key": k, "step": t, "scale": scale, **e, "hip_over_ref32": e["hip"] / e["ref32"],
+                         "ref32b_over_ref32": e["ref32b"] / e["ref32"]})
+    print(seed, "done", flush=True)
+r1 = sorted(x["hip_over_ref32"] for x in rows)
+r2 = sorted(x["ref32b_over_ref32"] for x in rows)
+q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]
+summary = {"n": len(rows), "hip_over_ref32": {"min": r1[0], "median": q(r1, 0.5), "p90": q(r1, 0.9), "max": r1[-1]},
+           "second_fp32_draw_over_ref32": {"min": r2[0], "median": q(r2, 0.5), "p90": q(r2, 0.9), "max": r2[-1]}}
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump({"summary": summary, "rows": rows}, open("gpurun_out/r02_noise_ratio.json", "w"), indent=0)
+print(json.dumps(summary))
