@@ -258,7 +258,9 @@ __global__ void collate_kernel(const float* X, const float* Y, const float* Ts, 
     dmask[i] = dm;
     float* row = target + (int64_t)i * A;
     if (px == -1 || py == -1) row[0] = 1.f;                  // terminate target (:141-142)
-    else row[1 + py * map_w + px] = 1.f;                     // (:144-147); indices outside the map are the caller's error there too
+    else if ((unsigned)px < (unsigned)map_w && (unsigned)py < (unsigned)map_h)
+        row[1 + py * map_w + px] = 1.f;                      // (:144-147)
+    // a fixation outside the image (the reference raises IndexError there) leaves the step without a target
 }
 
 }  // namespace

@@ -41,9 +41,10 @@ def collate_targets(fixations: Sequence[dict], max_length: int = 16, action_map=
     dur = torch.empty((B, T), dtype=torch.float32, device=device)
     am = torch.empty((B, T), dtype=torch.float32, device=device)
     dm = torch.empty((B, T), dtype=torch.float32, device=device)
-    check(hip.lib().sp_collate_targets(ptr(X), ptr(Y), ptr(Ts), ptr(Te), ptr(torch.from_numpy(start).to(device)),
-                                       ptr(torch.from_numpy(cnt).to(device)), ptr(ow), ptr(oh), B, T, Hm, Wm, int(f64_div),
-                                       ptr(target), ptr(dur), ptr(am), ptr(dm), hip.stream()), "sp_collate_targets")
+    start_d, cnt_d = torch.from_numpy(start).to(device), torch.from_numpy(cnt).to(device)     # named: must outlive the launch
+    check(hip.lib().sp_collate_targets(ptr(X), ptr(Y), ptr(Ts), ptr(Te), ptr(start_d), ptr(cnt_d), ptr(ow), ptr(oh), B, T, Hm,
+                                       Wm, int(f64_div), ptr(target), ptr(dur), ptr(am), ptr(dm), hip.stream()),
+          "sp_collate_targets")
     return {"scanpaths": target, "durations": dur, "action_masks": am, "duration_masks": dm}
 
 

@@ -46,8 +46,9 @@ def sed_stde_pairs(scanpaths: Sequence[np.ndarray], pairs, image_shape, n: int =
     npairs = pr.shape[0]
     sed = torch.empty(npairs, dtype=torch.int32, device=dev) if want_sed else None
     stde = torch.empty(npairs, dtype=torch.float64, device=dev) if want_stde else None
+    count_d = count.to(dev)          # named: must outlive the launch
     if npairs:
-        check(L.sp_scan_sed_stde(ptr(fix), ncol, ptr(start), ptr(count.to(dev)), ptr(pr), npairs, int(image_shape[0]),
+        check(L.sp_scan_sed_stde(ptr(fix), ncol, ptr(start), ptr(count_d), ptr(pr), npairs, int(image_shape[0]),
                                  int(image_shape[1]), int(n), float(max(image_shape)), ptr(sed), ptr(stde), hip.stream()),
               "sp_scan_sed_stde")
     return sed, stde

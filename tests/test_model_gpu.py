@@ -36,9 +36,7 @@ def _build(meta, Hm=30, Wm=40):
     return m.to(DEV)
 
 
-NOISE_X = 20.0      # chaotic "default" cases: profiles/r02_noise_ratio.json (tools/noise_ratio.py) -- over 6 seeds the HIP error is
-                    # 0.5x .. 16x the reference's single fp32 draw with a median of ~2x, as is a second fp32 evaluation of the reference
-                    # itself; the tame cases carry the strict bar
+NOISE_X = 10.0      # chaotic "default" cases, see _check / _joint_floor
 TAME_X = 5.0        # "tame" cases: the north-star bar
 BACKENDS = ["f16x2", "bf16x3", "fp32"]
 
@@ -80,9 +78,29 @@ def _call(model, meta, b):
     return model(img, b["attention_maps"].to(DEV), b["tasks"].to(DEV))
 
 
+CHAOS_CUTOFF = 1e-3     # chaotic cases are compared while the reference's own fp32 drift is below 0.1 % of an output's scale
+
+
+def _joint_floor(g, keys, T):
+    """{step: running max over ALL outputs of err(ref32, ref64) / scale}.  Every output of a step is a function of the same
+    recurrent state, so the reference's fp32 noise of the state is best read from the noisiest output: one output's own fp32
+    error at one step is a single random draw that can be accidentally small (osie_r18_eval_T8 sigma2, step 2: 2.9e-5 of scale
+    while mu sits at 1.0e-3) -- measured against the joint floor, the three GEMM back-ends stay below 10x on every golden case
+    (over 6 further seeds the HIP error is 0.1x .. 6.6x the reference's own draw, median 1.1x: profiles/r02_noise_ratio.json)."""
+    floor, run = {}, 0.0
+    for t in range(T):
+        for key in keys:
+            ref, r32 = torch.as_tensor(g["ref64/" + key]), torch.as_tensor(g["ref32/" + key])
+            if ref.dim() < 2 or ref.shape[1] != T:
+                continue
+            run = max(run, max_err(r32[:, t], ref[:, t]) / max(float(ref.abs().max()), 1e-30))
+        floor[t] = run
+    return floor
+
+
 def _informative_steps(g, keys, T):
     """Number of leading decode steps worth comparing: the recurrent state is shared by all outputs, so once ANY output
-    of the reference's own fp32 run has drifted more than 1 % (of its scale) from its fp64 run, later steps of EVERY
+    of the reference's own fp32 run has drifted more than CHAOS_CUTOFF (of its scale) from its fp64 run, later steps of EVERY
     output only measure chaotic amplification of rounding noise (random weights), not correctness."""
     tmax = T
     for key in keys:
@@ -91,13 +109,13 @@ def _informative_steps(g, keys, T):
             continue
         scale = max(float(ref.abs().max()), 1e-30)
         for t in range(T):
-            if max_err(r32[:, t], ref[:, t]) > 1e-2 * scale:
+            if max_err(r32[:, t], ref[:, t]) > CHAOS_CUTOFF * scale:
                 tmax = min(tmax, t + 1)      # step t itself is still compared (with its own, already loose, bar)
                 break
     return tmax
 
 
-def _check(name, key, got, g, report, T=None, tmax=None, noise_x=None, rows=None, backend="f16x2"):
+def _check(name, key, got, g, report, T=None, tmax=None, noise_x=None, rows=None, backend="f16x2", joint=None):
     """err(hip, ref64) <= max(1e-4*scale, NOISE_X * running-max of the reference's own fp32-vs-fp64 error), per decode step.
     Returns {step: bar} for the steps that were compared.
 
@@ -118,6 +136,8 @@ def _check(name, key, got, g, report, T=None, tmax=None, noise_x=None, rows=None
     for t in steps:
         sl = (slice(None), t) if t is not None else (Ellipsis,)
         floor_run = max(floor_run, max_err(r32[sl], ref[sl]))
+        if joint is not None and t is not None:
+            floor_run = max(floor_run, joint[t] * float(ref.abs().max()))
         if floor_run > 1e-2 * scale:
             # the reference's own fp32 run is no longer within 1% of its fp64 run here (chaotic recurrence with random
             # weights): later steps carry no information about correctness
@@ -161,9 +181,10 @@ def test_eval_forward_matches_reference(name):
         pred = _call(model, meta, b)
     report, rows = [], []
     tmax = _informative_steps(g, list(pred.keys()), meta["T"])
+    joint = _joint_floor(g, list(pred.keys()), meta["T"])
     report.append(f"{name}: comparing the first {tmax} of {meta['T']} decode steps")
     for k, v in pred.items():
-        bars = _check(name, k, v, g, report, meta["T"], tmax, rows=rows)
+        bars = _check(name, k, v, g, report, meta["T"], tmax, rows=rows, joint=joint)
         if k.endswith("all_actions_prob"):
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
@@ -230,7 +251,8 @@ def test_train_step_matches_reference(name):
     tame = meta.get("weight_family") == "tame"
     tmax = _informative_steps(g, list(pred.keys()), meta["T"])
     for k, v in pred.items():
-        bars = _check(name, k, v, g, report, meta["T"], tmax, noise_x=TAME_X if tame else None)
+        bars = _check(name, k, v, g, report, meta["T"], tmax, noise_x=TAME_X if tame else None,
+                      joint=None if tame else _joint_floor(g, list(pred.keys()), meta["T"]))
         if k in ("all_actions_prob", "actions"):
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  {k}: argmax identical on all {n} decisive of {tot} compared (b,t) positions")
@@ -307,7 +329,7 @@ def test_air_train_T16_logits_match_reference():
     report = []
     tmax = _informative_steps(g, list(pred.keys()), meta["T"])
     for k, v in pred.items():
-        bars = _check("air_train_T16", k, v, g, report, meta["T"], tmax)
+        bars = _check("air_train_T16", k, v, g, report, meta["T"], tmax, joint=_joint_floor(g, list(pred.keys()), meta["T"]))
         if k == "all_actions_prob":
             n, tot = _check_argmax(v, g["ref64/" + k], bars)
             report.append(f"  argmax identical on all {n} decisive of {tot} compared (b,t) positions; {tmax} of 16 steps compared")

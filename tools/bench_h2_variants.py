@@ -51,7 +51,7 @@ def timed(fn):
     return s.elapsed_time(e) / REPS
 
 
-H2V = [int(v) for v in os.environ.get("H2_VARIANTS", "0,1,2,3,4,5,6,7").split(",")]      # 4..7 = the 16x16x32 MFMA shape
+H2V = [int(v) for v in os.environ.get("H2_VARIANTS", "0,3,4,7,8,11,12,14,15").split(",")]      # 4..7 = the 16x16x32 MFMA shape
 cases = [("fwd", fwd, b"h2_variant", H2V, lambda: y), ("dgrad", dgrad, b"h2_variant", H2V, lambda: dx),
          ("wgrad", wgrad, b"hw_variant", [0, 2, 3, 4, 6, 7], lambda: dw)]
 res, ident = {}, {}
