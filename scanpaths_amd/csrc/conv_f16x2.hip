@@ -530,8 +530,10 @@ __device__ __forceinline__ int rotx(int r) { return rot4(r & 3) + (M16 ? 4 * ((r
 // M16: v_mfma_f32_16x16x32_f16 instead of 32x32x16 (see h2_kernel): one 32-pixel k-block per K-tile, 4x4 tiles of 16x16 per wave.
 // The two 16-lane groups of a 32-lane half then read pixel rows 8 apart at the SAME channels, so the stored rotation of pixel row
 // r becomes rot4(r&3) + 4*((r>>3)&1) chunks: the 4 rows x 2 k-groups of a half again cover all 8 32-byte slots of the bank row.
-template <int VAR, int NPROD = 3, bool M16 = false>
+// DBG (env SP_HW_DBG, timing experiments only): 1 = no global loads, 2 = no MFMAs, 3 = MFMAs only (no loads, no LDS reads, no barriers)
+template <int VAR, int NPROD = 3, bool M16 = false, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
+    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2, do_lds = DBG != 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -588,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     const uint32_t xrow = (uint32_t)(4 * p.Ci);
     int ld_kt = 0;
     auto issue_tile = [&](int stage) {
+        if constexpr (!do_load) return;
         unsigned char* st = smem + stage * HWSTAGE;
         const int64_t mt = m_begin + (int64_t)ld_kt * 32;
         const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (4 * (int64_t)p.Co);   // scalar
@@ -673,6 +676,19 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]
     auto read_group = [&](int stage_, int kk) {
         const unsigned char* st = smem + stage_ * HWSTAGE;
+        if constexpr (!do_lds) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    f16x8 z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[e] = (_Float16)(float)(stage_ + e + lane);
+                    af[kk][i][pl] = z;
+                    bf[kk][i][pl] = z;
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -687,6 +703,16 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             }
     };
     auto mma_group = [&](int kk) {
+        if constexpr (!do_mma) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const f16x8 x0 = af[kk][i][pl], x1 = bf[kk][i][pl];
+                    asm volatile("" ::"v"(x0), "v"(x1));
+                }
+            return;
+        }
         if constexpr (M16) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         if (kt_ + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (do_lds) __builtin_amdgcn_s_barrier();
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
@@ -973,9 +999,9 @@ int launch_h2(const H2Args& a, hipStream_t s) {
     return SP_OK;
 }
 
-template <int VAR, int NPROD = 3, bool M16 = false>
+template <int VAR, int NPROD = 3, bool M16 = false, int DBG = 0>
 int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
-    auto kern = hw_kernel<VAR, NPROD, M16>;
+    auto kern = hw_kernel<VAR, NPROD, M16, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HWSTAGE);
@@ -1123,7 +1149,12 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);
+    static const int dbg = getenv("SP_HW_DBG") ? atoi(getenv("SP_HW_DBG")) : 0;
+    if (dbg == 1) rc = launch_hw<2, 3, true, 1>(a, d->Co, s);
+    else if (dbg == 2) rc = launch_hw<2, 3, true, 2>(a, d->Co, s);
+    else if (dbg == 3) rc = launch_hw<2, 3, true, 3>(a, d->Co, s);
+    else if (dbg == 4) rc = launch_hw<2, 3, false, 1>(a, d->Co, s);
+    else if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);
     else switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
         case 0: rc = launch_hw<0>(a, d->Co, s); break;
         case 2: rc = launch_hw<2>(a, d->Co, s); break;

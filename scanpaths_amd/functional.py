@@ -132,9 +132,9 @@ def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
 def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree)"""
     scheme = scheme or _scheme_for(x.shape[-1])
-    cached = getattr(x, "_sp_split", None)       # an earlier consumer of the same tensor object already split it
-    if cached is not None and cached.scheme == scheme:
-        return cached
+    cache = getattr(x, "_sp_cache", None)        # {scheme: SplitOperand} shared by every alias of a multi-consumer tensor (fanout)
+    if cache is not None and scheme in cache:
+        return cache[scheme]
     if scheme == "bf16x3":
         op = SplitOperand(split3(x), None, scheme)
     else:
@@ -145,8 +145,8 @@ def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
         scale = hint if hint is not None else torch.empty(2, dtype=torch.float32, device=x.device)
         check(hip.lib().sp_split2_f16(ptr(xc), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
         op = SplitOperand(out, scale, scheme)
-    if getattr(x, "_sp_share_split", False):     # set by producers whose output feeds several GEMMs (the ConvLSTM state h)
-        x._sp_split = op
+    if cache is not None:                        # set by producers whose output feeds several GEMMs (the ConvLSTM state h)
+        cache[scheme] = op
     return op
 
 
@@ -327,7 +327,14 @@ class _FanOut(Function):
 
 
 def fanout(x: torch.Tensor, n: int):
-    return _FanOut.apply(x, n)
+    """n aliases of x whose gradients are summed in ONE pass; the operand-split cache and the fused-amax hint travel with them"""
+    outs = _FanOut.apply(x, n)
+    for attr in ("_sp_cache", "_sp_amax"):
+        v = getattr(x, attr, None)
+        if v is not None:
+            for o in outs:
+                setattr(o, attr, v)
+    return outs
 
 
 class _ScaleConst(Function):
@@ -381,7 +388,7 @@ class _Conv2d(Function):
         Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
         xs = None
-        shared = getattr(x, "_sp_share_split", False)
+        shared = getattr(x, "_sp_cache", None) is not None
         if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel(), free_a=shared):
             xs = split_op(x)
             wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
@@ -816,7 +823,7 @@ class _LstmCellRank1(Function):
                                           ptr(h), _hint_ptr(hint), hip.stream()), "sp_lstm_rank1_fwd")
         if hint is not None:
             h._sp_amax = hint
-        h._sp_share_split = True          # h feeds the saliency tap GEMM of this step and the h-gate conv of the next: split once
+        h._sp_cache = {}                  # h feeds the saliency tap GEMM of this step and the h-gate conv of the next: split once
         ctx.has = (hg is not None, c_prev is not None)
         ctx.save_for_backward(gates, c_prev, c, spcol, wc)
         return h, c

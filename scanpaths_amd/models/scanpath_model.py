@@ -295,14 +295,17 @@ class ScanpathModel(nn.Module):
         Wx = self._cat_phys([L.input_x.weight, L.forget_x.weight, L.output_x.weight, L.memory_x.weight])
         bias = torch.cat([self._sum_bias([g + "_x", g + "_h"] + [g + s for s in self.streams])
                           for g in ("input", "forget", "output")] + [self._sum_bias(["memory_x", "memory_h"])])
-        Xg = F.conv2d(vf, Wx, bias, pad=1)
+        # vf feeds the x-gate conv, its channel mean and the semantic pooling of every memory push: one gradient fan-in pass
+        # (sp_sum_n) instead of T + 2 read-read-write adds by autograd
+        n_vf = T + 3
+        vfs = list(F.fanout(vf, n_vf)) if vf.requires_grad and n_vf <= 32 else [vf] * n_vf
+        Xg = F.conv2d(vfs.pop(), Wx, bias, pad=1)
         Wh = self._cat_phys([L.input_h.weight, L.forget_h.weight, L.output_h.weight, L.memory_h.weight])
         Wr = [torch.cat([getattr(L, g + s).weight.permute(0, 2, 3, 1) for g in ("input", "forget", "output")], 0)
               .reshape(3 * 512 * 9, 512) for s in self.streams]
         KP = (9 * S + 3) // 4 * 4
-        mvf = F.channel_mean(vf).view(B * P)
+        mvf = F.channel_mean(vfs.pop()).view(B * P)
         u_sem, u_spa = self._attention_vectors()
-        vf3 = vf.view(B, P, Cc)
         # heads
         if self.task == "AiR":
             head_convs = [self.performance_sal_layer["True"], self.performance_sal_layer["False"]]   # good, poor
@@ -336,6 +339,7 @@ class ScanpathModel(nn.Module):
         def push(amaps):          # amaps [S,B,P]; memory update :277-296 / :317-336
             spf = F.mul_relu(amaps, mvf)
             sp_list.append(F.linear(spf.view(S * B, P), self.spatial_embed.weight, self.spatial_embed.bias))
+            vf3 = vfs.pop().view(B, P, Cc)
             pooled = F.semantic_pool(amaps, vf3) if (S <= 2 and Cc <= 512) else \
                 F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
             se_list.append(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), self.semantic_embed.weight,
@@ -358,8 +362,11 @@ class ScanpathModel(nn.Module):
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
             hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache) if h is not None else None        # step 0: h == 0
             h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc)
-            Z2 = F.sal_gather(F.conv2d(h, Wsal, None, pad=0), hmap, nh, nsrc)
-            Dpre = F.drt_direct(h, W11, cbsum, hmap, nh)
+            # h has three consumers (two heads now, the h-gate conv of the next step): one fan-in pass for its gradient
+            nuse = 3 if t + 1 < T else 2
+            h_sal, h_drt, h = (tuple(F.fanout(h, nuse)) + (None,))[:3] if h.requires_grad else (h, h, h)
+            Z2 = F.sal_gather(F.conv2d(h_sal, Wsal, None, pad=0), hmap, nh, nsrc)
+            Dpre = F.drt_direct(h_drt, W11, cbsum, hmap, nh)
             logits, amap, mu, s2 = F.head_finish(Z2, cb, w2, b2, nh, HC, not self.training, per_sample=per_sample, dpre=Dpre)
             outs["logits"].append(logits)
             outs["amap"].append(amap)

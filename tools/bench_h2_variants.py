@@ -53,7 +53,9 @@ def timed(fn):
 
 H2V = [int(v) for v in os.environ.get("H2_VARIANTS", "0,3,4,7,8,11,12,14,15").split(",")]      # 4..7 = the 16x16x32 MFMA shape
 cases = [("fwd", fwd, b"h2_variant", H2V, lambda: y), ("dgrad", dgrad, b"h2_variant", H2V, lambda: dx),
-         ("wgrad", wgrad, b"hw_variant", [0, 2, 3, 4, 6, 7], lambda: dw)]
+         ("wgrad", wgrad, b"hw_variant", [int(v) for v in os.environ.get("HW_VARIANTS", "0,2,6,7").split(",")], lambda: dw)]
+if os.environ.get("ONLY"):
+    cases = [c for c in cases if c[0] in os.environ["ONLY"].split(",")]
 res, ident = {}, {}
 for name, fn, knob, variants, outp in cases:
     ref = None
