@@ -207,8 +207,15 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         const uint32_t koffA = (uint32_t)ld_cblk * 128u;                 // scalar: 32-channel block inside the pixel row
         const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
         const uint32_t zrelA = p.x_bytes - koffA;
+        // DBG 5 (timing proxy for a one-pixel-halo activation block shared by the three horizontal taps): the activation pieces
+        // are loaded for the first tap of each filter row only (results are wrong, timing and data statistics are realistic)
+        if (DBG != 5 || ld_kx == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
+            for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(a_voff[j]));
+        }
         const uint32_t koffB = (uint32_t)ld_kt * 128u;
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
         const uint32_t zrelB = p.w_bytes - koffB;
@@ -222,6 +229,41 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 ++ld_ky;
             }
         }
+    };
+
+    // VAR 4 ("spread"): the 6 LDS-DMA pieces of a K-tile are issued one at a time between groups of 8 MFMAs instead of as one
+    // block (an LDS-DMA issue costs the issuing wave ~60 cycles among MFMAs, 100-185 inside a load block); tap-major order only
+    uint32_t pc_off[6];
+    const unsigned char *pc_baseA = nullptr, *pc_baseB = nullptr;
+    int pc_stage = 0;
+    auto prepare_tile = [&](int stage) {
+        if (ld_cblk == 0) tap_update();
+        const uint32_t koffA = (uint32_t)ld_cblk * 128u;
+        pc_baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
+        const uint32_t zrelA = p.x_bytes - koffA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pc_off[j] = a_ok[j] ? a_voff[j] : zrelA;
+        const uint32_t koffB = (uint32_t)ld_kt * 128u;
+        pc_baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
+        const uint32_t zrelB = p.w_bytes - koffB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pc_off[4 + j] = b_ok[j] ? b_voff[j] : zrelB;
+        pc_stage = stage;
+        ++ld_kt;
+        if (++ld_cblk == p.ncblk) {
+            ld_cblk = 0;
+            if (++ld_kx == p.KW) {
+                ld_kx = 0;
+                ++ld_ky;
+            }
+        }
+    };
+    auto issue_piece = [&](int q) {
+        unsigned char* st = smem + pc_stage * HSTAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < 4) SP_GLDS16(pc_baseA + pc_off[q], st + (wave + 8 * q) * 1024);
+        else SP_GLDS16(pc_baseB + pc_off[q], st + HA_BYTES + (wave + 8 * (q - 4)) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // fragment read offsets: row r, chunk c = kk*4 + plane*2 + h stored at position c ^ ((r>>1)&7)
@@ -378,7 +420,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     };
     auto wait_barrier = [&](int kt_) {
         // tile kt+1 must have landed: everything but the one younger tile (if it was issued)
-        if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (DBG == 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // the younger tile has 2 or 6 pieces: never wait for fewer than needed
+        else if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (do_lds) __builtin_amdgcn_s_barrier();
@@ -386,9 +429,27 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
     int stage = 0;
-    const bool late = VAR != 0 && wave >= 4;            // the half of the workgroup that runs behind (scalar: uniform branch)
-    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(1);
-    if (!late) {
+    const bool late = VAR >= 1 && VAR <= 3 && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
+    if (VAR == 3 && late) __builtin_amdgcn_s_setprio(1);
+    if constexpr (VAR == 4 && M16 && do_mma && do_load) {
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            const bool pre = kt + HNSTAGE - 1 < p.nkt;
+            if (pre) prepare_tile(prev_stage(stage));
+            read_frags(stage, kt);
+#pragma unroll
+            for (int pr = 0; pr < 16; ++pr) {
+                const int i = pr >> 2, j = pr & 3;
+                f32x4& a4 = acc4[i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                if (((pr + 1) * 6) / 16 != (pr * 6) / 16 && pre) issue_piece((pr * 6) / 16);
+            }
+            fold(kt);
+            wait_barrier(kt);
+            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+        }
+    } else if (!late) {
         for (int kt = 0; kt < p.nkt; ++kt) {
             const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
             // prefetch of tile kt+2 into the stage read in iteration kt-1: VAR >= 2 issues it FIRST (its partner wave is in its
@@ -434,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         mma_group(1);
         fold(p.nkt - 1);
     }
-    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(0);
+    if (VAR == 3 && late) __builtin_amdgcn_s_setprio(0);
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
@@ -1084,13 +1145,18 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
     if (dbg == 2) return f ? launch_h2<0, 2, 0>(a, st) : launch_h2<1, 2, 0>(a, st);
     if (dbg == 3) return f ? launch_h2<0, 3, 0>(a, st) : launch_h2<1, 3, 0>(a, st);
+    if (dbg == 5) return f ? launch_h2<0, 5, 3, 3, true>(a, st) : launch_h2<1, 5, 3, 3, true>(a, st);
+    if (dbg == 6) return f ? launch_h2<0, 1, 3, 3, true>(a, st) : launch_h2<1, 1, 3, 3, true>(a, st);      // no loads, 16x16x32 ping-pong
+    if (dbg == 7) return f ? launch_h2<0, 2, 3, 3, true>(a, st) : launch_h2<1, 2, 3, 3, true>(a, st);      // no MFMAs
+    if (dbg == 8) return f ? launch_h2<0, 3, 3, 3, true>(a, st) : launch_h2<1, 3, 3, 3, true>(a, st);      // MFMAs only
     if (nprod == 1)      // throughput mode: load-bound, the ping-pong schedule
         return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
     int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
     // bit 3 = channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
     const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
-    if ((variant & 8) && !cbm_ok) variant &= 7;
+    if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
     switch (variant) {
+        case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
         case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
         case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
         case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
