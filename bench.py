@@ -40,7 +40,7 @@ KERNEL_NAMES = {
     "h1_wgrad": "hw_kernel<1 plane>",
     "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)", "b3_dgrad": "b3_kernel<dgrad>", "b3_wgrad": "w3_kernel",
     "igemm_fwd": "igemm_kernel<fwd> (fp32 MFMA)", "igemm_dgrad": "igemm_kernel<dgrad> (fp32 MFMA)", "wgrad": "wgrad_kernel (fp32 MFMA)"}
-PMC_KEYS = {"h2_fwd": "h2_kernel<0, 0>", "h2_dgrad": "h2_kernel<1, 0>", "h2_wgrad": "hw_kernel"}
+PMC_PREFIX = {"h2_fwd": "h2_kernel<0,", "h2_dgrad": "h2_kernel<1,", "h2_wgrad": "hw_kernel"}      # kernel-name prefixes in profiles/*_pmc_hconv.json
 
 
 def parse():
@@ -278,11 +278,14 @@ def main():
         nprod = PRODUCTS.get(fam)
         peak = PEAK_F16_MFMA_TFLOPS if nprod else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_src = None, None
-        if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_KEYS:
+        # the committed PMC passes were taken on the h-gate conv shape (tools/bench_hconv.py: M = 81920, N = 2048, K = 4608)
+        if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_PREFIX and \
+                (dom_key[1], dom_key[2], dom_key[3]) == (81920, 2048, 4608):
             for fn in ("r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
-                    traffic, traffic_src = round(pmc[PMC_KEYS[kind]]["hbm_side_bytes_per_launch"]), fn
+                    key = [k for k in pmc if k.startswith(PMC_PREFIX[kind])][0]
+                    traffic, traffic_src = round(pmc[key]["hbm_side_bytes_per_launch"]), fn
                     break
                 except Exception:
                     continue
@@ -300,7 +303,8 @@ def main():
             "frac": round(dom["tflops"] / peak, 4),
             "traffic": traffic,
             "traffic_note": (f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{traffic_src}); "
-                             "includes Infinity-Cache hits") if traffic else "no committed PMC pass for this kernel/shape",
+                             "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.75 GB "
+                             "(weight gradient) / 1.05 GB (forward)") if traffic else "no committed PMC pass for this kernel/shape",
             "kernel": f"{KERNEL_NAMES.get(kind, kind)}: implicit GEMM M={M} N={N} K={K} ({dom_key[4]} taps) -- the timed GEMM "
                       "kind+shape with the largest total time",
             "achieved_note": "ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMM the reference computes) / HIP-event launch time on the "

@@ -649,6 +649,21 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     }
     const int y_adv = 32 / p.Wo, x_adv = 32 - y_adv * p.Wo;      // advancing 32 output pixels = y_adv rows + x_adv columns
     const uint32_t xrow = (uint32_t)(4 * p.Ci);
+    // incremental form of the input pixel of this lane: (iy, ix) and its byte offset advance by scalar constants per K-tile
+    int b_iy[2], b_ix[2];
+    uint32_t b_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        b_iy[j] = b_y[j] * p.stride + b_dy[j];
+        b_ix[j] = b_x[j] * p.stride + b_dx[j];
+        b_off[j] = (uint32_t)((b_b[j] * p.Hi + b_iy[j]) * p.Wi + b_ix[j]) * xrow + (uint32_t)b_c8[j];
+    }
+    const int adv_ix = x_adv * p.stride, adv_iy = y_adv * p.stride;
+    const uint32_t adv_off = (uint32_t)(adv_iy * p.Wi + adv_ix) * xrow;
+    const int wrapx_ix = p.Wo * p.stride;                                            // x wrapped: ix -= Wo*stride, iy += stride
+    const uint32_t wrapx_off = (uint32_t)(p.stride * p.Wi - p.Wo * p.stride) * xrow;
+    const int wrapy_iy = p.Ho * p.stride;                                            // y wrapped into the next image
+    const uint32_t wrapy_off = (uint32_t)(p.Hi * p.Wi - p.Ho * p.stride * p.Wi) * xrow;
     int ld_kt = 0;
     auto issue_tile = [&](int stage) {
         if constexpr (!do_load) return;
@@ -665,15 +680,26 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.X);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int iy = b_y[j] * p.stride + b_dy[j], ix = b_x[j] * p.stride + b_dx[j];
-            const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const uint32_t off = (uint32_t)((b_b[j] * p.Hi + iy) * p.Wi + ix) * xrow + (uint32_t)b_c8[j];
-            SP_GLDS16(baseB + (ok ? off : p.x_bytes), st + HWA_BYTES + (wave + 8 * j) * 1024);
-            // advance this lane's pixel by 32 for the next K-tile (no divisions)
+            const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)b_iy[j] < (unsigned)p.Hi && (unsigned)b_ix[j] < (unsigned)p.Wi;
+            SP_GLDS16(baseB + (ok ? b_off[j] : p.x_bytes), st + HWA_BYTES + (wave + 8 * j) * 1024);
+            // advance this lane's pixel by 32 for the next K-tile (no divisions, no multiplications)
             b_x[j] += x_adv;
             b_y[j] += y_adv;
-            if (b_x[j] >= p.Wo) { b_x[j] -= p.Wo; ++b_y[j]; }
-            while (b_y[j] >= p.Ho) { b_y[j] -= p.Ho; ++b_b[j]; }
+            b_ix[j] += adv_ix;
+            b_iy[j] += adv_iy;
+            b_off[j] += adv_off;
+            if (b_x[j] >= p.Wo) {
+                b_x[j] -= p.Wo;
+                ++b_y[j];
+                b_ix[j] -= wrapx_ix;
+                b_iy[j] += p.stride;
+                b_off[j] += wrapx_off;
+            }
+            while (b_y[j] >= p.Ho) {
+                b_y[j] -= p.Ho;
+                b_iy[j] -= wrapy_iy;
+                b_off[j] += wrapy_off;
+            }
         }
         ++ld_kt;
     };

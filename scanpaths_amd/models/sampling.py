@@ -77,7 +77,8 @@ class Sampling():
     def beam_search(self, all_actions_prob, log_normal_mu, log_normal_sigma2, beam=4):
         """BASELINE.json config 5 ("beam-4 scanpath sampling"); build-side decoder, the reference only samples (:16-46).
         The ``beam`` most probable action sequences per sample under sum_t log p_t(a_t) (terminate ends a sequence, allowed
-        from t >= min_length) by csrc/sampling.hip ``beam_kernel``; durations are the medians of the predicted log-normals,
+        from t >= min_length; like any sum-of-log-probability decoder it prefers short scanpaths: every further fixation costs
+        log p < 0) by csrc/sampling.hip ``beam_kernel``; durations are the medians of the predicted log-normals,
         exp(mu) (random_sample's exp(eps*sigma2 + mu) at eps = 0).  Returns {"selected_actions" [B,beam,T] int64,
         "scores" [B,beam] float64 (log-probability, best first), "durations" [B,beam,T], "scanpath_length" [B,beam]}; feed
         ``selected_actions[:, k]`` / ``durations[:, k]`` to ``generate_scanpath`` for fixation vectors."""

@@ -79,13 +79,21 @@ def test_beam_search_matches_oracle_and_is_optimal():
     out = s.beam_search(probs, torch.zeros(B, T, device=DEV), torch.ones(B, T, device=DEV), beam=4)
     acts, sc = out["selected_actions"], out["scores"]
     assert (sc[:, :-1] >= sc[:, 1:]).all()
+    # optimality against one known candidate: the greedy path (per-step arg-max, ended by its first terminate).  The best
+    # sequence under sum-of-log-probabilities may well terminate earlier (every further step costs log p < 0), so beam 0 need
+    # not EQUAL the greedy path -- but it can never score below it
     pm = probs.clone()
     pm[:, 0, 0] = 0                    # terminate masked at t < min_length
-    greedy = pm.argmax(-1)
-    first0 = (greedy == 0).float().cumsum(1)
-    greedy = torch.where((first0 - (greedy == 0).float()) > 0, torch.zeros_like(greedy), greedy)     # zero after the first terminate
-    assert torch.equal(acts[:, 0], greedy)
+    gp, ga = pm.max(-1)
+    alive = ((ga == 0).float().cumsum(1) - (ga == 0).float()) == 0            # steps up to and including the first terminate
+    greedy_score = (gp.double().log() * alive).sum(1)
+    assert (sc[:, 0] >= greedy_score - 1e-9).all()
     assert (acts[:, 0] != acts[:, 1]).any(1).all()
+    # every returned sequence really has the score it claims
+    idx = acts.clamp(min=0)
+    lp = torch.gather(probs.unsqueeze(1).expand(B, 4, T, A), 3, idx.unsqueeze(-1)).squeeze(-1).double().log()
+    live = ((acts == 0).float().cumsum(2) - (acts == 0).float()) == 0
+    assert torch.allclose((lp * live).sum(2), sc, rtol=0, atol=1e-9)
     fix, am, dm = s.generate_scanpath(torch.zeros(B, 3, 2, 2, device=DEV), None, out["durations"][:, 0], acts[:, 0])
     assert len(fix) == B and am.shape == (B, T)
 
