@@ -308,7 +308,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
-    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2, do_lds = DBG != 3;
+    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2 && DBG != 9, do_lds = DBG != 3 && DBG != 9;      // DBG 9: loads only
+    constexpr bool do_bar = DBG != 3;
     int issued = 0;
     if (do_load)
         for (; issued < HNSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         else if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (do_lds) __builtin_amdgcn_s_barrier();
+        if constexpr (do_bar) __builtin_amdgcn_s_barrier();
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
@@ -585,6 +586,14 @@ __device__ __forceinline__ f16x8 tr_pair_h(const unsigned char* base, int off0, 
 __device__ __forceinline__ int rot4(int q) { return 2 * (q & 1) + 8 * (q >> 1); }
 template <bool M16>
 __device__ __forceinline__ int rotx(int r) { return rot4(r & 3) + (M16 ? 4 * ((r >> 3) & 1) : 0); }
+// 16x16x32 layout of hw_kernel: the stored position of source chunk j of pixel row r is  perm(j) ^ swz16(r), where perm moves the
+// channel-tile index i to the TOP bits of the position (so the four tiles of a wave sit 256 B apart and are reached through the
+// instruction's immediate offset: 2 + 4 address registers instead of 32) and swz16(r) in {0,2,..,14} only touches bits 1-3: the
+// 4 rows x 2 k-groups of a 32-lane half still cover all eight 32-byte slots of the bank row (SQ_LDS_BANK_CONFLICT = 0).
+__device__ __forceinline__ int swz16(int r) { return rot4(r & 3) + 4 * ((r >> 3) & 1); }
+__device__ __forceinline__ int permA16(int j) { return ((j & 0x0c) << 2) | ((j & 0x30) >> 2) | (j & 3); }            // [wm|i|pl|p] <-> [i|wm|pl|p], involution
+__device__ __forceinline__ int permB16(int j) { return ((j & 0x0c) << 1) | ((j & 0x10) >> 2) | (j & 3); }            // [wn|i1 i0|pl|p] -> [i1 i0|wn|pl|p]
+__device__ __forceinline__ int unpermB16(int x) { return ((x & 0x18) >> 1) | ((x & 0x04) << 2) | (x & 3); }
 
 // VAR: schedule of the two waves sharing a SIMD, as h2_kernel: 0 lockstep (round 1), 2 ping-pong with one barrier per K-tile
 // (waves 0-3: [issue loads(t+2)] [read(t)] [24 MFMA(t)]; waves 4-7: [24 MFMA(t-1)] [read(t)] [issue loads(t+2)]), 3 = 2 + s_setprio.
@@ -594,7 +603,9 @@ __device__ __forceinline__ int rotx(int r) { return rot4(r & 3) + (M16 ? 4 * ((r
 // DBG (env SP_HW_DBG, timing experiments only): 1 = no global loads, 2 = no MFMAs, 3 = MFMAs only (no loads, no LDS reads, no barriers)
 template <int VAR, int NPROD = 3, bool M16 = false, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
-    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2, do_lds = DBG != 3;
+    // DBG 5: LDS-DMA loads only (no fragment reads, no MFMAs; barriers kept); DBG 6: fragment reads only (no loads, no MFMAs)
+    constexpr bool do_load = DBG != 1 && DBG != 3 && DBG != 6, do_mma = DBG != 2 && DBG != 5 && DBG != 6, do_lds = DBG != 3 && DBG != 5;
+    constexpr bool do_bar = DBG != 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     for (int j = 0; j < 4; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 6, pos = g & 63;
-        const int js = (pos - rotx<M16>(r)) & 63;                // un-rotate: which source chunk lands here
+        const int js = M16 ? permA16(pos ^ swz16(r)) : ((pos - rot4(r & 3)) & 63);      // which source chunk lands at this position
         a_r[j] = r;
         a_cok[j] = co0 + (js >> 2) * 16 < p.Co;
         a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.Co) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     for (int j = 0; j < 2; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 5, pos = g & 31;
-        const int js = (pos - rotx<M16>(r)) & 31;
+        const int js = M16 ? unpermB16(pos ^ swz16(r)) : ((pos - rot4(r & 3)) & 31);
         const int col = n0 + (js >> 2) * 16;                      // first column of this lane's 16-channel group
         const int tap = col / p.Ci, ci = col - tap * p.Ci;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -717,11 +728,13 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 if constexpr (M16) {
-                    const int row = 8 * kg + 4 * s2 + q;
-                    const int ja = (wm * 4 + i) * 4 + pl * 2 + (pp >> 1);
-                    offA[i][pl][s2] = row * HWA_ROW + ((ja + rotx<true>(row)) & 63) * 16 + (pp & 1) * 8;
-                    const int jb = (wn * 4 + i) * 4 + pl * 2 + (pp >> 1);
-                    offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + ((jb + rotx<true>(row)) & 31) * 16 + (pp & 1) * 8;
+                    // base registers only for i < 2 (A: i = 0; B: i = 0, 1) and s2 = 0; the other tiles / the +4-row group are
+                    // constant byte offsets from them (A: i * 256, B: (i >> 1) * 256, s2: 4 rows), see swz16
+                    const int row = 8 * kg + q;
+                    const int pa = (((wm << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row));
+                    offA[i][pl][s2] = row * HWA_ROW + pa * 16 + (pp & 1) * 8 + i * 256 + s2 * 4 * HWA_ROW;
+                    const int pb = ((((i & 1) << 3) | (wn << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row));
+                    offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + pb * 16 + (pp & 1) * 8 + (i >> 1) * 256 + s2 * 4 * HWB_ROW;
                 } else {
                     const int row = 8 * h + 4 * s2 + q;
                     const int ja = (wm * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         if (kt_ + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (do_lds) __builtin_amdgcn_s_barrier();
+        if constexpr (do_bar) __builtin_amdgcn_s_barrier();
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
@@ -1175,6 +1188,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (dbg == 6) return f ? launch_h2<0, 1, 3, 3, true>(a, st) : launch_h2<1, 1, 3, 3, true>(a, st);      // no loads, 16x16x32 ping-pong
     if (dbg == 7) return f ? launch_h2<0, 2, 3, 3, true>(a, st) : launch_h2<1, 2, 3, 3, true>(a, st);      // no MFMAs
     if (dbg == 8) return f ? launch_h2<0, 3, 3, 3, true>(a, st) : launch_h2<1, 3, 3, 3, true>(a, st);      // MFMAs only
+    if (dbg == 9) return f ? launch_h2<0, 9, 3, 3, true>(a, st) : launch_h2<1, 9, 3, 3, true>(a, st);      // LDS-DMA loads only
     if (nprod == 1)      // throughput mode: load-bound, the ping-pong schedule
         return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
     int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
@@ -1246,6 +1260,8 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     else if (dbg == 2) rc = launch_hw<2, 3, true, 2>(a, d->Co, s);
     else if (dbg == 3) rc = launch_hw<2, 3, true, 3>(a, d->Co, s);
     else if (dbg == 4) rc = launch_hw<2, 3, false, 1>(a, d->Co, s);
+    else if (dbg == 5) rc = launch_hw<2, 3, true, 5>(a, d->Co, s);
+    else if (dbg == 6) rc = launch_hw<2, 3, true, 6>(a, d->Co, s);
     else if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);
     else switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
         case 0: rc = launch_hw<0>(a, d->Co, s); break;
