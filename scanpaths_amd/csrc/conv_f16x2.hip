@@ -669,6 +669,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         b_ix[j] = b_x[j] * p.stride + b_dx[j];
         b_off[j] = (uint32_t)((b_b[j] * p.Hi + b_iy[j]) * p.Wi + b_ix[j]) * xrow + (uint32_t)b_c8[j];
     }
+    const bool tiny_map = HoWo < 32;
     const int adv_ix = x_adv * p.stride, adv_iy = y_adv * p.stride;
     const uint32_t adv_off = (uint32_t)(adv_iy * p.Wi + adv_ix) * xrow;
     const int wrapx_ix = p.Wo * p.stride;                                            // x wrapped: ix -= Wo*stride, iy += stride
@@ -706,11 +707,17 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                 b_iy[j] += p.stride;
                 b_off[j] += wrapx_off;
             }
-            while (b_y[j] >= p.Ho) {
+            if (b_y[j] >= p.Ho) {           // maps of >= 32 pixels cross at most one image boundary per K-tile
                 b_y[j] -= p.Ho;
                 b_iy[j] -= wrapy_iy;
                 b_off[j] += wrapy_off;
             }
+            if (tiny_map)                   // scalar condition: pure-GEMM uses of the kernel (Ho*Wo < 32)
+                while (b_y[j] >= p.Ho) {
+                    b_y[j] -= p.Ho;
+                    b_iy[j] -= wrapy_iy;
+                    b_off[j] += wrapy_off;
+                }
         }
         ++ld_kt;
     };

@@ -1,7 +1,7 @@
 """Diagnostic: eval outputs of samples 0..1 at per-GPU batch 32 (320x512) vs the same samples at batch 2 vs the fp64 / fp32 oracle.
 Separates 'rounding noise of a random-weight net' from a large-batch bug."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import scanpath_oracle as O
 from scanpaths_amd import functional as F
 from scanpaths_amd.models.baseline_attention import baseline

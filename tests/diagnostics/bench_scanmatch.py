@@ -1,7 +1,7 @@
 """ScanMatch scoring throughput: the batched HIP Needleman-Wunsch against the oracle (numpy/python
 restatement of the reference's DP loop) on the validation-shaped workload -- 10 sampled scanpaths per image scored against
 the image's human scanpaths, evaluation configuration (320x240, 16x12 bins, TempBin 50, Threshold 3.5).
-    python tools/bench_scanmatch.py [--images 2000] [--humans 6] [--samples 10] [--cpu-pairs 40]
+    python tests/diagnostics/bench_scanmatch.py [--images 2000] [--humans 6] [--samples 10] [--cpu-pairs 40]
 Prints one JSON line."""
 import argparse
 import json
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

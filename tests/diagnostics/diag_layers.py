@@ -3,7 +3,7 @@ import sys, os
 import numpy as np
 import torch
 import torch.nn.functional as TF
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 from helpers import case_inputs, load_golden, max_err, oracle_state
 from test_model_gpu import _build, DEV

@@ -6,7 +6,7 @@ the oracle with a different thread count (different oneDNN summation order): how
 Writes gpurun_out/r02_noise_ratio.json."""
 import json, os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import scanpath_oracle as O
 from scanpaths_amd.models.scanpath_model import ScanpathModel
 from scanpaths_amd.procedural import fill_module, procedural_state_dict

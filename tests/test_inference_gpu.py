@@ -93,7 +93,7 @@ def test_eval_forward_hip_graph_replay_is_bit_identical():
 
 def test_hip_graph_replays_with_different_amplitudes_are_bit_identical_to_eager():
     """The fused-amax slots of the 2xfp16 operand scale (functional._amax_hint) are reset in stream order by the producing
-    launcher (common.h SP_RESET_AMAX: a memset node inside the captured graph), so a replay never sees max(old, new): three
+    launcher (common.h SP_RESET_AMAX: a one-thread kernel node inside the captured graph), so a replay never sees max(old, new): three
     replays on different inputs -- ordinary, x100 amplitude, then x0.01 (the case a stale maximum would ruin: a too-small
     scale loses the low plane) -- are each bit-identical to an eager forward on the same input."""
     from scanpaths_amd.models.baseline_attention import baseline
@@ -136,7 +136,7 @@ def test_full_size_eval_is_independent_of_batch_mates_and_normalised():
           run up to GEMM re-association (different tile / split-K decomposition and per-tensor operand scale): 1e-5 of scale;
     (ii)  the decoder outputs agree to 5e-2 of their scale -- loose on purpose: at this size the random-weight net cancels
           ~900-scale activations into ~2-scale logits, and the reference's OWN fp32 run is 7e-3 (relative) away from its fp64
-          run on these inputs (tools/batch_check.py: HIP bs32 8.7e-3, HIP bs2 2.3e-3, oracle fp32 7.4e-3); a coupling bug
+          run on these inputs (tests/diagnostics/batch_check.py: HIP bs32 8.7e-3, HIP bs2 2.3e-3, oracle fp32 7.4e-3); a coupling bug
           would be O(1);
     (iii) action probabilities are a distribution over the 1 + 40*64 actions, sigma2 > 0, everything finite;
     (iv)  two runs are bit-identical (no atomics in the data path)."""
