@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void sequences_kernel(const double* __restrict_
     const int sp = blockIdx.x * 64 + threadIdx.x;
     if (sp >= nsp) return;
     const double* f = fix + start[sp] * ncol;
-    int len = 0;
+    long long len = 0;
     for (int k = 0; k < count[sp]; ++k) {
         const int sym = symbol_of(f[k * ncol] - offx, f[k * ncol + 1] - offy, Xres, Yres, Xbin, Ybin, mask);
         long long reps = 1;
@@ -68,12 +68,13 @@ __global__ __launch_bounds__(64) void sequences_kernel(const double* __restrict_
             reps = (long long)rint((double)(long long)d / tempbin);     // numpy.round: half to even
             if (reps < 0) reps = 0;
         }
-        for (long long r = 0; r < reps; ++r) {
-            if (seq && len < ld) seq[(int64_t)sp * ld + len] = sym;
-            ++len;
+        if (seq) {                                    // write what fits; the count below is exact however long the fixation lasts
+            const long long room = len < ld ? min(reps, (long long)ld - len) : 0;
+            for (long long r = 0; r < room; ++r) seq[(int64_t)sp * ld + len + r] = sym;
         }
+        len += reps;                                  // (a heavy-tailed sampled duration must not spin a thread for 1e10 iterations)
     }
-    seq_len[sp] = len;
+    seq_len[sp] = (int)min(len, (long long)0x7fffffff);
 }
 
 // LONG = false: strip column and the A symbols live in LDS (sequences up to SM_MAXLEN symbols, every validation-shaped pair).

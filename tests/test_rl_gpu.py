@@ -91,6 +91,44 @@ def test_rl_step_end_to_end():
     assert info["same_reward_hmean"].shape == (4, N) and not m.training
 
 
+def test_rl_step_redraws_samples_with_non_finite_or_overlong_durations():
+    """exp(eps*sigma2 + mu) is heavy-tailed; an inf duration (the reference's int(round(inf)) raises there) or one beyond
+    the scorer's symbol cap must not abort the training step -- the sample is redrawn and counted in info["resamples"]"""
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.sampling import Sampling
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.rl import rl_step
+    from scanpaths_amd.synth import make_batch
+    from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch
+    from test_scanmatch_oracle import rl_case
+
+    class Spiky(Sampling):
+        """every first draw of a head carries one absurd duration"""
+        def random_sample(self, *a):
+            out = super().random_sample(*a)
+            self.n = getattr(self, "n", 0) + 1
+            if self.n in (1, 3):
+                d = out["durations"].clone()
+                d[0, 0] = float("inf") if self.n == 1 else 1e7
+                out["durations"] = d
+                out["selected_actions"][0, 0] = 5          # make sure the fixation is kept
+            return out
+
+    T, N = 4, 2
+    m = baseline(convLSTM_length=T)
+    fill_module(m, 6)
+    m = m.to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-5, weight_decay=5e-5, clip=12.5)
+    b = make_batch("AiR", N, 240, 320, T, seed=6)
+    gt, perf, _ = rl_case()
+    gt, perf = [gt[0], gt[3]], [perf[0], perf[3]]
+    cfg = dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), Threshold=3.5)
+    loss, info = rl_step(m, Spiky(convLSTM_length=T, min_length=1, seed=1), opt, b["images"].to(DEV), b["attention_maps"].to(DEV),
+                         gt, perf, ScanMatch(TempBin=50, **cfg), ScanMatch(**cfg), rl_sample_number=1)
+    assert info["resamples"] >= 2 and np.isfinite(float(loss))
+
+
 def test_eval_mode_backward_matches_oracle():
     """The RL phase differentiates the EVAL-mode forward (softmax heads, running-stat BatchNorm; AiR/train.py:244-251).  One
     decode step at 240x320: a weighted sum of the eval outputs and its parameter gradients against the fp64 oracle; bar =

@@ -113,6 +113,32 @@ def test_long_strings_against_the_oracle():
             assert v == SO.nw_score(seqs[i], seqs[j], S, gap), (gap, lens[i], lens[j])
 
 
+def test_sequences_beyond_the_lds_limit_use_the_global_scratch_kernel():
+    """A heavy-tailed sampled duration (RL phase) maps to more than sp_scanmatch_max_len() symbols: the scorer switches to the
+    global-scratch kernel (same arithmetic: bit-exact with the oracle) instead of raising; beyond MAX_SYMBOLS it raises
+    SequenceTooLong, which rl_step treats as a rejected sample."""
+    from scanpaths_amd import hip
+    from scanpaths_amd.utils.evaltools.scanmatch import MAX_SYMBOLS, SequenceTooLong
+    sm = _sm(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), TempBin=50, Threshold=3.5)
+    S = SO.submatrix(16, 12, 3.5)
+    g = np.random.Generator(np.random.PCG64(5))
+    limit = hip.lib().sp_scanmatch_max_len()
+    long_fix = np.stack([g.uniform(0, 320, 12), g.uniform(0, 240, 12), g.uniform(100, 600, 12)], 1)
+    long_fix[4, 2] = 230_000.0                               # one 230 s fixation -> 4600 symbols on its own
+    short_fix = np.stack([g.uniform(0, 320, 7), g.uniform(0, 240, 7), g.uniform(100, 600, 7)], 1)
+    seq, ln = sm.sequences([long_fix, short_fix])
+    assert int(ln[0]) > limit and seq.shape[1] > limit
+    got = sm.match_pairs(seq, ln, seq, ln, torch.tensor([(0, 1), (1, 0), (0, 0), (1, 1)], dtype=torch.int32)).cpu().numpy()
+    a = SO.fixation_to_sequence(long_fix, 320, 240, 16, 12, (0, 0), 50.0).astype(np.int32)
+    b = SO.fixation_to_sequence(short_fix, 320, 240, 16, 12, (0, 0), 50.0).astype(np.int32)
+    want = [SO.nw_score(a, b, S, 0.0), SO.nw_score(b, a, S, 0.0), SO.nw_score(a, a, S, 0.0), SO.nw_score(b, b, S, 0.0)]
+    assert list(got) == want
+    huge = long_fix.copy()
+    huge[4, 2] = 50.0 * (MAX_SYMBOLS + 10)
+    with pytest.raises(SequenceTooLong):
+        sm.sequences([huge])
+
+
 def test_custom_mask_and_errors():
     sm = _sm(Xres=64, Yres=48, Xbin=4, Ybin=3, Threshold=1.5)
     g = np.random.Generator(np.random.PCG64(3))
