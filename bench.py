@@ -326,7 +326,8 @@ def main():
                                   "frac_of_2500": round(tflop_per_img * value / world / PEAK_F16_MFMA_TFLOPS, 4),
                                   "note": "reduced-column FLOPs/img (BASELINE.md §3; train = 3x forward) x measured img/s per GPU"}
 
-    headline = args.task == "air" and args.mode == "train" and args.precision == "f32"
+    headline = (args.task == "air" and args.mode == "train" and args.precision == "f32" and args.batch == 32 and args.T == 16
+                and (args.height, args.width) == (320, 512) and args.arch == "resnet50")
     if headline:
         metric = "images/sec/GPU (AiR train step, bs=32, 320x512) at 1/2/4/8 MI355X"
     else:
