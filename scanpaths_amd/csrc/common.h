@@ -96,7 +96,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // workgroup each for the LDS-heavy GEMM kernels) cover 4 M-tiles x 8 N-tiles, so an XCD's L2 serves 4 activation panels and
 // 8 weight slices to 32 tiles (1.75 MB of operand per tile at K=4608) instead of 2 x 16 (2.2 MB).  Falls back to
 // n-fastest order when the grid is not a multiple of the super-tile.
-__device__ __forceinline__ void supertile_map(int lid, int tiles_m, int tiles_n, int& tm, int& tn) {
+// tall = true: 8 M-tiles x 4 N-tiles per XCD group instead of 4 x 8 -- for the channel-block-major K order, where consecutive
+// K-tiles re-read the same activation pixels (an activation panel costs ~1.5/9 of its bytes from beyond L2), so the weight slices
+// dominate the fabric traffic and fewer distinct N-tiles per group pay.
+__device__ __forceinline__ void supertile_map(int lid, int tiles_m, int tiles_n, int& tm, int& tn, bool tall = false) {
+    if (tall && (tiles_n & 3) == 0 && (tiles_m & 7) == 0) {
+        const int g = lid >> 5, w = lid & 31;
+        const int gn = tiles_n >> 2;
+        tm = (g / gn) * 8 + (w >> 2);
+        tn = (g % gn) * 4 + (w & 3);
+        return;
+    }
     if ((tiles_n & 7) == 0 && (tiles_m & 3) == 0) {
         const int g = lid >> 5, w = lid & 31;
         const int gn = tiles_n >> 3;

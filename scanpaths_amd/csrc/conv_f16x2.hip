@@ -31,7 +31,7 @@ constexpr int HB_BYTES = HBN * 128;              // 16384
 constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
 constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
-constexpr int H2_DEFAULT_VARIANT = 7;            // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
+constexpr int H2_DEFAULT_VARIANT = 15;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
 constexpr int HW_DEFAULT_VARIANT = 6;            // schedule variant of hw_kernel
 
 struct H2Args {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int tn, tmi;
-    supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn);
+    supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
     const int64_t m0 = (int64_t)tmi * HBM;
     const int n0 = tn * HBN;
     const int HoWo = p.Ho * p.Wo;

@@ -142,6 +142,9 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         if _lib.sp_abi_version() != 1:
             raise RuntimeError("libscanpaths_amd.so ABI version mismatch")
+        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant")):      # A/B timing / profiling only
+            if os.environ.get(env):
+                check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib
 
 

@@ -336,16 +336,26 @@ class ScanpathModel(nn.Module):
         sp_list: List[torch.Tensor] = []
         se_list: List[torch.Tensor] = []
 
+        def rep(t, n):
+            """n aliases of a tensor that every decode step (or memory push) uses once: its T (+1) gradient contributions are
+            summed by ONE sp_sum_n pass instead of T small read-read-write adds that autograd would launch one by one"""
+            return list(F.fanout(t, n)) if (t is not None and t.requires_grad and 1 < n <= 32) else [t] * n
+
+        spw, spb = rep(self.spatial_embed.weight, T + 1), rep(self.spatial_embed.bias, T + 1)
+        sew, seb = rep(self.semantic_embed.weight, T + 1), rep(self.semantic_embed.bias, T + 1)
+        mvfs, u_spas, u_sems = rep(mvf, T + 1), rep(u_spa, T + 1), rep(u_sem, T + 1)
+        Wrs = [rep(w, T) for w in Wr]
+        Wsals, W11s, cbsums, cbs, w2s, b2s = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T), rep(w2, T), rep(b2, T)
+
         def push(amaps):          # amaps [S,B,P]; memory update :277-296 / :317-336
-            spf = F.mul_relu(amaps, mvf)
-            sp_list.append(F.linear(spf.view(S * B, P), self.spatial_embed.weight, self.spatial_embed.bias))
+            spf = F.mul_relu(amaps, mvfs.pop())
+            sp_list.append(F.linear(spf.view(S * B, P), spw.pop(), spb.pop()))
             vf3 = vfs.pop().view(B, P, Cc)
             pooled = F.semantic_pool(amaps, vf3) if (S <= 2 and Cc <= 512) else \
                 F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
-            se_list.append(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), self.semantic_embed.weight,
-                                    self.semantic_embed.bias))
-            sp_mem = F.list_attention(torch.stack(sp_list, 0), u_spa)        # [S*B,P]
-            se_mem = F.list_attention(torch.stack(se_list, 0), u_sem)        # [S*B,C]
+            se_list.append(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop()))
+            sp_mem = F.list_attention(torch.stack(sp_list, 0), u_spas.pop())        # [S*B,P]
+            se_mem = F.list_attention(torch.stack(se_list, 0), u_sems.pop())        # [S*B,C]
             return sp_mem, se_mem
 
         a0 = attention_maps.reshape(1, B, P).to(torch.float32)
@@ -357,7 +367,7 @@ class ScanpathModel(nn.Module):
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t in range(T):
             se = se_mem.view(S, B, Cc)
-            parts = [F.gemm(se[s], Wr[s], None, "nk").view(B, 3 * 512, 9) for s in range(S)]
+            parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk").view(B, 3 * 512, 9) for s in range(S)]
             wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
             hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache) if h is not None else None        # step 0: h == 0
@@ -365,9 +375,10 @@ class ScanpathModel(nn.Module):
             # h has three consumers (two heads now, the h-gate conv of the next step): one fan-in pass for its gradient
             nuse = 3 if t + 1 < T else 2
             h_sal, h_drt, h = (tuple(F.fanout(h, nuse)) + (None,))[:3] if h.requires_grad else (h, h, h)
-            Z2 = F.sal_gather(F.conv2d(h_sal, Wsal, None, pad=0), hmap, nh, nsrc)
-            Dpre = F.drt_direct(h_drt, W11, cbsum, hmap, nh)
-            logits, amap, mu, s2 = F.head_finish(Z2, cb, w2, b2, nh, HC, not self.training, per_sample=per_sample, dpre=Dpre)
+            Z2 = F.sal_gather(F.conv2d(h_sal, Wsals.pop(), None, pad=0), hmap, nh, nsrc)
+            Dpre = F.drt_direct(h_drt, W11s.pop(), cbsums.pop(), hmap, nh)
+            logits, amap, mu, s2 = F.head_finish(Z2, cbs.pop(), w2s.pop(), b2s.pop(), nh, HC, not self.training,
+                                                 per_sample=per_sample, dpre=Dpre)
             outs["logits"].append(logits)
             outs["amap"].append(amap)
             outs["mu"].append(mu)
