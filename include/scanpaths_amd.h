@@ -127,6 +127,14 @@ int sp_conv_igemm_f16x1(const sp_conv_desc* d, const void* Xsplit, const float* 
                         const float* bias, float* out, void* stream);
 int sp_conv_wgrad_f16x1(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                         const float* y_scale, float* dW, void* workspace, void* stream);
+/* One ConvLSTM step (t >= 1) with the cell fused into the epilogue of the h-gate conv (reference: models/baseline_attention.py
+ * ConvLSTM cell :88-118 as restated in SURVEY.md §8a; replaces sp_conv_igemm_f16x2 + sp_lstm_rank1_fwd):
+ *   pre = conv(h_prev, Wh) + xg + [spcol x wc] (i, f, o gates);  gates = sigmoid(i, f, o), tanh(g);  c = f*c_prev + i*g;  h = o*c
+ * d: mode 0, stride 1, Kc = C, Nout = 4C (gate-major weight rows i, f, o, g), Ho x Wo = Hi x Wi = P pixels, P % 256 == 0, KP <= 32.
+ * xg / gates [B*P][4C], c_prev / c_out / h_out [B*P][C], spcol [B*P][KP], wc [B][3C][KP]; h_amax may be NULL. */
+int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hsplit, const float* h_scale, const void* Wsplit, const float* w_scale,
+                           const float* xg, const float* c_prev, const float* spcol, const float* wc, int P, int KP, float* gates,
+                           float* c_out, float* h_out, unsigned* h_amax, void* stream);
 
 
 /* column sums of a row-major [M][C] matrix (ld = row stride): out[c] = beta*out[c] + sum_m x[m][c]

@@ -50,6 +50,16 @@ struct H2Args {
     float alpha;
     int beta, relu;
     uint32_t x_bytes, w_bytes;
+    // LSTM epilogue (h2_kernel<..., LSTM = true>): the GEMM is the h-gate conv of the ConvLSTM, Nout = 4 * lC gate columns
+    const float* l_xg;      // [M][4][lC]  x-gate pre-activations (gate-major columns i, f, o, g)
+    const float* l_cprev;   // [M][lC]
+    const float* l_spcol;   // [M][lKP]    taps of the spatial memory maps
+    const float* l_wc;      // [B][3 lC][lKP] per-sample contracted filter of the rank-1 gate term
+    float* l_gates;         // [M][4][lC]  activated gates
+    float* l_c;             // [M][lC]
+    float* l_h;             // [M][lC]
+    unsigned* l_hamax;      // max |h| (float bits), reset by the launcher
+    int lC, lP, lKP;
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
@@ -79,8 +89,17 @@ struct H2Args {
 // being re-fetched from the Infinity Cache / HBM side per tap.  Per loader lane: the byte offset of its pixel at tap (0,0) and a
 // bit mask of the taps that fall inside the image; the tap's offset is one scalar per K-tile.  Needs KH*KW <= 32 and (dgrad)
 // stride 1; the sum order over K differs from the tap-major build, so results agree to rounding, not bitwise.
-template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false>
+// LSTM (forward, M16 only): the GEMM is the h-gate conv of the ConvLSTM and the epilogue is the whole cell.  The 128 weight rows of a
+// workgroup are gathered as  4 gates x 32 channels  (tile row r -> gate (r>>4)&3, channel c0 + 16*(r>>6) + (r&15)): no data is
+// permuted, only the loader's row address, and a lane then holds the four gate pre-activations of ONE channel for its 16 pixels
+// in acc4[i][0..3].  Epilogue: + x-gate term + rank-1 gate term (spcol x wc, staged in the now idle LDS), sigmoid/tanh, cell and
+// hidden state, max|h| -- the [M][4C] h-gate tensor (42 MB per decode step at the benchmark size) is never written or re-read.
+// Needs P % 256 == 0 (a 256-pixel tile lies inside one sample: one filter slice per workgroup), C % 32 == 0, KP <= 32.
+__device__ __forceinline__ float h2_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }      // = decoder.hip sigmoidf_
+
+template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
+    static_assert(!LSTM || (M16 && MODE == 0), "the LSTM epilogue is written for the forward 16x16x32 build");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -92,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     int tn, tmi;
     supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
     const int64_t m0 = (int64_t)tmi * HBM;
-    const int n0 = tn * HBN;
+    const int n0 = LSTM ? tn * 32 : tn * HBN;          // LSTM: first CHANNEL of the tile
     const int HoWo = p.Ho * p.Wo;
 
     // ---- loader mapping: LDS chunk g = t + 512 j -> row g/8, position g%8; source chunk = position ^ swizzle(row) ----
@@ -125,8 +144,14 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         const int idx = t + 512 * j;
         const int row = idx >> 3, pos = idx & 7;
         const int c8 = (pos ^ ((row >> 1) & 7)) * 16;
-        b_ok[j] = (n0 + row) < p.Nout;
-        b_voff[j] = b_ok[j] ? (uint32_t)((int64_t)(n0 + row) * p.ldwb + c8) : 0u;
+        if constexpr (LSTM) {
+            const int ch = n0 + (row >> 6) * 16 + (row & 15);
+            b_ok[j] = ch < p.lC;
+            b_voff[j] = b_ok[j] ? (uint32_t)((int64_t)(((row >> 4) & 3) * p.lC + ch) * p.ldwb + c8) : 0u;
+        } else {
+            b_ok[j] = (n0 + row) < p.Nout;
+            b_voff[j] = b_ok[j] ? (uint32_t)((int64_t)(n0 + row) * p.ldwb + c8) : 0u;
+        }
     }
     int ld_ky = 0, ld_kx = 0, ld_cblk = 0, ld_kt = 0;
     uint32_t a_voff[4];
@@ -501,6 +526,72 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
     const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
+    if constexpr (LSTM) {
+        // every LDS read of the K loop was waited for before its last barrier (the late waves multiply from registers): the ring is free
+        const int KP = p.lKP, C = p.lC;
+        const int WST = KP + 1;                                   // odd-ish stride: the 16 channel lanes hit distinct banks
+        float* sp_s = reinterpret_cast<float*>(smem);             // [256][KP]
+        float* wc_s = sp_s + HBM * KP;                            // [3][32][WST]
+        const int b = (int)(m0 / p.lP);
+        for (int i = t; i < HBM * KP; i += 512) sp_s[i] = (m0 + i / KP) < p.M ? p.l_spcol[m0 * KP + i] : 0.f;
+        for (int i = t; i < 96 * KP; i += 512) {
+            const int k = i % KP, qj = i / KP;                    // qj = gate * 32 + channel
+            const int ch = n0 + (qj & 31);
+            wc_s[qj * WST + k] = ch < C ? p.l_wc[((int64_t)b * 3 * C + (qj >> 5) * C + ch) * KP + k] : 0.f;
+        }
+        __syncthreads();
+        const int cl = wn * 16 + l16, ch = n0 + cl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tot4[i][q][r] = ((tot4[i][q][r] + acc4[i][q][r]) * isx) * isw;
+        for (int k = 0; k < KP; ++k) {
+            const float w0 = wc_s[cl * WST + k], w1 = wc_s[(32 + cl) * WST + k], w2 = wc_s[(64 + cl) * WST + k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = sp_s[(wm * 64 + i * 16 + 4 * g4 + r) * KP + k];
+                    tot4[i][0][r] += sv * w0;
+                    tot4[i][1][r] += sv * w1;
+                    tot4[i][2][r] += sv * w2;
+                }
+        }
+        float hmx = 0.f;
+        if (ch < C) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                    if (m >= p.M) continue;
+                    const float* px = p.l_xg + m * 4 * C + ch;
+                    const float gi = h2_sigmoid(tot4[i][0][r] + px[0]);
+                    const float gf = h2_sigmoid(tot4[i][1][r] + px[C]);
+                    const float go = h2_sigmoid(tot4[i][2][r] + px[2 * C]);
+                    const float gg = tanhf(tot4[i][3][r] + px[3 * C]);
+                    const float cp = p.l_cprev ? p.l_cprev[m * C + ch] : 0.f;
+                    const float cn = gf * cp + gi * gg;
+                    const float hn = go * cn;
+                    float* pg = p.l_gates + m * 4 * C + ch;
+                    pg[0] = gi;
+                    pg[C] = gf;
+                    pg[2 * C] = go;
+                    pg[3 * C] = gg;
+                    p.l_c[m * C + ch] = cn;
+                    p.l_h[m * C + ch] = hn;
+                    hmx = fmaxf(hmx, fabsf(hn));
+                }
+        }
+        if (p.l_hamax) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) hmx = fmaxf(hmx, __shfl_xor(hmx, off));
+            if (lane == 0 && hmx > 0.f) atomicMax(p.l_hamax, __float_as_uint(hmx));
+        }
+        return;
+    }
     if constexpr (M16) {
         // C/D layout of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -1091,9 +1182,9 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
-template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false>
+template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false>
 int launch_h2(const H2Args& a, hipStream_t s) {
-    auto kern = h2_kernel<MODE, DBG, VAR, NPROD, M16, CBM>;
+    auto kern = h2_kernel<MODE, DBG, VAR, NPROD, M16, CBM, LSTM>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HSTAGE);
@@ -1169,7 +1260,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (d->Kc % 32 || d->ldx != d->Kc) return SP_EINVAL;      // a 32-k K-tile must lie inside one filter tap
     if (((uintptr_t)Xs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
-    H2Args a;
+    H2Args a{};
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
     a.sx = x_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * d->Ho * d->Wo;
@@ -1228,6 +1319,42 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
 extern "C" int sp_conv_igemm_f16x1(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
                                    const float* w_scale, const float* bias, float* out, void* stream) {
     return conv_igemm_f16(d, Xs, x_scale, Ws, w_scale, bias, out, stream, 1);
+}
+
+// ConvLSTM step with the cell fused into the h-gate conv (h2_kernel<..., LSTM>):
+//   pre = conv3x3(h_prev, Wh) + xg + [spcol x wc]_{i,f,o};  gates = (sigmoid i, f, o; tanh g);  c = f c_prev + i g;  h = o c
+// d describes the conv (mode 0, 3x3, Kc = C, Nout = 4C, ldc ignored).  Reference: models/baseline_attention.py ConvLSTM cell
+// (SURVEY.md §8a); replaces sp_conv_igemm_f16x2 + sp_lstm_rank1_fwd for steps t >= 1.
+extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, const float* h_scale, const void* Ws,
+                                      const float* w_scale, const float* xg, const float* c_prev, const float* spcol,
+                                      const float* wc, int P, int KP, float* gates, float* c_out, float* h_out, unsigned* h_amax,
+                                      void* stream) {
+    if (!d || !Hs || !Ws || !h_scale || !w_scale || !xg || !spcol || !wc || !gates || !c_out || !h_out) return SP_ENULL;
+    if (d->mode != 0 || d->Kc % 32 || d->ldx != d->Kc || d->nbatch != 1 || d->stride != 1 || d->dil < 1) return SP_EINVAL;
+    if (d->Nout != 4 * d->Kc || d->Ho != d->Hi || d->Wo != d->Wi || d->KH * d->KW < 2 || d->KH * d->KW > 32) return SP_EINVAL;
+    if (P != d->Ho * d->Wo || P % HBM || KP < 1 || KP > 32) return SP_EINVAL;
+    if (((uintptr_t)Hs | (uintptr_t)Ws) & 15) return SP_EINVAL;
+    H2Args a{};
+    a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
+    a.sx = h_scale; a.sw = w_scale;
+    a.M = (int64_t)d->N_img * P;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->Nout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
+    a.ldwb = 4 * (int64_t)d->KH * d->KW * d->Kc;
+    a.ncblk = d->Kc / 32;
+    a.nkt = d->KH * d->KW * a.ncblk;
+    a.tiles_n = d->Kc / 32;
+    a.alpha = 1.f; a.beta = 0; a.relu = 0;
+    const int64_t xb = 4LL * a.M * d->Kc, wb = 4LL * d->Nout * d->KH * d->KW * d->Kc;
+    if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32) || a.M <= 0) return SP_EINVAL;
+    a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
+    a.l_xg = xg; a.l_cprev = c_prev; a.l_spcol = spcol; a.l_wc = wc;
+    a.l_gates = gates; a.l_c = c_out; a.l_h = h_out; a.l_hamax = h_amax;
+    a.lC = d->Kc; a.lP = P; a.lKP = KP;
+    hipStream_t st = (hipStream_t)stream;
+    SP_RESET_AMAX(h_amax, st);
+    return launch_h2<0, 0, 3, 3, true, true, true>(a, st);
 }
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {

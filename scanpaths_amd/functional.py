@@ -419,45 +419,49 @@ class _Conv2d(Function):
         x, wp, y, xs_buf, xs_scale = ctx.saved_tensors
         xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
         dy = dy.contiguous()
-        N, H, W_, Ci = x.shape
-        Co, KH, KW, _ = wp.shape
-        _, Ho, Wo, _ = dy.shape
         if relu:
             dyr = torch.empty_like(dy)
             check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
             dy = dyr
-        dx = dw = db = None
-        dys = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel()):
-                dys = split_op(dy)
-                wcache = ctx.wcache
-                wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
-                if wT is None:
-                    wT = split_op_wT(wp, dys.scheme)
-                    if wcache is not None:
-                        wcache[("wT", dys.scheme)] = wT
-                _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
-                          ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
-            else:
-                _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
-                       KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
-        if ctx.needs_input_grad[1]:
-            dwp = torch.empty_like(wp)
-            wsch = _wgrad_scheme(Ci, Co)
-            free = xs is not None and (dys is not None and dys.scheme == wsch)
-            if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=free):
-                _wgrad_b3(xs if xs is not None else split_op(x, wsch),
-                          dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch), dwp, N_img=N, Hi=H,
-                          Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
-            else:
-                _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
-                       KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
-            dw = dwp.permute(0, 3, 1, 2)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum_any(dy, Co)
+        dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = _colsum_any(dy, wp.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None, None
+
+
+def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw):
+    """data and weight gradient of y = conv(x, wp) (NHWC, physical weight [Co,KH,KW,Ci]); xs: the forward's split x or None"""
+    N, H, W_, Ci = x.shape
+    Co, KH, KW, _ = wp.shape
+    _, Ho, Wo, _ = dy.shape
+    dx = dw = None
+    dys = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel()):
+            dys = split_op(dy)
+            wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
+            if wT is None:
+                wT = split_op_wT(wp, dys.scheme)
+                if wcache is not None:
+                    wcache[("wT", dys.scheme)] = wT
+            _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
+                      ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+        else:
+            _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
+                   KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+    if need_dw:
+        dwp = torch.empty_like(wp)
+        wsch = _wgrad_scheme(Ci, Co)
+        free = xs is not None and (dys is not None and dys.scheme == wsch)
+        if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=free):
+            _wgrad_b3(xs if xs is not None else split_op(x, wsch),
+                      dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch), dwp, N_img=N, Hi=H,
+                      Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
+        else:
+            _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
+                   KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
+        dw = dwp.permute(0, 3, 1, 2)
+    return dx, dw
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None):
@@ -831,40 +835,119 @@ class _LstmCellRank1(Function):
     @staticmethod
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc = ctx.saved_tensors
-        dh = dh.contiguous() if dh is not None else None
-        dc = dc.contiguous() if dc is not None else None
-        B, P, KP = spcol.shape
-        C4 = gates.shape[-1]
-        Cc = C4 // 4
-        N3 = 3 * Cc
-        rows = gates.numel() // C4
-        dpre = torch.empty_like(gates)
-        dcp = torch.empty_like(c)
-        hint = _amax_hint(gates.device)
-        check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
-                                              ptr(dcp), _hint_ptr(hint), hip.stream()), "sp_lstm_pointwise_bwd")
-        if hint is not None:
-            dpre._sp_amax = hint
-        dsp = dwc = None
-        if ctx.needs_input_grad[3]:
-            dsp = torch.empty_like(spcol)
-            _igemm(dpre, wc, None, dsp, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1,
-                   nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
-        if ctx.needs_input_grad[4]:
-            dwc = torch.empty_like(wc)
-            L = hip.lib()
-            if KP <= 24:
-                ws = hip.workspace(L.sp_rank1_dwc_workspace(B, P, N3, KP), dpre.device, slot=0)
-                check(L.sp_rank1_dwc(ptr(dpre), ptr(spcol), B, P, C4, N3, KP, ptr(ws), ptr(dwc), hip.stream()), "sp_rank1_dwc")
-            else:
-                _wgrad(spcol, dpre, dwc, N_img=P, Hi=1, Wi=1, Ci=KP, ldx=KP, Ho=1, Wo=1, Co=N3, ldy=C4, ldo=KP, nbatch=B,
-                       sX=P * KP, sY=P * C4, sO=N3 * KP)
+        dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[3],
+                                                   ctx.needs_input_grad[4])
         has_hg, has_c = ctx.has
         return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
 
 
+def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc):
+    """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint), c_prev, spcol and wc"""
+    dh = dh.contiguous() if dh is not None else None
+    dc = dc.contiguous() if dc is not None else None
+    B, P, KP = spcol.shape
+    C4 = gates.shape[-1]
+    Cc = C4 // 4
+    N3 = 3 * Cc
+    rows = gates.numel() // C4
+    dpre = torch.empty_like(gates)
+    dcp = torch.empty_like(c)
+    hint = _amax_hint(gates.device)
+    check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
+                                          ptr(dcp), _hint_ptr(hint), hip.stream()), "sp_lstm_pointwise_bwd")
+    if hint is not None:
+        dpre._sp_amax = hint
+    dsp = dwc = None
+    if need_dsp:
+        dsp = torch.empty_like(spcol)
+        _igemm(dpre, wc, None, dsp, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1,
+               nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
+    if need_dwc:
+        dwc = torch.empty_like(wc)
+        L = hip.lib()
+        if KP <= 24:
+            ws = hip.workspace(L.sp_rank1_dwc_workspace(B, P, N3, KP), dpre.device, slot=0)
+            check(L.sp_rank1_dwc(ptr(dpre), ptr(spcol), B, P, C4, N3, KP, ptr(ws), ptr(dwc), hip.stream()), "sp_rank1_dwc")
+        else:
+            _wgrad(spcol, dpre, dwc, N_img=P, Hi=1, Wi=1, Ci=KP, ldx=KP, Ho=1, Wo=1, Co=N3, ldy=C4, ldo=KP, nbatch=B,
+                   sX=P * KP, sY=P * C4, sO=N3 * KP)
+    return dpre, dcp, dsp, dwc
+
+
 def lstm_cell_rank1(xg, hg, c_prev, spcol, wc):
     return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc)
+
+
+FUSE_GATE_LSTM = os.environ.get("SP_FUSE_LSTM", "1") != "0"
+
+
+def gateconv_lstm_fusable(h, w_h, spcol) -> bool:
+    """the fused h-gate conv + cell kernel (sp_gateconv_lstm_f16x2) applies: 2xfp16 back-end, 3x3 stride-1 gate conv on
+    C % 32 == 0 channels, P % 256 == 0 pixels per sample (a 256-pixel tile inside one sample), KP <= 32"""
+    if not (FUSE_GATE_LSTM and USE_BF16X3 and not THROUGHPUT_MODE and h is not None):
+        return False
+    N, H, W_, Ci = h.shape
+    B, P, KP = spcol.shape
+    Co, _, KH, KW = w_h.shape
+    return (_scheme_for(Ci) == "f16x2" and Ci % 32 == 0 and Co == 4 * Ci and (KH, KW) == (3, 3) and P == H * W_
+            and P % 256 == 0 and KP <= 32 and _b3_pays(N * P, Co, 9 * Ci, Ci, a_elems=h.numel(), free_a=True))
+
+
+class _GateConvLstm(Function):
+    """One ConvLSTM step t >= 1 in ONE kernel: the cell (with the rank-1 gate term) is the epilogue of the h-gate conv
+    (sp_gateconv_lstm_f16x2), so the [B,Hm,Wm,4C] h-gate tensor is never materialised.  Backward = _LstmCellRank1's followed by
+    _Conv2d's (same kernels as the unfused pair)."""
+    @staticmethod
+    def forward(ctx, h_prev, w_h, xg, c_prev, spcol, wc, wcache):
+        h_prev, xg, c_prev = h_prev.contiguous(), xg.contiguous(), c_prev.contiguous()
+        spcol, wc = spcol.contiguous(), wc.contiguous()
+        N, H, W_, Ci = h_prev.shape
+        B, P, KP = spcol.shape
+        wp = _phys(w_h.detach())
+        Co, KH, KW, _ = wp.shape
+        assert xg.numel() == B * P * Co and wc.shape == (B, 3 * Ci, KP) and N == B, (xg.shape, spcol.shape, wc.shape)
+        xs = split_op(h_prev)
+        wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
+        if wsplit is None:
+            wsplit = split_op(wp, xs.scheme)
+            if wcache is not None:
+                wcache[("w", xs.scheme)] = wsplit
+        gates = torch.empty_like(xg)
+        c = torch.empty_like(c_prev)
+        h = torch.empty_like(c_prev)
+        hint = _amax_hint(xg.device)
+        d = ConvDesc(N, H, W_, Ci, Ci, H, W_, Co, Co, KH, KW, 1, 1, 1, 0, KH * KW * Ci, 1.0, 0, 0, 1, 0, 0, 0, 0, None)
+
+        def launch():
+            check(hip.lib().sp_gateconv_lstm_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(wsplit.buf), ptr(wsplit.scale),
+                                                   ptr(xg), ptr(c_prev), ptr(spcol), ptr(wc), P, KP, ptr(gates), ptr(c), ptr(h),
+                                                   _hint_ptr(hint), hip.stream()), "sp_gateconv_lstm_f16x2")
+        if hip.TIMER is None:
+            launch()
+        else:
+            hip.TIMER.bracket(("h2_fwd", N * P, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * N * P * Co * KH * KW * Ci, launch)
+        if hint is not None:
+            h._sp_amax = hint
+        h._sp_cache = {}
+        keep = ctx.needs_input_grad[1] and _w3_pays(N * P, Co, KH * KW * Ci, Ci, free_splits=True) \
+            and xs.scheme == _wgrad_scheme(Ci, Co)
+        ctx.xs_scheme = xs.scheme if keep else None
+        ctx.wcache = wcache
+        ctx.save_for_backward(gates, c_prev, c, spcol, wc, h_prev, wp, xs.buf if keep else None, xs.scale if keep else None)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, c, spcol, wc, h_prev, wp, xs_buf, xs_scale = ctx.saved_tensors
+        dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
+                                                   ctx.needs_input_grad[5])
+        xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
+        dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dhp, dw, dpre, dcp, dsp, dwc, None
+
+
+def gateconv_lstm(h_prev, w_h, xg, c_prev, spcol, wc, wcache=None):
+    return _GateConvLstm.apply(h_prev, w_h, xg, c_prev, spcol, wc, wcache)
 
 
 class _Im2col(Function):

@@ -370,8 +370,11 @@ class ScanpathModel(nn.Module):
             parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk").view(B, 3 * 512, 9) for s in range(S)]
             wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
-            hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache) if h is not None else None        # step 0: h == 0
-            h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc)
+            if F.gateconv_lstm_fusable(h, Wh, spcol):       # the cell as the epilogue of the h-gate conv: no h-gate tensor
+                h, c = F.gateconv_lstm(h, Wh, Xg_t[t], c, spcol, wc, wh_cache)
+            else:
+                hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache) if h is not None else None        # step 0: h == 0
+                h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc)
             # h has three consumers (two heads now, the h-gate conv of the next step): one fan-in pass for its gradient
             nuse = 3 if t + 1 < T else 2
             h_sal, h_drt, h = (tuple(F.fanout(h, nuse)) + (None,))[:3] if h.requires_grad else (h, h, h)

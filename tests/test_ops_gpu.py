@@ -192,12 +192,14 @@ def test_maxpool_ceil_with_ties(hw):
     _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-6, "dx")
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "epilogue"])
 def test_lstm_cell_and_gate_conv(fused):
-    """fused=False: rank-1 gate terms accumulated by the batched GEMM of gate_conv; fused=True: the path the model uses --
-    plain h-conv + lstm_cell_rank1 (rank-1 terms inside the pointwise kernel; 135 pixels = 2 full 64-pixel tiles + a tail)"""
+    """fused=False: rank-1 gate terms accumulated by the batched GEMM of gate_conv; fused=True: plain h-conv + lstm_cell_rank1
+    (rank-1 terms inside the pointwise kernel; 135 pixels = 2 full 64-pixel tiles + a tail: the path of map sizes whose pixel
+    count is no multiple of 256); "epilogue": the whole cell as the epilogue of the h-gate conv (sp_gateconv_lstm_f16x2, the
+    path of the 40x64 benchmark map; 3 samples x 256 pixels, 96 channels = 3 channel tiles of the gathered weight rows)"""
     from scanpaths_amd import functional as F
-    B, Hm, Wm, C, S = (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
+    B, Hm, Wm, C, S = (3, 16, 16, 96, 2) if fused == "epilogue" else (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
     KP = 20
     h, c = _rand(B, C, Hm, Wm, seed=24), _rand(B, C, Hm, Wm, seed=25)
     xg = _rand(B, 4 * C, Hm, Wm, seed=26)
@@ -232,7 +234,10 @@ def test_lstm_cell_and_gate_conv(fused):
         parts.append(F.gemm(seg[s], wflat, None, "nk").view(B, 3 * C, 9))
     wc = torch.cat(parts + [torch.zeros(B, 3 * C, KP - 9 * S, device=dev)], 2)
     spcol = F.im2col3x3(spg, KP)
-    if fused:
+    if fused == "epilogue":
+        hn, cn = F.gateconv_lstm(hg_, whg, xgg, cg_, spcol, wc, {})
+        assert float(hn._sp_amax[1]) == float(hn.abs().max())          # fused max|h| hint (float bits in slot 1)
+    elif fused:
         hn, cn = F.lstm_cell_rank1(xgg, F.conv2d(hg_, whg, None, pad=1), cg_, spcol, wc)
     else:
         hgate = F.gate_conv(hg_, whg, spcol, wc, (Hm, Wm))
