@@ -119,6 +119,12 @@ int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xsplit, const float* 
 int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d);
 int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                         const float* y_scale, float* dW, void* workspace, void* stream);
+/* forward conv whose epilogue also writes the first reduction stage of the BatchNorm behind it (per 256-row tile and output column:
+ * sum, sum of squares in fp64; min, max in fp32): st_partial [tiles][2][Nout], st_mm [tiles][2][Nout], tiles = sp_conv_stats_tiles(M).
+ * No bias / relu / beta.  models/resnet.py:57-93 (conv -> bn). */
+int64_t sp_conv_stats_tiles(int64_t M);
+int sp_conv_igemm_f16x2_stats(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit,
+                              const float* w_scale, float* out, double* st_partial, float* st_mm, void* stream);
 /* THROUGHPUT MODE (SURVEY.md §7 hard part 1 / BASELINE.md §4 "bf16-MFMA mode", reported separately from the fp32-faithful
  * headline): the same kernels on the same split-2 operands with only the main product a1*b1, i.e. both operands rounded to ONE
  * fp16 plane (per-tensor power-of-two scale), fp32 accumulation, a third of the MFMA work.  Does NOT meet the 1e-4 parity bar
@@ -167,6 +173,26 @@ int sp_bn_backward(const float* dy, const float* x, const float* y, const float*
                    const float* gamma, int relu, int training, int64_t M, int C, float* dx, float* dres,
                    float* dgamma, float* dbeta, void* workspace,
                    unsigned* dx_amax /* nullable, as y_amax */, void* stream);
+
+/* Train-mode BatchNorm that also EMITS the 2xfp16 split operand of the consumer conv (layout of sp_split2_f16) and keeps the ReLU
+ * mask as one bit per element -- same arithmetic as sp_bn_stats + sp_bn_apply / sp_bn_backward (models/resnet.py:29-46,63-90),
+ * one HBM pass fewer per direction.  The operand scale comes from an upper bound of max|output| (per-channel extrema of x through
+ * the affine map, + max|residual|; backward: |gamma*invstd|*(max|d| + |k1| + |k2|*max|xhat|)), see csrc/bn_pool.hip.
+ *   ext [2][C]: per-channel min / max of x (saved for backward);  planes: 2*M*C fp16 + 64 zero bytes;  y_scale / dx_scale [2]:
+ *   {scale, bound} as sp_split2_f16's scale_amax;  bound: 4-byte scratch word (reset by the launcher);  mask: sp_bn_mask_words
+ *   uint64 words (required when relu);  y / dx (fp32 copies) may be NULL when nothing reads them;  res_amax: device word holding
+ *   the float bits of (a bound of) max|residual|. */
+int64_t sp_bn_split_workspace(int64_t M, int C);
+int64_t sp_bn_mask_words(int64_t M, int C);
+int sp_bn_fwd_split(const float* x, int64_t M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                    const float* residual, const unsigned* res_amax, int relu, float* mean, float* invstd, float* running_mean,
+                    float* running_var, float* ext, float* y, void* planes, float* y_scale, unsigned* bound,
+                    unsigned long long* mask, void* workspace,
+                    const double* pre_partial /* nullable: [pre_G][2][C] sums from sp_conv_igemm_f16x2_stats */,
+                    const float* pre_mm /* [pre_G][2][C] min / max */, int pre_G, void* stream);
+int sp_bn_bwd_split(const float* dy, const float* x, const unsigned long long* mask, const float* mean, const float* invstd,
+                    const float* gamma, const float* ext, int64_t M, int C, float* dx, float* dres, void* planes, float* dx_scale,
+                    unsigned* bound, float* dgamma, float* dbeta, void* workspace, void* stream);
 
 /* MaxPool2d(3, stride 2, pad 0, ceil_mode=True), NHWC.  models/resnet.py:104. */
 int sp_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int Ho, int Wo, void* stream);

@@ -230,6 +230,335 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* dy, const float
     if (amax) block_amax_commit(mx, amax, sh4);
 }
 
+
+// ================================================================================================================
+// BatchNorm that EMITS the 2xfp16 split operand of its consumer conv (train mode; conv_f16x2.hip layout [row][C/16][2][16]).
+// The operand scale needs an upper bound of max|output| BEFORE the apply pass.  It does not have to be tight: a power-of-two scale
+// s with bound * s in [8192, 16384) keeps 22 significant bits for every element within 2^-11 of the bound and an absolute error of
+// 2^-38 * bound below that, so a bound that is a few times too large costs nothing measurable -- it only has to be >= the maximum
+// (fp16 overflow).  Forward: the statistics pass also tracks min / max of x per channel; the output of the per-channel affine map
+// (+ReLU) is then bounded exactly, a residual adds its own max|.|.  Backward: |dx| <= |gamma*invstd| * (max|d| + |k1| + |k2| *
+// max|xhat|) per channel.  Saved traffic: the consumer's split pass no longer re-reads the tensor (4 B/element forward and
+// backward), and the ReLU mask is kept as one bit per element (the backward passes read 1/32 of a word instead of the fp32
+// output, twice).  Mask layout: 64 consecutive float4 (= one wave iteration) -> 4 uint64 ballots (x, y, z, w components).
+__device__ __forceinline__ float bn_affine(float a, float mu, float is, float ga, float be) {
+    return __fmaf_rn(__fmul_rn(__fsub_rn(a, mu), is), ga, be);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_mm_partial(const float* __restrict__ x, int64_t M, int C, int G,
+                                                           double* __restrict__ partial, float* __restrict__ mm) {
+    __shared__ double sh[2][RL][CB + 1];
+    __shared__ float shm[2][RL][CB + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * CB + tx * 4;
+    const int g = blockIdx.y;
+    const int64_t rows_per = sp_cdiv_dev(M, G);
+    const int64_t r0 = (int64_t)g * rows_per, r1 = min(M, r0 + rows_per);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (c < C)
+        for (int64_t r = r0 + ty; r < r1; r += RL) {
+            const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += (double)v[k];
+                q[k] += (double)(v[k] * v[k]);
+                mn[k] = fminf(mn[k], v[k]);
+                mx[k] = fmaxf(mx[k], v[k]);
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sh[0][ty][tx * 4 + k] = s[k];
+        sh[1][ty][tx * 4 + k] = q[k];
+        shm[0][ty][tx * 4 + k] = mn[k];
+        shm[1][ty][tx * 4 + k] = mx[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * CB; i += 256) {
+        const int v = i / CB, cc = i % CB;
+        double a = 0.0;
+        float m = v == 0 ? INFINITY : -INFINITY;
+#pragma unroll
+        for (int y = 0; y < RL; ++y) {
+            a += sh[v][y][cc];
+            m = v == 0 ? fminf(m, shm[0][y][cc]) : fmaxf(m, shm[1][y][cc]);
+        }
+        const int cg = blockIdx.x * CB + cc;
+        if (cg < C) {
+            partial[((int64_t)g * 2 + v) * C + cg] = a;
+            mm[((int64_t)g * 2 + v) * C + cg] = m;
+        }
+    }
+}
+
+// extrema of [G][2][C] float partials (min in slot 0, max in slot 1); valid where final_reduce returned true
+__device__ __forceinline__ void final_minmax(const float* __restrict__ mm, int C, int G, float& mn, float& mx) {
+    __shared__ float shx[2][FIN_L][FIN_C];
+    const int tx = threadIdx.x & (FIN_C - 1), ty = threadIdx.x / FIN_C;
+    const int c = blockIdx.x * FIN_C + tx;
+    float a = INFINITY, b = -INFINITY;
+    if (c < C)
+        for (int g = ty; g < G; g += FIN_L) {
+            a = fminf(a, mm[((int64_t)g * 2 + 0) * C + c]);
+            b = fmaxf(b, mm[((int64_t)g * 2 + 1) * C + c]);
+        }
+    shx[0][ty][tx] = a;
+    shx[1][ty][tx] = b;
+    __syncthreads();
+    mn = INFINITY;
+    mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < FIN_L; ++l) {
+        mn = fminf(mn, shx[0][l][tx]);
+        mx = fmaxf(mx, shx[1][l][tx]);
+    }
+}
+
+// block maximum of a per-thread bound -> one atomicMax (order-free: the result does not depend on the schedule)
+__device__ __forceinline__ void commit_bound(float b, unsigned* slot) {
+    __shared__ float shb[FIN_C * FIN_L / 64];
+    b = wave_max(b);
+    if ((threadIdx.x & 63) == 0) shb[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < FIN_C * FIN_L / 64; ++w) m = fmaxf(m, shb[w]);
+        if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+    }
+}
+
+__global__ __launch_bounds__(FIN_C * FIN_L) void bn_stats_mm_final(const double* partial, const float* mm, int64_t M, int C, int G,
+                                                                    float eps, float momentum, const float* gamma,
+                                                                    const float* beta, int relu, float* mean, float* invstd,
+                                                                    float* rmean, float* rvar, float* ext, unsigned* bound) {
+    int c;
+    double r[2];
+    float mn, mx;
+    final_minmax(mm, C, G, mn, mx);
+    const bool own = final_reduce<2>(partial, C, G, c, r);
+    float bnd = 0.f;
+    if (own) {
+        const double mu = r[0] / (double)M;
+        double var = r[1] / (double)M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float muf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = muf;
+        invstd[c] = isf;
+        if (rmean) {
+            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * muf;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+        ext[c] = mn;
+        ext[C + c] = mx;
+        // the affine map is monotone per channel: its extrema sit at the extrema of x (evaluated with the apply pass's own formula)
+        const float v1 = bn_affine(mn, muf, isf, gamma[c], beta[c]), v2 = bn_affine(mx, muf, isf, gamma[c], beta[c]);
+        bnd = relu ? fmaxf(fmaxf(v1, v2), 0.f) : fmaxf(fabsf(v1), fabsf(v2));
+    }
+    commit_bound(bnd, bound);
+}
+
+// y = relu?(bn(x) + res): optional fp32 output, split operand, optional ReLU bit mask.  scale from the bound (+ max|res|).
+__global__ __launch_bounds__(256) void bn_apply_split_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ res,
+                                                             const unsigned* __restrict__ bound, const unsigned* __restrict__ res_amax,
+                                                             int relu, int64_t n4, int C, float* __restrict__ y,
+                                                             uint16_t* __restrict__ planes, float* __restrict__ y_scale,
+                                                             unsigned long long* __restrict__ mask) {
+    const float total = __uint_as_float(*bound) + (res_amax ? __uint_as_float(*res_amax) : 0.f);
+    const float s = scale_of(__float_as_uint(total));
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n4; base += stride) {
+        const int64_t i = base + lane;
+        const bool live = i < n4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const int c = (int)((i * 4) % C);
+            const float4 a = reinterpret_cast<const float4*>(x)[i];
+            const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+            const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(beta + c);
+            o.x = bn_affine(a.x, mu.x, is.x, ga.x, be.x);
+            o.y = bn_affine(a.y, mu.y, is.y, ga.y, be.y);
+            o.z = bn_affine(a.z, mu.z, is.z, ga.z, be.z);
+            o.w = bn_affine(a.w, mu.w, is.w, ga.w, be.w);
+            if (res) {
+                const float4 rr = reinterpret_cast<const float4*>(res)[i];
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+        }
+        if (relu) {
+            if (mask) {
+                const unsigned long long b0 = __ballot(live && o.x > 0.f), b1 = __ballot(live && o.y > 0.f);
+                const unsigned long long b2 = __ballot(live && o.z > 0.f), b3 = __ballot(live && o.w > 0.f);
+                if (lane < 4) mask[(base >> 6) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+            }
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        if (live) {
+            if (y) reinterpret_cast<float4*>(y)[i] = o;
+            if (planes) {
+                ushort4 pa, pb;
+                split2(o.x, s, pa.x, pb.x);
+                split2(o.y, s, pa.y, pb.y);
+                split2(o.z, s, pa.z, pb.z);
+                split2(o.w, s, pa.w, pb.w);
+                uint16_t* po = planes + (i >> 2) * 32 + (int)(i & 3) * 4;
+                *reinterpret_cast<ushort4*>(po) = pa;
+                *reinterpret_cast<ushort4*>(po + 16) = pb;
+            }
+        }
+    }
+    if (planes && blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(planes + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        y_scale[0] = s;
+        y_scale[1] = total;          // an upper bound of max|y| (what a later residual add / re-split may rely on)
+    }
+}
+
+__device__ __forceinline__ float4 mask_select(const unsigned long long* __restrict__ mask, int64_t i, float4 d) {
+    const unsigned long long* w = mask + (i >> 6) * 4;
+    const int b = (int)(i & 63);
+    d.x = ((w[0] >> b) & 1ull) ? d.x : 0.f;
+    d.y = ((w[1] >> b) & 1ull) ? d.y : 0.f;
+    d.z = ((w[2] >> b) & 1ull) ? d.z : 0.f;
+    d.w = ((w[3] >> b) & 1ull) ? d.w : 0.f;
+    return d;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_mm_partial(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const unsigned long long* __restrict__ mask,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         int64_t M, int C, int G, double* __restrict__ partial,
+                                                         float* __restrict__ dmax) {
+    __shared__ double sh[2][RL][CB + 1];
+    __shared__ float shm[RL][CB + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * CB + tx * 4;
+    const int g = blockIdx.y;
+    const int64_t rows_per = sp_cdiv_dev(M, G);
+    const int64_t r0 = (int64_t)g * rows_per, r1 = min(M, r0 + rows_per);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+        for (int64_t r = r0 + ty; r < r1; r += RL) {
+            float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
+            const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+            if (mask) d = mask_select(mask, (r * C + c) >> 2, d);
+            const float dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s1[k] += (double)dv[k];
+                s2[k] += (double)(dv[k] * (av[k] - m4[k]) * i4[k]);
+                mx[k] = fmaxf(mx[k], fabsf(dv[k]));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sh[0][ty][tx * 4 + k] = s1[k];
+        sh[1][ty][tx * 4 + k] = s2[k];
+        shm[ty][tx * 4 + k] = mx[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * CB; i += 256) {
+        const int v = i / CB, cc = i % CB;
+        double a = 0.0;
+        float m = 0.f;
+#pragma unroll
+        for (int y = 0; y < RL; ++y) {
+            a += sh[v][y][cc];
+            m = fmaxf(m, shm[y][cc]);
+        }
+        const int cg = blockIdx.x * CB + cc;
+        if (cg < C) {
+            partial[((int64_t)g * 2 + v) * C + cg] = a;
+            if (v == 0) dmax[(int64_t)g * C + cg] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(FIN_C * FIN_L) void bn_bwd_mm_final(const double* partial, const float* dmax, int64_t M, int C, int G,
+                                                                  const float* gamma, const float* mean, const float* invstd,
+                                                                  const float* ext, float* dgamma, float* dbeta, float* coef,
+                                                                  unsigned* bound) {
+    __shared__ float shd[FIN_L][FIN_C];
+    const int tx = threadIdx.x & (FIN_C - 1), ty = threadIdx.x / FIN_C;
+    const int cc = blockIdx.x * FIN_C + tx;
+    float dm = 0.f;
+    if (cc < C)
+        for (int g = ty; g < G; g += FIN_L) dm = fmaxf(dm, dmax[(int64_t)g * C + cc]);
+    shd[ty][tx] = dm;
+    int c;
+    double r[2];
+    const bool own = final_reduce<2>(partial, C, G, c, r);      // (contains the __syncthreads that publishes shd)
+    float bnd = 0.f;
+    if (own) {
+        dm = 0.f;
+#pragma unroll
+        for (int l = 0; l < FIN_L; ++l) dm = fmaxf(dm, shd[l][tx]);
+        dbeta[c] = (float)r[0];
+        dgamma[c] = (float)r[1];
+        const float k1 = (float)(r[0] / (double)M), k2 = (float)(r[1] / (double)M);
+        coef[c] = k1;
+        coef[C + c] = k2;
+        const float xh = fmaxf(fabsf(ext[c] - mean[c]), fabsf(ext[C + c] - mean[c])) * invstd[c];
+        bnd = fabsf(gamma[c] * invstd[c]) * (dm + fabsf(k1) + fabsf(k2) * xh) * 1.0001f;
+    }
+    commit_bound(bnd, bound);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const unsigned long long* __restrict__ mask,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ coef,
+                                                                 const unsigned* __restrict__ bound, int64_t n4, int C,
+                                                                 float* __restrict__ dx, float* __restrict__ dres,
+                                                                 uint16_t* __restrict__ planes, float* __restrict__ dx_scale) {
+    const float s = scale_of(*bound);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        float4 d = reinterpret_cast<const float4*>(dy)[i];
+        if (mask) d = mask_select(mask, i, d);
+        if (dres) reinterpret_cast<float4*>(dres)[i] = d;
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
+        const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
+        float4 o;
+        o.x = ga.x * is.x * (d.x - k1.x - (a.x - mu.x) * is.x * k2.x);
+        o.y = ga.y * is.y * (d.y - k1.y - (a.y - mu.y) * is.y * k2.y);
+        o.z = ga.z * is.z * (d.z - k1.z - (a.z - mu.z) * is.z * k2.z);
+        o.w = ga.w * is.w * (d.w - k1.w - (a.w - mu.w) * is.w * k2.w);
+        if (dx) reinterpret_cast<float4*>(dx)[i] = o;
+        if (planes) {
+            ushort4 pa, pb;
+            split2(o.x, s, pa.x, pb.x);
+            split2(o.y, s, pa.y, pb.y);
+            split2(o.z, s, pa.z, pb.z);
+            split2(o.w, s, pa.w, pb.w);
+            uint16_t* po = planes + (i >> 2) * 32 + (int)(i & 3) * 4;
+            *reinterpret_cast<ushort4*>(po) = pa;
+            *reinterpret_cast<ushort4*>(po + 16) = pb;
+        }
+    }
+    if (planes && blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(planes + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dx_scale[0] = s;
+        dx_scale[1] = __uint_as_float(*bound);
+    }
+}
+
 // ---------------------------------------------------------------- column sums / row sums
 __global__ __launch_bounds__(256) void colsum_partial(const float* x, int64_t M, int C, int ld, int G, double* partial) {
     col_reduce<1>(M, C, G, partial, [&](int64_t r, int c, float4* v) {
@@ -447,6 +776,72 @@ extern "C" int sp_bn_backward(const float* dy, const float* x, const float* y, c
     SP_RESET_AMAX(dx_amax, s);
     hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, relu,
                        training, n4, C, dx, dres, dx_amax);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int64_t sp_bn_split_workspace(int64_t M, int C) {
+    const int64_t G = pick_G(M, C);
+    return G * 2 * C * (int64_t)sizeof(double) + G * 2 * C * (int64_t)sizeof(float) + 2 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t sp_bn_mask_words(int64_t M, int C) { return sp_cdiv(M * C / 4, 64) * 4; }
+
+extern "C" int sp_bn_fwd_split(const float* x, int64_t M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                               const float* residual, const unsigned* res_amax, int relu, float* mean, float* invstd,
+                               float* running_mean, float* running_var, float* ext, float* y, void* planes, float* y_scale,
+                               unsigned* bound, unsigned long long* mask, void* workspace, const double* pre_partial,
+                               const float* pre_mm, int pre_G, void* stream) {
+    if (!x || !gamma || !beta || !mean || !invstd || !ext || !y_scale || !bound || !workspace) return SP_ENULL;
+    if ((residual && !res_amax) || (relu && !mask) || (!y && !planes)) return SP_ENULL;
+    if (C % 4 || (planes && C % 16) || M <= 0 || ((uintptr_t)planes & 15)) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int G = pick_G(M, C);
+    const double* partial = (double*)workspace;
+    const float* mm = (float*)((double*)workspace + (int64_t)G * 2 * C);
+    SP_RESET_AMAX(bound, s);
+    if (pre_partial) {                 // first stage done by the producing conv's epilogue (sp_conv_igemm_f16x2_stats)
+        if (!pre_mm || pre_G < 1) return SP_EINVAL;
+        partial = pre_partial;
+        mm = pre_mm;
+        G = pre_G;
+    } else {
+        hipLaunchKernelGGL(bn_stats_mm_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, x, M, C, G, (double*)workspace,
+                           (float*)((double*)workspace + (int64_t)G * 2 * C));
+        SP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_stats_mm_final, dim3((unsigned)sp_cdiv(C, FIN_C)), dim3(FIN_C * FIN_L), 0, s, partial, mm, M, C, G, eps,
+                       momentum, gamma, beta, relu, mean, invstd, running_mean, running_var, ext, bound);
+    SP_LAUNCH_CHECK();
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_apply_split_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, mean, invstd, gamma, beta, residual, bound,
+                       residual ? res_amax : nullptr, relu, n4, C, y, (uint16_t*)planes, y_scale, relu ? mask : nullptr);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_bn_bwd_split(const float* dy, const float* x, const unsigned long long* mask, const float* mean,
+                               const float* invstd, const float* gamma, const float* ext, int64_t M, int C, float* dx,
+                               float* dres, void* planes, float* dx_scale, unsigned* bound, float* dgamma, float* dbeta,
+                               void* workspace, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !ext || !dx_scale || !bound || !dgamma || !dbeta || !workspace) return SP_ENULL;
+    if (!dx && !planes) return SP_ENULL;
+    if (C % 4 || (planes && C % 16) || M <= 0 || ((uintptr_t)planes & 15)) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = pick_G(M, C);
+    double* partial = (double*)workspace;
+    float* dmax = (float*)(partial + (int64_t)G * 2 * C);
+    float* coef = dmax + (int64_t)G * 2 * C;
+    SP_RESET_AMAX(bound, s);
+    hipLaunchKernelGGL(bn_bwd_mm_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, dy, x, mask, mean, invstd, M, C, G,
+                       partial, dmax);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_mm_final, dim3((unsigned)sp_cdiv(C, FIN_C)), dim3(FIN_C * FIN_L), 0, s, partial, dmax, M, C, G, gamma,
+                       mean, invstd, ext, dgamma, dbeta, coef, bound);
+    SP_LAUNCH_CHECK();
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_split_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, mask, mean, invstd, gamma, coef,
+                       bound, n4, C, dx, dres, (uint16_t*)planes, dx_scale);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

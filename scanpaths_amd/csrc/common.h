@@ -31,7 +31,7 @@ __global__ void sp_zero_words_kernel(unsigned* p, int n) {
     } while (0)
 
 // process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default
-enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_COUNT = 2 };
+enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_COUNT = 4 };
 extern int sp_tuning_values[SP_TUNE_COUNT];
 static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }
 
@@ -80,6 +80,27 @@ __device__ __forceinline__ void block_amax_commit(float m, unsigned* amax, float
         if (b > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, b);
     }
 }
+// ---- 2xfp16 operand split (conv_f16x2.hip; shared with the producers that emit split operands directly) ----
+// power-of-two scale with amax * s in [8192, 16384)
+__device__ __forceinline__ float scale_of(unsigned amax_bits) {
+    const float a = __uint_as_float(amax_bits);
+    if (!(a > 0.f) || !(a < INFINITY)) return 1.f;
+    int e;
+    (void)frexpf(a, &e);                 // a = f * 2^e, f in [0.5, 1)
+    e = 14 - e;                          // a * 2^(14-e) in [8192, 16384)
+    e = max(-126, min(126, e));
+    return ldexpf(1.f, e);
+}
+
+__device__ __forceinline__ void split2(float v, float s, uint16_t& a, uint16_t& b) {
+    const float xs = v * s;
+    const _Float16 x1 = (_Float16)xs;
+    const float r1 = xs - (float)x1;
+    const _Float16 x2 = (_Float16)r1;
+    a = __builtin_bit_cast(uint16_t, x1);
+    b = __builtin_bit_cast(uint16_t, x2);
+}
+
 __device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
 }

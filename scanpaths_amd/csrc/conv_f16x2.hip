@@ -31,6 +31,7 @@ constexpr int HB_BYTES = HBN * 128;              // 16384
 constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
 constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
+constexpr int HW_DEFAULT_MAP = 0;                // sp_set_tuning("hw_map", 1): aligned-rounds workgroup order of hw_kernel
 constexpr int H2_DEFAULT_VARIANT = 15;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
 constexpr int HW_DEFAULT_VARIANT = 6;            // schedule variant of hw_kernel
 
@@ -60,6 +61,11 @@ struct H2Args {
     float* l_h;             // [M][lC]
     unsigned* l_hamax;      // max |h| (float bits), reset by the launcher
     int lC, lP, lKP;
+    // BatchNorm batch statistics of the output, fused into the epilogue (forward, 16x16x32 build): per M-tile and output column
+    // the sum and the sum of squares (fp64) and min / max (fp32) of the tile's valid rows, in the [G = M-tiles][2][Nout] layout
+    // of bn_pool.hip's first reduction stage -- the BatchNorm behind this conv starts at its second stage
+    double* st_partial;
+    float* st_mm;
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
@@ -594,24 +600,70 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     }
     if constexpr (M16) {
         // C/D layout of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg
+        const bool stats = MODE == 0 && p.st_partial != nullptr;        // scalar
+        double* sh_s = reinterpret_cast<double*>(smem);                  // [4 wm][128 col][2]  (the ring is idle: see the LSTM epilogue)
+        float* sh_m = reinterpret_cast<float*>(smem + 4 * HBN * 2 * sizeof(double));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l16;
-            if (n >= p.Nout) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
+            const bool n_ok = n < p.Nout;
+            const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
+            double cs = 0.0, cq = 0.0;
+            float cmn = INFINITY, cmx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
-                    if (m < p.M) {
+                    if (n_ok && m < p.M) {
                         float* dst = p.C + m * p.ldc + n;
                         float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
                         if (p.beta) v += *dst;
                         if (p.relu) v = fmaxf(v, 0.f);
                         *dst = v;
+                        if (stats) {
+                            cs += (double)v;
+                            cq += (double)v * (double)v;
+                            cmn = fminf(cmn, v);
+                            cmx = fmaxf(cmx, v);
+                        }
                     }
                 }
+            if (stats) {                       // the four 16-lane groups hold rows 4*g4 + r of the same column
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    cs += __shfl_xor(cs, off);
+                    cq += __shfl_xor(cq, off);
+                    cmn = fminf(cmn, __shfl_xor(cmn, off));
+                    cmx = fmaxf(cmx, __shfl_xor(cmx, off));
+                }
+                if (g4 == 0) {
+                    const int col = wn * 64 + j * 16 + l16;
+                    sh_s[(wm * HBN + col) * 2 + 0] = cs;
+                    sh_s[(wm * HBN + col) * 2 + 1] = cq;
+                    sh_m[(wm * HBN + col) * 2 + 0] = cmn;
+                    sh_m[(wm * HBN + col) * 2 + 1] = cmx;
+                }
+            }
+        }
+        if (stats) {
+            __syncthreads();
+            if (t < HBN && n0 + t < p.Nout) {
+                double a = 0.0, b = 0.0;
+                float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {              // fixed order over the four row groups of the tile
+                    a += sh_s[(w * HBN + t) * 2 + 0];
+                    b += sh_s[(w * HBN + t) * 2 + 1];
+                    mn = fminf(mn, sh_m[(w * HBN + t) * 2 + 0]);
+                    mx = fmaxf(mx, sh_m[(w * HBN + t) * 2 + 1]);
+                }
+                const int64_t g = m0 / HBM;
+                p.st_partial[(g * 2 + 0) * p.Nout + n0 + t] = a;
+                p.st_partial[(g * 2 + 1) * p.Nout + n0 + t] = b;
+                p.st_mm[(g * 2 + 0) * p.Nout + n0 + t] = mn;
+                p.st_mm[(g * 2 + 1) * p.Nout + n0 + t] = mx;
+            }
         }
         return;
     }
@@ -653,6 +705,7 @@ struct HWArgs {
     int Hi, Wi, Ci, Ho, Wo, Co;
     int KH, KW, stride, pad, dil;
     int Ntot, ldo, tiles_n, splits;
+    int map_mode;          // 1: 1-D grid, per-XCD order in which the 32 workgroups running together share ONE pixel range (see hw_kernel)
     int64_t rows_per_split, slab_stride;
     float alpha;
     int beta;
@@ -704,10 +757,34 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     const int l32 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
+    int tn, tmi, split;
+    if (p.map_mode == 1) {
+        // XCD x (= block id % 8 under round-robin dispatch) owns the output-channel tiles x, x+8, ...; its workgroups are ordered so
+        // that each group of 32 consecutive ones (one per CU: they run together) covers 32 N-tiles of ONE pixel range -- they stream the
+        // same dY rows and the same (tap-shifted) X rows through the XCD's L2 in step.  With tiles ordered n-fastest across all
+        // 36 N-tiles a round straddles two pixel ranges and each range is streamed twice.  The tiles_n % 32 left-over N-tiles of all
+        // pixel ranges come last.
+        const int q = blockIdx.x >> 3, S = p.splits;
+        const int per_cot = p.tiles_n * S;
+        const int cot = q / per_cot, q2 = q - cot * per_cot;
+        tmi = cot * 8 + (blockIdx.x & 7);
+        const int G = p.tiles_n >> 5, main = G * 32 * S;
+        if (q2 < main) {
+            const int g = q2 / (32 * S), r = q2 - g * 32 * S;
+            split = r >> 5;
+            tn = g * 32 + (r & 31);
+        } else {
+            const int q3 = q2 - main, rem = p.tiles_n - G * 32;
+            split = q3 / rem;
+            tn = G * 32 + (q3 - split * rem);
+        }
+    } else {
+        const int lid = xcd_remap(blockIdx.x, gridDim.x);
+        tn = lid % p.tiles_n;
+        tmi = lid / p.tiles_n;
+        split = blockIdx.y;
+    }
     const int co0 = tmi * 256, n0 = tn * 128;
-    const int split = blockIdx.y;
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
     const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
     const int nkt = (int)((m_end - m_begin + 31) / 32);
@@ -1085,6 +1162,8 @@ __global__ void hw_reduce_kernel(const float* slab, float* out, int Co, int Ntot
 
 int hw_splits(const sp_wgrad_desc* d) {
     const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
+    const int forced = sp_tuning_get(SP_TUNE_HW_SPLITS, 0);      // experiments only
+    if (forced > 0) return (int)std::min<int64_t>(forced, std::max<int64_t>(1, M / 32));
     const int64_t tiles = sp_cdiv(d->Co, 256) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, 128);
     int64_t want = sp_cdiv(2048, tiles);                          // 1 workgroup per CU: aim for >= 8 rounds of 256
     want = std::min<int64_t>(want, std::max<int64_t>(1, M / 1024));   // >= 32 K-tiles per split
@@ -1117,26 +1196,6 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* x, int64_t n4, i
     __shared__ float sh4[4];
     m = block_max_256(m, sh4);
     if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
-}
-
-// power-of-two scale with amax * s in [8192, 16384)
-__device__ __forceinline__ float scale_of(unsigned amax_bits) {
-    const float a = __uint_as_float(amax_bits);
-    if (!(a > 0.f) || !(a < INFINITY)) return 1.f;
-    int e;
-    (void)frexpf(a, &e);                 // a = f * 2^e, f in [0.5, 1)
-    e = 14 - e;                          // a * 2^(14-e) in [8192, 16384)
-    e = max(-126, min(126, e));
-    return ldexpf(1.f, e);
-}
-
-__device__ __forceinline__ void split2(float v, float s, uint16_t& a, uint16_t& b) {
-    const float xs = v * s;
-    const _Float16 x1 = (_Float16)xs;
-    const float r1 = xs - (float)x1;
-    const _Float16 x2 = (_Float16)r1;
-    a = __builtin_bit_cast(uint16_t, x1);
-    b = __builtin_bit_cast(uint16_t, x2);
 }
 
 // x fp32 [rows][K] (K % 16 == 0)  ->  [rows][K/16][2][16] fp16.  One thread per 4 consecutive k.
@@ -1206,7 +1265,8 @@ int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
         attr_set = true;
     }
     const int64_t grid = sp_cdiv(Co, 256) * a.tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
+    if (a.map_mode == 1) hipLaunchKernelGGL(kern, dim3((unsigned)(grid * a.splits)), dim3(512), HNSTAGE * HWSTAGE, s, a);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -1254,7 +1314,8 @@ extern "C" int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* 
 }
 
 static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws, const float* w_scale,
-                          const float* bias, float* out, void* stream, int nprod) {
+                          const float* bias, float* out, void* stream, int nprod, double* st_partial = nullptr,
+                          float* st_mm = nullptr) {
     if (!d || !Xs || !Ws || !x_scale || !w_scale || !out) return SP_ENULL;
     if (d->mode != 0 && d->mode != 1) return SP_EINVAL;
     if (d->Kc % 32 || d->ldx != d->Kc) return SP_EINVAL;      // a 32-k K-tile must lie inside one filter tap
@@ -1279,6 +1340,12 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     static const int dbg = getenv("SP_H2_DBG") ? atoi(getenv("SP_H2_DBG")) : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool f = d->mode == 0;
+    if (st_partial) {        // fused BatchNorm statistics: forward, fp32-faithful, the 16x16x32 build only
+        if (!f || !st_mm || nprod != 3 || d->beta || d->relu || bias) return SP_EINVAL;
+        a.st_partial = st_partial; a.st_mm = st_mm;
+        return (d->KH * d->KW > 1 && d->KH * d->KW <= 32) ? launch_h2<0, 0, 3, 3, true, true>(a, st)
+                                                          : launch_h2<0, 0, 3, 3, true, false>(a, st);
+    }
     if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
     if (dbg == 2) return f ? launch_h2<0, 2, 0>(a, st) : launch_h2<1, 2, 0>(a, st);
     if (dbg == 3) return f ? launch_h2<0, 3, 0>(a, st) : launch_h2<1, 3, 0>(a, st);
@@ -1314,6 +1381,15 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
 extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
                                    const float* w_scale, const float* bias, float* out, void* stream) {
     return conv_igemm_f16(d, Xs, x_scale, Ws, w_scale, bias, out, stream, 3);
+}
+
+// forward conv + the first reduction stage of the BatchNorm behind it: st_partial [tiles][2][Nout] doubles (sum, sum of squares),
+// st_mm [tiles][2][Nout] floats (min, max), tiles = sp_conv_stats_tiles(M) -- the layout sp_bn_fwd_split accepts as pre_partial
+extern "C" int64_t sp_conv_stats_tiles(int64_t M) { return sp_cdiv(M, HBM); }
+extern "C" int sp_conv_igemm_f16x2_stats(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
+                                         const float* w_scale, float* out, double* st_partial, float* st_mm, void* stream) {
+    if (!st_partial || !st_mm) return SP_ENULL;
+    return conv_igemm_f16(d, Xs, x_scale, Ws, w_scale, nullptr, out, stream, 3, st_partial, st_mm);
 }
 
 extern "C" int sp_conv_igemm_f16x1(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
@@ -1379,6 +1455,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     a.tiles_n = (int)sp_cdiv(a.Ntot, 128);
     a.splits = hw_splits(d);
     if (a.splits > 1 && !workspace) return SP_ENULL;
+    a.map_mode = (sp_tuning_get(SP_TUNE_HW_MAP, HW_DEFAULT_MAP) == 1 && sp_cdiv(d->Co, 256) % 8 == 0) ? 1 : 0;
     a.rows_per_split = sp_cdiv(sp_cdiv(a.M, a.splits), 32) * 32;
     a.slab_stride = (int64_t)d->Co * d->ldo;
     a.out = a.splits > 1 ? (float*)workspace : dW;

@@ -125,6 +125,10 @@ def _amax_hint(device) -> Optional[torch.Tensor]:
     return hint
 
 
+def _amax_hint_active() -> bool:
+    return bool(USE_BF16X3 and SPLIT_SCHEME == "f16x2" and FUSED_AMAX)
+
+
 def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
     return None if hint is None else hint.data_ptr() + 4
 
@@ -176,7 +180,7 @@ def _b3_pays(M, N, K, Kc, nbatch=1, a_elems=None, free_a=False):
 
 
 def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
-              alpha=1.0, beta=0, relu=0):
+              alpha=1.0, beta=0, relu=0, stats=None):
     """implicit-GEMM conv / dgrad on split operands (SplitOperand, or a raw split-3 buffer)"""
     if not isinstance(Xs, SplitOperand):
         Xs, Ws = SplitOperand(Xs, None, "bf16x3"), SplitOperand(Ws, None, "bf16x3")
@@ -186,7 +190,10 @@ def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, l
     f16 = Xs.scheme == "f16x2"
 
     def launch():
-        if f16:
+        if stats is not None:          # (partial, mm): BatchNorm statistics of the output from the epilogue
+            check(hip.lib().sp_conv_igemm_f16x2_stats(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(Ws.buf), ptr(Ws.scale), ptr(out),
+                                                      ptr(stats[0]), ptr(stats[1]), hip.stream()), "sp_conv_igemm_f16x2_stats")
+        elif f16:
             fn = hip.lib().sp_conv_igemm_f16x1 if THROUGHPUT_MODE else hip.lib().sp_conv_igemm_f16x2
             check(fn(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(Ws.buf), ptr(Ws.scale), ptr(bias), ptr(out), hip.stream()),
                   "sp_conv_igemm_f16x2")
@@ -377,7 +384,7 @@ def _out_hw(H, W, KH, KW, stride, pad, dil):
 # ----------------------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None, bn_stats=False):
         # wcache: dict shared by all applications of the SAME weight inside one forward/backward (the h-gate conv runs T times):
         # its split forms ("w": forward operand, "wT": data-gradient operand) are produced once instead of per step
         x = x.contiguous()
@@ -396,8 +403,17 @@ class _Conv2d(Function):
                 wsplit = split_op(wp, xs.scheme)
                 if wcache is not None:
                     wcache[("w", xs.scheme)] = wsplit
+            stats = None
+            if bn_stats and BN_SPLIT and xs.scheme == "f16x2" and not THROUGHPUT_MODE and bias is None and not relu:
+                # bn_stats: a train-mode BatchNorm follows -- the epilogue writes the first stage of its batch statistics
+                G = hip.lib().sp_conv_stats_tiles(N * Ho * Wo)
+                stats = (torch.empty((G, 2, Co), dtype=torch.float64, device=x.device),
+                         torch.empty((G, 2, Co), dtype=torch.float32, device=x.device), G)
             _igemm_b3(xs, wsplit, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,
-                      ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
+                      ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu, stats=stats)
+            y._sp_from_split = xs.scheme == "f16x2"        # a BatchNorm behind this conv may emit the split gradient (bn_act)
+            if stats is not None:
+                y._sp_bnstats = stats
             # the weight-gradient GEMM consumes the same split operand: keep it (6 B/element) instead of re-splitting x in
             # backward (HBM pass of 10 B/element per conv); sized for 288 GB
             if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=True)
@@ -425,7 +441,7 @@ class _Conv2d(Function):
             dy = dyr
         dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         db = _colsum_any(dy, wp.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw):
@@ -464,8 +480,16 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw):
     return dx, dw
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None):
-    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache)
+def conv_takes_split(x_shape, w, stride=1, pad=0, dil=1) -> bool:
+    """would conv2d(x, w) run on the 2xfp16 split path if x [N,H,W,Ci] arrived with its split operand attached (bn_act emit_split)"""
+    N, H, W_, Ci = x_shape
+    Co, _, KH, KW = w.shape
+    Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
+    return _scheme_for(Ci) == "f16x2" and _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=N * H * W_ * Ci, free_a=True)
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None, bn_stats=False):
+    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache, bn_stats)
 
 
 class _PadLast(Function):
@@ -646,7 +670,78 @@ class _BnAct(Function):
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
-def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True):
+BN_SPLIT = os.environ.get("SP_BN_SPLIT", "1") != "0"
+
+
+class _BnActSplit(Function):
+    """Train-mode BatchNorm(+residual, +ReLU) whose passes also emit what their consumers need (sp_bn_fwd_split / sp_bn_bwd_split):
+    the 2xfp16 split operand of the consumer conv (forward: of the output; backward: of the gradient w.r.t. the conv output, both
+    GEMMs of the producing conv's backward read it), with the operand scale taken from an upper bound of the maximum instead of a
+    measured one, and the ReLU mask as one bit per element instead of the fp32 output.  emit_fwd / emit_bwd: whether the split
+    operands will be read (else only the bound is attached as the max|.| hint)."""
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre):
+        # pre: (partial, mm, G) -- first statistics stage already done by the producing conv's epilogue (conv2d bn_stats=True)
+        x = x.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        n = x.numel()
+        L = hip.lib()
+        dev = x.device
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+        ext = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+        ws = hip.workspace(L.sp_bn_split_workspace(M, Cc), dev, slot=1)
+        emit_fwd = bool(emit_fwd) and Cc % 16 == 0
+        planes = torch.empty(2 * n + 32, dtype=torch.float16, device=dev) if emit_fwd else None
+        mask = torch.empty(L.sp_bn_mask_words(M, Cc), dtype=torch.int64, device=dev) if relu else None
+        y = torch.empty_like(x)
+        res = residual.contiguous() if residual is not None else None
+        zhint, bhint = _amax_hint(dev), _amax_hint(dev)
+        check(L.sp_bn_fwd_split(ptr(x), M, Cc, eps, momentum, ptr(gamma), ptr(beta), ptr(res),
+                                _hint_ptr(residual._sp_amax) if residual is not None else None, int(relu), ptr(mean), ptr(invstd),
+                                ptr(rmean), ptr(rvar), ptr(ext), ptr(y), ptr(planes), ptr(zhint), _hint_ptr(bhint), ptr(mask),
+                                ptr(ws), ptr(pre[0]) if pre else None, ptr(pre[1]) if pre else None, pre[2] if pre else 0,
+                                hip.stream()), "sp_bn_fwd_split")
+        y._sp_amax = zhint
+        if planes is not None:
+            y._sp_cache = {"f16x2": SplitOperand(planes, zhint, "f16x2")}
+        ctx.cfg = (relu, residual is not None, bool(emit_bwd) and Cc % 16 == 0)
+        ctx.save_for_backward(x, mask, mean, invstd, gamma.detach(), ext)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        relu, has_res, emit = ctx.cfg
+        x, mask, mean, invstd, gamma, ext = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        L = hip.lib()
+        dev = x.device
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
+        planes = torch.empty(2 * x.numel() + 32, dtype=torch.float16, device=dev) if emit else None
+        ws = hip.workspace(L.sp_bn_split_workspace(M, Cc), dev, slot=1)
+        dhint, bhint = _amax_hint(dev), _amax_hint(dev)
+        check(L.sp_bn_bwd_split(ptr(dy), ptr(x), ptr(mask), ptr(mean), ptr(invstd), ptr(gamma), ptr(ext), M, Cc, ptr(dx),
+                                ptr(dres), ptr(planes), ptr(dhint), _hint_ptr(bhint), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                hip.stream()), "sp_bn_bwd_split")
+        dx._sp_amax = dhint
+        if planes is not None:
+            dx._sp_cache = {"f16x2": SplitOperand(planes, dhint, "f16x2")}
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True, emit_split=False):
+    """emit_split: the output feeds a conv that runs on the 2xfp16 split path -- the BatchNorm pass writes that operand itself"""
+    if (training and BN_SPLIT and x.shape[-1] % 4 == 0 and _amax_hint_active()
+            and (residual is None or getattr(residual, "_sp_amax", None) is not None)):
+        emit_bwd = getattr(x, "_sp_from_split", False)       # the producing conv's backward GEMMs read the split gradient
+        return _BnActSplit.apply(x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_split, emit_bwd,
+                                 getattr(x, "_sp_bnstats", None))
     return _BnAct.apply(x, gamma, beta, rmean, rvar, residual, training, momentum, eps, relu)
 
 

@@ -198,39 +198,53 @@ class ScanpathModel(nn.Module):
                 nn.init.zeros_(m.bias)
 
     # ------------------------------------------------------------------------------------------------
-    def _bn(self, bn: _BN, x, residual=None, relu=True):
-        y = F.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training=self.training, relu=relu)
+    def _bn(self, bn: _BN, x, residual=None, relu=True, emit_split=False):
+        y = F.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training=self.training, relu=relu,
+                     emit_split=emit_split)
         if self.training:
             bn.num_batches_tracked += 1
         return y
 
     def encode(self, images):
-        """models/resnet.py:96-152 + dilate_resnet (baseline_attention.py:226-238), NHWC."""
+        """models/resnet.py:96-152 + dilate_resnet (baseline_attention.py:226-238), NHWC.  emit_split: a BatchNorm whose output
+        feeds a conv on the 2xfp16 split path writes that conv's operand in its own pass (F.bn_act)."""
         r = self.resnet
         x = F.nchw_to_nhwc(images, 4)
         w0 = F.pad_last(r[0].weight.permute(0, 2, 3, 1), 4).permute(0, 3, 1, 2)     # Cin 3 -> 4 (zero)
         x = F.conv2d(x, w0, None, stride=2, pad=3)
         x = self._bn(r[1], x)
+        st = self.training            # conv epilogues write the first stage of the batch statistics of the BatchNorm behind them
         x = F.maxpool3s2(x)
         kind = ARCHS[self.arch][0]
+        blocks = []
         for li in range(4):
             first_stride = 2 if li == 2 else 1       # layer2[0], layer4[0] strides forced to 1
             dil = {2: 2, 3: 4}.get(li, 1)
             for bi, blk in enumerate(r[4 + li]):
-                s = first_stride if bi == 0 else 1
-                if kind == "bottleneck":
-                    o = self._bn(blk.bn1, F.conv2d(x, blk.conv1.weight, None, stride=s))
-                    o = self._bn(blk.bn2, F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil))
-                    o = F.conv2d(o, blk.conv3.weight, None)
-                    last = blk.bn3
-                else:
-                    o = self._bn(blk.bn1, F.conv2d(x, blk.conv1.weight, None, stride=s, pad=1))
-                    o = F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil)
-                    last = blk.bn2
-                idn = x
-                if blk.downsample is not None:
-                    idn = self._bn(blk.downsample[1], F.conv2d(x, blk.downsample[0].weight, None, stride=s), relu=False)
-                x = self._bn(last, o, residual=idn, relu=True)
+                blocks.append((blk, first_stride if bi == 0 else 1, dil))
+        for k, (blk, s, dil) in enumerate(blocks):
+            if kind == "bottleneck":
+                o = F.conv2d(x, blk.conv1.weight, None, stride=s, bn_stats=st)
+                o = self._bn(blk.bn1, o, emit_split=F.conv_takes_split(o.shape, blk.conv2.weight, pad=dil, dil=dil))
+                o = F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil, bn_stats=st)
+                o = self._bn(blk.bn2, o, emit_split=F.conv_takes_split(o.shape, blk.conv3.weight))
+                o = F.conv2d(o, blk.conv3.weight, None, bn_stats=st)
+                last = blk.bn3
+            else:
+                o = F.conv2d(x, blk.conv1.weight, None, stride=s, pad=1, bn_stats=st)
+                o = self._bn(blk.bn1, o, emit_split=F.conv_takes_split(o.shape, blk.conv2.weight, pad=dil, dil=dil))
+                o = F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil, bn_stats=st)
+                last = blk.bn2
+            idn = x
+            if blk.downsample is not None:
+                idn = self._bn(blk.downsample[1], F.conv2d(x, blk.downsample[0].weight, None, stride=s, bn_stats=st), relu=False)
+            if k + 1 < len(blocks):          # consumers of the block output: conv1 (and the downsample conv) of the next block
+                nb, ns, _ = blocks[k + 1]
+                emit = F.conv_takes_split(o.shape, nb.conv1.weight, stride=ns, pad=0 if kind == "bottleneck" else 1) or \
+                    (nb.downsample is not None and F.conv_takes_split(o.shape, nb.downsample[0].weight, stride=ns))
+            else:
+                emit = True                  # the decoder's 3x3 feature conv
+            x = self._bn(last, o, residual=idn, relu=True, emit_split=emit)
         return x
 
     # ------------------------------------------------------------------------------------------------

@@ -514,21 +514,112 @@ def test_fused_amax_hints_equal_the_separate_pass():
     assert getattr(y, "_sp_amax", None) is not None
     hinted = F.split_op(y)
     plain = F.split_op(y.detach().clone())                       # no hint: separate amax pass
+    # train-mode BN leaves an upper BOUND of max|y| (per-channel extrema through the affine map): exact without a residual
     assert torch.equal(hinted.buf, plain.buf) and float(hinted.scale[0]) == float(plain.scale[0])
-    amax = torch.tensor([hinted.scale[1].item()]).view(torch.int32).view(torch.float32)     # float bits stored by atomicMax
+    amax = torch.tensor([hinted.scale[1].item()]).view(torch.int32).view(torch.float32)     # float bits of the bound
     assert float(amax) == float(y.abs().max())
-    # backward hints: dx of BN, and the LSTM cell pair
+    # backward hints: dx of BN (a bound: |gamma*invstd| * (max|d| + |k1| + |k2| max|xhat|)), and the LSTM cell pair
     gy = _rand(*y.shape, seed=8).to(dev)
     (dx,) = torch.autograd.grad(y, x, gy)
     if getattr(dx, "_sp_amax", None) is not None:                # identity of the grad tensor object is up to autograd
-        a = F.split_op(dx); b = F.split_op(dx.detach().clone())
-        assert torch.equal(a.buf, b.buf)
+        bound, true = float(dx._sp_amax[1]), float(dx.abs().max())
+        assert true <= bound <= 8 * true, (true, bound)
+        a = F.split_op(dx)
+        assert float((_decode_split(a, dx.shape) - dx).abs().max()) <= 2.0 ** -21 * bound
     B, Hm, Wm, C = 2, 5, 7, 64
     xg = _rand(B, Hm, Wm, 4 * C, seed=9).to(dev)
     spcol, wc = _rand(B, Hm * Wm, 12, seed=10).to(dev), _rand(B, 3 * C, 12, seed=11, scale=0.1).to(dev)
     h, c = F.lstm_cell_rank1(xg, None, None, spcol, wc)
     a = F.split_op(h); b = F.split_op(h.detach().clone())
     assert getattr(h, "_sp_amax", None) is not None and torch.equal(a.buf, b.buf)
+
+
+def _decode_split(op, shape):
+    """fp32 value of a 2xfp16 split operand [rows][K/16][2][16]"""
+    n = 1
+    for d in shape:
+        n *= d
+    planes = op.buf[:2 * n].view(-1, 2, 16).float()
+    return ((planes[:, 0] + planes[:, 1]) / float(op.scale[0])).reshape(shape)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_act_emits_the_split_operand_and_the_bit_mask(relu, monkeypatch):
+    """train-mode BN with a residual whose passes write the consumer's 2xfp16 operand (forward: of y, backward: of dx) and keep the
+    ReLU mask as bits: values against the plain three-kernel path (SP_BN_SPLIT=0) and fp64, operands against their fp32 tensors"""
+    from scanpaths_amd import functional as F
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3:
+        pytest.skip("2xfp16 back-end not active")
+    dev = _dev()
+    N, H, W, C = 3, 9, 11, 64                                    # 297 pixels x 64: a ragged last wave for the bit mask
+    x0 = (_rand(N, H, W, C, seed=15) * 2 + 0.5).to(dev)
+    r0 = _rand(N, H, W, C, seed=16).to(dev)
+    gamma, beta = (_rand(C, seed=17).abs() + 0.5).to(dev), _rand(C, seed=18).to(dev)
+    gy = _rand(N, H, W, C, seed=21).to(dev)
+
+    def run(split):
+        monkeypatch.setattr(F, "BN_SPLIT", split)
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        x._sp_from_split = True                                  # as if a split-path conv had produced x: backward emits too
+        res = F.bn_act(r, ga, be, torch.zeros(C, device=dev), torch.ones(C, device=dev), None, training=True, relu=False)
+        y = F.bn_act(x, ga, be, rm, rv, res, training=True, relu=relu, emit_split=True)
+        seen = {}
+        x.register_hook(lambda g: seen.setdefault("dx", g))
+        y.backward(gy)
+        return y, x.grad, r.grad, ga.grad, be.grad, rm, rv, seen.get("dx")
+
+    ys, dxs, drs, dgs, dbs, rms, rvs, dx_obj = run(True)
+    assert isinstance(getattr(ys, "_sp_cache", None), dict) and "f16x2" in ys._sp_cache
+    yp, dxp, drp, dgp, dbp, rmp, rvp, _ = run(False)
+    assert getattr(yp, "_sp_cache", None) is None
+    for a, b, tol, what in ((ys, yp, 1e-6, "y"), (dxs, dxp, 1e-5, "dx"), (drs, drp, 1e-5, "dres"), (dgs, dgp, 1e-5, "dgamma"),
+                            (dbs, dbp, 1e-5, "dbeta"), (rms, rmp, 1e-6, "rmean"), (rvs, rvp, 1e-6, "rvar")):
+        _close(a, b, tol, what)
+    op = ys._sp_cache["f16x2"]
+    bound, true = float(op.scale[1]), float(ys.abs().max())
+    assert true <= bound <= 4 * true, (true, bound)
+    assert float((_decode_split(op, ys.shape) - ys.detach()).abs().max()) <= 2.0 ** -21 * bound
+    cache = getattr(dx_obj, "_sp_cache", None)
+    if cache is not None:                                        # the gradient object as the producing conv's backward sees it
+        opd = cache["f16x2"]
+        b2, t2 = float(opd.scale[1]), float(dxs.abs().max())
+        assert t2 <= b2 <= 8 * t2, (t2, b2)
+        assert float((_decode_split(opd, dxs.shape) - dxs).abs().max()) <= 2.0 ** -21 * b2
+
+
+def test_conv_epilogue_writes_the_batchnorm_statistics():
+    """conv2d(bn_stats=True) on the 2xfp16 path: per 256-row tile and output column the epilogue leaves sum / sum of squares (fp64)
+    and min / max (fp32) of the conv output -- exactly the first stage of bn_pool.hip's statistics; the BatchNorm behind it gives
+    the same result with and without them (ragged last tile: 2 x 63 x 65 = 8190 pixels)"""
+    from scanpaths_amd import functional as F
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3:
+        pytest.skip("2xfp16 back-end not active")
+    dev = _dev()
+    N, H, W, Ci, Co = 2, 63, 65, 128, 160
+    x = _rand(N, H, W, Ci, seed=51).to(dev)
+    w = (_rand(Co, Ci, 3, 3, seed=52, scale=0.05)).to(dev).contiguous(memory_format=torch.channels_last)
+    assert F.conv_takes_split(x.shape, w, pad=1)
+    y = F.conv2d(x, w, None, pad=1, bn_stats=True)
+    st = getattr(y, "_sp_bnstats", None)
+    assert st is not None and st[2] == (N * H * W + 255) // 256
+    y2 = y.reshape(-1, Co)
+    for t in (0, 7, st[2] - 1):
+        rows = y2[256 * t:256 * (t + 1)]
+        assert torch.equal(st[1][t, 0], rows.min(0).values) and torch.equal(st[1][t, 1], rows.max(0).values)
+        _close(st[0][t, 0], rows.double().sum(0), 1e-12, "tile sum")
+        _close(st[0][t, 1], (rows.double() ** 2).sum(0), 1e-12, "tile sum of squares")
+    ga, be = (_rand(Co, seed=53).abs() + 0.5).to(dev), _rand(Co, seed=54).to(dev)
+    outs = []
+    for use in (True, False):
+        yy = y.detach().clone()
+        if use:
+            yy._sp_bnstats = st
+        rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+        outs.append((F.bn_act(yy, ga, be, rm, rv, None, training=True, relu=True), rm, rv))
+    for a, b in zip(outs[0], outs[1]):
+        _close(a, b, 1e-6, "bn with / without epilogue statistics")
 
 
 @pytest.mark.parametrize("S,B,P,C", [(2, 3, 1200, 512), (1, 2, 333, 64), (2, 2, 2560, 512)])
