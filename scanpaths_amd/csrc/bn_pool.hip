@@ -14,6 +14,15 @@ constexpr int CB = 64;        // channels per block column (16 float4 lanes)
 constexpr int RL = 16;        // row lanes per block (256 threads = 16 x 16)
 constexpr int MAX_G = 256;    // row-slab count upper bound
 
+// slab count of the wide (256 channels per block column) backward reduction: more, shorter slabs keep >= 4 blocks per CU
+inline int pick_G_wide(int64_t M, int C) {
+    const int64_t colblocks = sp_cdiv(C, 256);
+    int64_t g = sp_cdiv(1024, colblocks);
+    g = std::min<int64_t>(g, sp_cdiv(M, 4 * 8));
+    g = std::min<int64_t>(g, 1024);
+    return (int)std::max<int64_t>(g, 1);
+}
+
 inline int pick_G(int64_t M, int C) {
     const int64_t colblocks = sp_cdiv(C, CB);
     int64_t g = sp_cdiv(2048, colblocks);              // ~8 blocks per CU overall
@@ -77,17 +86,19 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* x, int64_t 
 // Second stage of the column reductions: block = 32 channels x 8 slab lanes; each thread adds every 8th slab partial
 // (independent loads, G/8 deep instead of a G-deep dependent chain: 66 us -> ~8 us per call, ~110 calls per train step), the
 // 8 lane sums are combined in fixed order through LDS -> bitwise reproducible.  NV values per channel, layout [G][NV][C].
+// FC channels x FL slab lanes per block (FC * FL = 256): 32 x 8 for the <= 256 slabs of the column-reduction kernels, 8 x 32 for
+// the per-M-tile partials a conv epilogue leaves (up to M / 256 of them: 1280 at the 80x128 maps)
 constexpr int FIN_C = 32, FIN_L = 8;
-template <int NV>
+template <int NV, int FC = FIN_C, int FL = FIN_L>
 __device__ __forceinline__ bool final_reduce(const double* __restrict__ partial, int C, int G, int& c, double (&out)[NV]) {
-    __shared__ double shf[NV][FIN_L][FIN_C];
-    const int tx = threadIdx.x & (FIN_C - 1), ty = threadIdx.x / FIN_C;
-    c = blockIdx.x * FIN_C + tx;
+    __shared__ double shf[NV][FL][FC];
+    const int tx = threadIdx.x & (FC - 1), ty = threadIdx.x / FC;
+    c = blockIdx.x * FC + tx;
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
     if (c < C)
-        for (int g = ty; g < G; g += FIN_L)
+        for (int g = ty; g < G; g += FL)
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[v] += partial[((int64_t)g * NV + v) * C + c];
 #pragma unroll
@@ -98,7 +109,7 @@ __device__ __forceinline__ bool final_reduce(const double* __restrict__ partial,
     for (int v = 0; v < NV; ++v) {
         double s = 0.0;
 #pragma unroll
-        for (int l = 0; l < FIN_L; ++l) s += shf[v][l][tx];
+        for (int l = 0; l < FL; ++l) s += shf[v][l][tx];
         out[v] = s;
     }
     return true;
@@ -294,13 +305,14 @@ __global__ __launch_bounds__(256) void bn_stats_mm_partial(const float* __restri
 }
 
 // extrema of [G][2][C] float partials (min in slot 0, max in slot 1); valid where final_reduce returned true
+template <int FC = FIN_C, int FL = FIN_L>
 __device__ __forceinline__ void final_minmax(const float* __restrict__ mm, int C, int G, float& mn, float& mx) {
-    __shared__ float shx[2][FIN_L][FIN_C];
-    const int tx = threadIdx.x & (FIN_C - 1), ty = threadIdx.x / FIN_C;
-    const int c = blockIdx.x * FIN_C + tx;
+    __shared__ float shx[2][FL][FC];
+    const int tx = threadIdx.x & (FC - 1), ty = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + tx;
     float a = INFINITY, b = -INFINITY;
     if (c < C)
-        for (int g = ty; g < G; g += FIN_L) {
+        for (int g = ty; g < G; g += FL) {
             a = fminf(a, mm[((int64_t)g * 2 + 0) * C + c]);
             b = fmaxf(b, mm[((int64_t)g * 2 + 1) * C + c]);
         }
@@ -310,7 +322,7 @@ __device__ __forceinline__ void final_minmax(const float* __restrict__ mm, int C
     mn = INFINITY;
     mx = -INFINITY;
 #pragma unroll
-    for (int l = 0; l < FIN_L; ++l) {
+    for (int l = 0; l < FL; ++l) {
         mn = fminf(mn, shx[0][l][tx]);
         mx = fmaxf(mx, shx[1][l][tx]);
     }
@@ -329,15 +341,16 @@ __device__ __forceinline__ void commit_bound(float b, unsigned* slot) {
     }
 }
 
-__global__ __launch_bounds__(FIN_C * FIN_L) void bn_stats_mm_final(const double* partial, const float* mm, int64_t M, int C, int G,
-                                                                    float eps, float momentum, const float* gamma,
-                                                                    const float* beta, int relu, float* mean, float* invstd,
-                                                                    float* rmean, float* rvar, float* ext, unsigned* bound) {
+template <int FC, int FL>
+__global__ __launch_bounds__(256) void bn_stats_mm_final(const double* partial, const float* mm, int64_t M, int C, int G,
+                                                         float eps, float momentum, const float* gamma, const float* beta, int relu,
+                                                         float* mean, float* invstd, float* rmean, float* rvar, float* ext,
+                                                         unsigned* bound) {
     int c;
     double r[2];
     float mn, mx;
-    final_minmax(mm, C, G, mn, mx);
-    const bool own = final_reduce<2>(partial, C, G, c, r);
+    final_minmax<FC, FL>(mm, C, G, mn, mx);
+    const bool own = final_reduce<2, FC, FL>(partial, C, G, c, r);
     float bnd = 0.f;
     if (own) {
         const double mu = r[0] / (double)M;
@@ -400,18 +413,14 @@ __global__ __launch_bounds__(256) void bn_apply_split_kernel(const float* __rest
             }
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
-        if (live) {
-            if (y) reinterpret_cast<float4*>(y)[i] = o;
-            if (planes) {
-                ushort4 pa, pb;
-                split2(o.x, s, pa.x, pb.x);
-                split2(o.y, s, pa.y, pb.y);
-                split2(o.z, s, pa.z, pb.z);
-                split2(o.w, s, pa.w, pb.w);
-                uint16_t* po = planes + (i >> 2) * 32 + (int)(i & 3) * 4;
-                *reinterpret_cast<ushort4*>(po) = pa;
-                *reinterpret_cast<ushort4*>(po + 16) = pb;
-            }
+        if (live && y) reinterpret_cast<float4*>(y)[i] = o;
+        if (planes) {                  // (wave-uniform)
+            ushort4 pa, pb;
+            split2(o.x, s, pa.x, pb.x);
+            split2(o.y, s, pa.y, pb.y);
+            split2(o.z, s, pa.z, pb.z);
+            split2(o.w, s, pa.w, pb.w);
+            store_planes_quad(planes, i, live, pa, pb);
         }
     }
     if (planes && blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(planes + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
@@ -431,15 +440,19 @@ __device__ __forceinline__ float4 mask_select(const unsigned long long* __restri
     return d;
 }
 
+// TX lanes along the channels (x 4 channels each), 256 / TX row lanes: 16 x 16 for narrow maps, 64 x 4 for C >= 256 (a wave then
+// reads 1 KB contiguous per row instead of four 256-byte pieces)
+template <int TX>
 __global__ __launch_bounds__(256) void bn_bwd_mm_partial(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const unsigned long long* __restrict__ mask,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          int64_t M, int C, int G, double* __restrict__ partial,
                                                          float* __restrict__ dmax) {
-    __shared__ double sh[2][RL][CB + 1];
-    __shared__ float shm[RL][CB + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int c = blockIdx.x * CB + tx * 4;
+    constexpr int CBW = TX * 4, RLW = 256 / TX;
+    __shared__ double sh[2][RLW][CBW + 1];
+    __shared__ float shm[RLW][CBW + 1];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c = blockIdx.x * CBW + tx * 4;
     const int g = blockIdx.y;
     const int64_t rows_per = sp_cdiv_dev(M, G);
     const int64_t r0 = (int64_t)g * rows_per, r1 = min(M, r0 + rows_per);
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial(const float* __restrict
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
         const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
-        for (int64_t r = r0 + ty; r < r1; r += RL) {
+        for (int64_t r = r0 + ty; r < r1; r += RLW) {
             float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
             const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
             if (mask) d = mask_select(mask, (r * C + c) >> 2, d);
@@ -469,16 +482,16 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial(const float* __restrict
         shm[ty][tx * 4 + k] = mx[k];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * CB; i += 256) {
-        const int v = i / CB, cc = i % CB;
+    for (int i = threadIdx.x; i < 2 * CBW; i += 256) {
+        const int v = i / CBW, cc = i % CBW;
         double a = 0.0;
         float m = 0.f;
 #pragma unroll
-        for (int y = 0; y < RL; ++y) {
+        for (int y = 0; y < RLW; ++y) {
             a += sh[v][y][cc];
             m = fmaxf(m, shm[y][cc]);
         }
-        const int cg = blockIdx.x * CB + cc;
+        const int cg = blockIdx.x * CBW + cc;
         if (cg < C) {
             partial[((int64_t)g * 2 + v) * C + cg] = a;
             if (v == 0) dmax[(int64_t)g * C + cg] = m;
@@ -486,25 +499,25 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(FIN_C * FIN_L) void bn_bwd_mm_final(const double* partial, const float* dmax, int64_t M, int C, int G,
-                                                                  const float* gamma, const float* mean, const float* invstd,
-                                                                  const float* ext, float* dgamma, float* dbeta, float* coef,
-                                                                  unsigned* bound) {
-    __shared__ float shd[FIN_L][FIN_C];
-    const int tx = threadIdx.x & (FIN_C - 1), ty = threadIdx.x / FIN_C;
-    const int cc = blockIdx.x * FIN_C + tx;
+template <int FC, int FL>
+__global__ __launch_bounds__(256) void bn_bwd_mm_final(const double* partial, const float* dmax, int64_t M, int C, int G,
+                                                       const float* gamma, const float* mean, const float* invstd,
+                                                       const float* ext, float* dgamma, float* dbeta, float* coef, unsigned* bound) {
+    __shared__ float shd[FL][FC];
+    const int tx = threadIdx.x & (FC - 1), ty = threadIdx.x / FC;
+    const int cc = blockIdx.x * FC + tx;
     float dm = 0.f;
     if (cc < C)
-        for (int g = ty; g < G; g += FIN_L) dm = fmaxf(dm, dmax[(int64_t)g * C + cc]);
+        for (int g = ty; g < G; g += FL) dm = fmaxf(dm, dmax[(int64_t)g * C + cc]);
     shd[ty][tx] = dm;
     int c;
     double r[2];
-    const bool own = final_reduce<2>(partial, C, G, c, r);      // (contains the __syncthreads that publishes shd)
+    const bool own = final_reduce<2, FC, FL>(partial, C, G, c, r);      // (contains the __syncthreads that publishes shd)
     float bnd = 0.f;
     if (own) {
         dm = 0.f;
 #pragma unroll
-        for (int l = 0; l < FIN_L; ++l) dm = fmaxf(dm, shd[l][tx]);
+        for (int l = 0; l < FL; ++l) dm = fmaxf(dm, shd[l][tx]);
         dbeta[c] = (float)r[0];
         dgamma[c] = (float)r[1];
         const float k1 = (float)(r[0] / (double)M), k2 = (float)(r[1] / (double)M);
@@ -524,32 +537,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
                                                                  float* __restrict__ dx, float* __restrict__ dres,
                                                                  uint16_t* __restrict__ planes, float* __restrict__ dx_scale) {
     const float s = scale_of(*bound);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        float4 d = reinterpret_cast<const float4*>(dy)[i];
-        if (mask) d = mask_select(mask, i, d);
-        if (dres) reinterpret_cast<float4*>(dres)[i] = d;
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 a = reinterpret_cast<const float4*>(x)[i];
-        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-        const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
-        const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
-        float4 o;
-        o.x = ga.x * is.x * (d.x - k1.x - (a.x - mu.x) * is.x * k2.x);
-        o.y = ga.y * is.y * (d.y - k1.y - (a.y - mu.y) * is.y * k2.y);
-        o.z = ga.z * is.z * (d.z - k1.z - (a.z - mu.z) * is.z * k2.z);
-        o.w = ga.w * is.w * (d.w - k1.w - (a.w - mu.w) * is.w * k2.w);
-        if (dx) reinterpret_cast<float4*>(dx)[i] = o;
-        if (planes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n4; base += stride) {      // wave-uniform
+        const int64_t i = base + lane;
+        const bool live = i < n4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const int c = (int)((i * 4) % C);
+            float4 d = reinterpret_cast<const float4*>(dy)[i];
+            if (mask) d = mask_select(mask, i, d);
+            if (dres) reinterpret_cast<float4*>(dres)[i] = d;
+            const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 a = reinterpret_cast<const float4*>(x)[i];
+            const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+            const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
+            const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
+            o.x = ga.x * is.x * (d.x - k1.x - (a.x - mu.x) * is.x * k2.x);
+            o.y = ga.y * is.y * (d.y - k1.y - (a.y - mu.y) * is.y * k2.y);
+            o.z = ga.z * is.z * (d.z - k1.z - (a.z - mu.z) * is.z * k2.z);
+            o.w = ga.w * is.w * (d.w - k1.w - (a.w - mu.w) * is.w * k2.w);
+            if (dx) reinterpret_cast<float4*>(dx)[i] = o;
+        }
+        if (planes) {                  // (wave-uniform)
             ushort4 pa, pb;
             split2(o.x, s, pa.x, pb.x);
             split2(o.y, s, pa.y, pb.y);
             split2(o.z, s, pa.z, pb.z);
             split2(o.w, s, pa.w, pb.w);
-            uint16_t* po = planes + (i >> 2) * 32 + (int)(i & 3) * 4;
-            *reinterpret_cast<ushort4*>(po) = pa;
-            *reinterpret_cast<ushort4*>(po + 16) = pb;
+            store_planes_quad(planes, i, live, pa, pb);
         }
     }
     if (planes && blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(planes + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
@@ -781,7 +798,7 @@ extern "C" int sp_bn_backward(const float* dy, const float* x, const float* y, c
 }
 
 extern "C" int64_t sp_bn_split_workspace(int64_t M, int C) {
-    const int64_t G = pick_G(M, C);
+    const int64_t G = std::max(pick_G(M, C), pick_G_wide(M, C));
     return G * 2 * C * (int64_t)sizeof(double) + G * 2 * C * (int64_t)sizeof(float) + 2 * (int64_t)C * (int64_t)sizeof(float);
 }
 
@@ -810,8 +827,12 @@ extern "C" int sp_bn_fwd_split(const float* x, int64_t M, int C, float eps, floa
                            (float*)((double*)workspace + (int64_t)G * 2 * C));
         SP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_stats_mm_final, dim3((unsigned)sp_cdiv(C, FIN_C)), dim3(FIN_C * FIN_L), 0, s, partial, mm, M, C, G, eps,
-                       momentum, gamma, beta, relu, mean, invstd, running_mean, running_var, ext, bound);
+    if (G > 256)
+        hipLaunchKernelGGL((bn_stats_mm_final<8, 32>), dim3((unsigned)sp_cdiv(C, 8)), dim3(256), 0, s, partial, mm, M, C, G, eps,
+                           momentum, gamma, beta, relu, mean, invstd, running_mean, running_var, ext, bound);
+    else
+        hipLaunchKernelGGL((bn_stats_mm_final<FIN_C, FIN_L>), dim3((unsigned)sp_cdiv(C, FIN_C)), dim3(256), 0, s, partial, mm, M, C,
+                           G, eps, momentum, gamma, beta, relu, mean, invstd, running_mean, running_var, ext, bound);
     SP_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
     hipLaunchKernelGGL(bn_apply_split_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, mean, invstd, gamma, beta, residual, bound,
@@ -828,16 +849,25 @@ extern "C" int sp_bn_bwd_split(const float* dy, const float* x, const unsigned l
     if (!dx && !planes) return SP_ENULL;
     if (C % 4 || (planes && C % 16) || M <= 0 || ((uintptr_t)planes & 15)) return SP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int G = pick_G(M, C);
+    const bool wide = C >= 256 && C % 256 == 0;
+    const int G = wide ? pick_G_wide(M, C) : pick_G(M, C);
     double* partial = (double*)workspace;
     float* dmax = (float*)(partial + (int64_t)G * 2 * C);
     float* coef = dmax + (int64_t)G * 2 * C;
     SP_RESET_AMAX(bound, s);
-    hipLaunchKernelGGL(bn_bwd_mm_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, dy, x, mask, mean, invstd, M, C, G,
-                       partial, dmax);
+    if (wide)
+        hipLaunchKernelGGL(bn_bwd_mm_partial<64>, dim3((unsigned)(C / 256), G), dim3(256), 0, s, dy, x, mask, mean, invstd, M, C, G,
+                           partial, dmax);
+    else
+        hipLaunchKernelGGL(bn_bwd_mm_partial<16>, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, dy, x, mask, mean, invstd, M, C,
+                           G, partial, dmax);
     SP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_mm_final, dim3((unsigned)sp_cdiv(C, FIN_C)), dim3(FIN_C * FIN_L), 0, s, partial, dmax, M, C, G, gamma,
-                       mean, invstd, ext, dgamma, dbeta, coef, bound);
+    if (G > 256)
+        hipLaunchKernelGGL((bn_bwd_mm_final<8, 32>), dim3((unsigned)sp_cdiv(C, 8)), dim3(256), 0, s, partial, dmax, M, C, G, gamma,
+                           mean, invstd, ext, dgamma, dbeta, coef, bound);
+    else
+        hipLaunchKernelGGL((bn_bwd_mm_final<FIN_C, FIN_L>), dim3((unsigned)sp_cdiv(C, FIN_C)), dim3(256), 0, s, partial, dmax, M, C,
+                           G, gamma, mean, invstd, ext, dgamma, dbeta, coef, bound);
     SP_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_split_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, mask, mean, invstd, gamma, coef,

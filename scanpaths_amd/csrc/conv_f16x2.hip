@@ -461,8 +461,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
     int stage = 0;
-    const bool late = VAR >= 1 && VAR <= 3 && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
-    if (VAR == 3 && late) __builtin_amdgcn_s_setprio(1);
+    const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
+    if ((VAR == 3 || VAR == 5) && late) __builtin_amdgcn_s_setprio(1);
     if constexpr (VAR == 4 && M16 && do_mma && do_load) {
         for (int kt = 0; kt < p.nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < p.nkt;
@@ -486,8 +486,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
             // prefetch of tile kt+2 into the stage read in iteration kt-1: VAR >= 2 issues it FIRST (its partner wave is in its
             // matrix segment now), the lockstep / half-stagger variants behind the MFMAs in program order (see b3_kernel)
-            if (VAR >= 2 && pre) issue_tile(prev_stage(stage));
+            if (VAR >= 2 && VAR != 5 && pre) issue_tile(prev_stage(stage));
             read_frags(stage, kt);
+            if (VAR == 5 && pre) issue_tile(prev_stage(stage));          // VAR 5 (= 3 with the fragment reads ahead of the issue block)
             mma_group(0);
             mma_group(1);
             if (VAR < 2 && pre) issue_tile(prev_stage(stage));
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         mma_group(1);
         fold(p.nkt - 1);
     }
-    if (VAR == 3 && late) __builtin_amdgcn_s_setprio(0);
+    if ((VAR == 3 || VAR == 5) && late) __builtin_amdgcn_s_setprio(0);
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
@@ -748,7 +749,9 @@ __device__ __forceinline__ int unpermB16(int x) { return ((x & 0x18) >> 1) | ((x
 template <int VAR, int NPROD = 3, bool M16 = false, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     // DBG 5: LDS-DMA loads only (no fragment reads, no MFMAs; barriers kept); DBG 6: fragment reads only (no loads, no MFMAs)
-    constexpr bool do_load = DBG != 1 && DBG != 3 && DBG != 6, do_mma = DBG != 2 && DBG != 5 && DBG != 6, do_lds = DBG != 3 && DBG != 5;
+    // DBG 7: dY (A) loads only + everything else; DBG 8: X (B) loads only + everything else; DBG 9: loads + MFMAs, no fragment reads
+    constexpr bool do_load = DBG != 1 && DBG != 3 && DBG != 6, do_mma = DBG != 2 && DBG != 5 && DBG != 6, do_lds = DBG != 3 && DBG != 5 && DBG != 9;
+    constexpr bool load_a = DBG != 8, load_b = DBG != 7;
     constexpr bool do_bar = DBG != 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -855,13 +858,13 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = a_cok[j] && a_r[j] < rows_left;
-            SP_GLDS16(baseA + (ok ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
+            if constexpr (load_a) SP_GLDS16(baseA + (ok ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
         }
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.X);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)b_iy[j] < (unsigned)p.Hi && (unsigned)b_ix[j] < (unsigned)p.Wi;
-            SP_GLDS16(baseB + (ok ? b_off[j] : p.x_bytes), st + HWA_BYTES + (wave + 8 * j) * 1024);
+            if constexpr (load_b) SP_GLDS16(baseB + (ok ? b_off[j] : p.x_bytes), st + HWA_BYTES + (wave + 8 * j) * 1024);
             // advance this lane's pixel by 32 for the next K-tile (no divisions, no multiplications)
             b_x[j] += x_adv;
             b_y[j] += y_adv;
@@ -943,7 +946,9 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     {
         int issued = 0;
         for (; issued < HNSTAGE - 1 && issued < nkt; ++issued) issue_tile(issued);
-        if (issued >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (issued >= 2 && DBG == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (issued >= 2 && DBG == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (issued >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -1039,7 +1044,9 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         }
     };
     auto wait_barrier = [&](int kt_) {
-        if (kt_ + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (kt_ + 2 < nkt && DBG == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kt_ + 2 < nkt && DBG == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (kt_ + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (do_bar) __builtin_amdgcn_s_barrier();
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
-            if (VAR >= 2 && pre) issue_tile(prev_stage(stage));
+            if (VAR >= 2 && VAR != 4 && pre) issue_tile(prev_stage(stage));
             if (VAR == 0 && !M16) {         // round-1 order: reads of a 16-pixel group right before its MFMAs
                 read_group(stage, 0);
                 mma_group(0);
@@ -1061,6 +1068,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             } else {
                 read_group(stage, 0);
                 read_group(stage, 1);
+                if (VAR == 4 && pre) issue_tile(prev_stage(stage));      // VAR 4: fragment reads ahead of the LDS-DMA issue block
                 mma_group(0);
                 mma_group(1);
             }
@@ -1202,18 +1210,18 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* x, int64_t n4, i
 __global__ __launch_bounds__(256) void split2_kernel(const float* x, int64_t n4, const unsigned* amax, uint16_t* out,
                                                      float* scale_out) {
     const float s = scale_of(*amax);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n4; base += stride) {      // wave-uniform
+        const int64_t i = base + lane;
+        const bool live = i < n4;
+        const float4 v = live ? reinterpret_cast<const float4*>(x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         ushort4 a, b;
         split2(v.x, s, a.x, b.x);
         split2(v.y, s, a.y, b.y);
         split2(v.z, s, a.z, b.z);
         split2(v.w, s, a.w, b.w);
-        const int64_t g = i >> 2;            // 16-k group
-        const int sub = (int)(i & 3) * 4;
-        uint16_t* o = out + g * 32 + sub;
-        *reinterpret_cast<ushort4*>(o) = a;
-        *reinterpret_cast<ushort4*>(o + 16) = b;
+        store_planes_quad(out, i, live, a, b);
     }
     if (blockIdx.x == 0 && threadIdx.x < 8)       // 64-byte zero block right after the data
         reinterpret_cast<uint2*>(out + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
@@ -1359,9 +1367,11 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
     // bit 3 = channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
     const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
+    if (variant == 17 && !cbm_ok) variant = 7;
     if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
     switch (variant) {
         case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
+        case 17: return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);      // = 15, reads before the issue block
         case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
         case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
         case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
@@ -1473,6 +1483,9 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     else if (dbg == 4) rc = launch_hw<2, 3, false, 1>(a, d->Co, s);
     else if (dbg == 5) rc = launch_hw<2, 3, true, 5>(a, d->Co, s);
     else if (dbg == 6) rc = launch_hw<2, 3, true, 6>(a, d->Co, s);
+    else if (dbg == 7) rc = launch_hw<2, 3, true, 7>(a, d->Co, s);
+    else if (dbg == 8) rc = launch_hw<2, 3, true, 8>(a, d->Co, s);
+    else if (dbg == 9) rc = launch_hw<2, 3, true, 9>(a, d->Co, s);
     else if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);
     else switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
         case 0: rc = launch_hw<0>(a, d->Co, s); break;
@@ -1480,6 +1493,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
         case 3: rc = launch_hw<3>(a, d->Co, s); break;
         case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
         case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
+        case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
         default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
     }
     if (rc != SP_OK) return rc;
