@@ -13,6 +13,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default
+enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_AMAX_RESET = 4, SP_TUNE_COUNT = 5 };
+extern int sp_tuning_values[SP_TUNE_COUNT];
+static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }
+
 // A producer's fused-amax slot is zeroed IN STREAM ORDER by the producer's own launcher, so every launch -- eager or a HIP-graph
 // replay on new inputs -- starts from 0 instead of max(old, new).  A one-thread KERNEL, not hipMemsetAsync: 4-byte memset nodes
 // captured into a HIP graph did not reliably precede the kernels that follow them on replay (replays at a different input
@@ -22,18 +27,30 @@ __global__ void sp_zero_words_kernel(unsigned* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
 }
 }  // namespace
-#define SP_RESET_AMAX(ptr, stream)                                                                                          \
+// sp_set_tuning("amax_reset", 1): the caller hands in ZEROED slots (the Python host draws every slot from a zero-filled pool and never
+// reuses one), so the reset node is only added while the stream is being captured into a graph (a replay re-uses the slot);
+// ~350 one-thread launches per training step otherwise.  Default 0: always reset.
+static inline bool sp_reset_needed(hipStream_t s) {
+    if (sp_tuning_get(SP_TUNE_AMAX_RESET, 0) != 1) return true;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) return true;
+    return st != hipStreamCaptureStatusNone;
+}
+#define SP_RESET_AMAX_ALWAYS(ptr, stream)                                                                                   \
     do {                                                                                                                    \
         if (ptr) {                                                                                                          \
             hipLaunchKernelGGL(sp_zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)(stream), (unsigned*)(ptr), 1);     \
             SP_LAUNCH_CHECK();                                                                                              \
         }                                                                                                                   \
     } while (0)
+#define SP_RESET_AMAX(ptr, stream)                                                                                          \
+    do {                                                                                                                    \
+        if ((ptr) && sp_reset_needed((hipStream_t)(stream))) {                                                              \
+            hipLaunchKernelGGL(sp_zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)(stream), (unsigned*)(ptr), 1);     \
+            SP_LAUNCH_CHECK();                                                                                              \
+        }                                                                                                                   \
+    } while (0)
 
-// process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default
-enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_COUNT = 4 };
-extern int sp_tuning_values[SP_TUNE_COUNT];
-static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }
 
 static inline int64_t sp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -32,8 +32,8 @@ constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
 constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
 constexpr int HW_DEFAULT_MAP = 0;                // sp_set_tuning("hw_map", 1): aligned-rounds workgroup order of hw_kernel
-constexpr int H2_DEFAULT_VARIANT = 15;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
-constexpr int HW_DEFAULT_VARIANT = 6;            // schedule variant of hw_kernel
+constexpr int H2_DEFAULT_VARIANT = 17;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
+constexpr int HW_DEFAULT_VARIANT = 8;            // schedule variant of hw_kernel
 
 struct H2Args {
     const uint16_t* X;    // [pixels][Kc/16][2][16]
@@ -1280,7 +1280,7 @@ int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
 }
 
 int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
-    SP_RESET_AMAX(amax, s);          // a kernel node, not a memset node: see common.h
+    SP_RESET_AMAX_ALWAYS(amax, s);   // scratch word of the caller's scale buffer (not a pooled slot); a kernel node, not a memset node: see common.h
     const int64_t n4 = n / 4;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256 * 4), 1024));
     hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, n, amax);
@@ -1351,7 +1351,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (st_partial) {        // fused BatchNorm statistics: forward, fp32-faithful, the 16x16x32 build only
         if (!f || !st_mm || nprod != 3 || d->beta || d->relu || bias) return SP_EINVAL;
         a.st_partial = st_partial; a.st_mm = st_mm;
-        return (d->KH * d->KW > 1 && d->KH * d->KW <= 32) ? launch_h2<0, 0, 3, 3, true, true>(a, st)
+        return (d->KH * d->KW > 1 && d->KH * d->KW <= 32) ? launch_h2<0, 0, 5, 3, true, true>(a, st)
                                                           : launch_h2<0, 0, 3, 3, true, false>(a, st);
     }
     if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
@@ -1440,7 +1440,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);
-    return launch_h2<0, 0, 3, 3, true, true, true>(a, st);
+    return launch_h2<0, 0, 5, 3, true, true, true>(a, st);
 }
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {

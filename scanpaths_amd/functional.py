@@ -344,6 +344,49 @@ def fanout(x: torch.Tensor, n: int):
     return outs
 
 
+GRAD_MERGE = os.environ.get("SP_GRAD_MERGE", "1") != "0"
+
+
+class GradMerge:
+    """Shared by the two consumers of a ResNet block input (conv1 and the identity branch / the downsample conv): the consumer whose
+    backward runs first leaves its input gradient in ``first``; conv1's data-gradient GEMM -- always the last to run, it sits at
+    the end of the block's backward chain -- then accumulates into that buffer (epilogue beta = 1) instead of writing its own tensor
+    for autograd to add: one read + one write of the block-input gradient instead of a write, two reads and a write."""
+    __slots__ = ("first", "merged")
+
+    def __init__(self):
+        self.first, self.merged = None, False
+
+
+class _Tap(Function):
+    """x -> (x for conv1, x for the other consumer); backward returns the merged gradient when conv1 accumulated into the other
+    consumer's buffer (GradMerge), else the sum of the two."""
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_main, g_side):
+        h = ctx.holder
+        merged, h.first, h.merged = h.merged, None, False
+        if g_main is None or g_side is None:
+            return (g_main if g_side is None else g_side), None
+        if merged:
+            return g_main, None                      # = the other consumer's buffer, conv1's data gradient already added
+        return _add_raw(g_main.contiguous(), g_side.contiguous()), None
+
+
+def tap(x: torch.Tensor, holder: GradMerge):
+    outs = _Tap.apply(x, holder)
+    for attr in ("_sp_cache", "_sp_amax"):
+        v = getattr(x, attr, None)
+        if v is not None:
+            for o in outs:
+                setattr(o, attr, v)
+    return outs
+
+
 class _ScaleConst(Function):
     @staticmethod
     def forward(ctx, x, c):
@@ -384,7 +427,9 @@ def _out_hw(H, W, KH, KW, stride, pad, dil):
 # ----------------------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None, bn_stats=False):
+    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None, bn_stats=False, grad_store=None, grad_accum=None):
+        # grad_store / grad_accum: GradMerge of a block input -- leave the input gradient there / accumulate into what is there
+        ctx.grad_store, ctx.grad_accum = grad_store, grad_accum
         # wcache: dict shared by all applications of the SAME weight inside one forward/backward (the h-gate conv runs T times):
         # its split forms ("w": forward operand, "wT": data-gradient operand) are produced once instead of per step
         x = x.contiguous()
@@ -439,20 +484,28 @@ class _Conv2d(Function):
             dyr = torch.empty_like(dy)
             check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
             dy = dyr
-        dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                accum=ctx.grad_accum)
+        if ctx.grad_store is not None and dx is not None:
+            ctx.grad_store.first = dx
         db = _colsum_any(dy, wp.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw):
-    """data and weight gradient of y = conv(x, wp) (NHWC, physical weight [Co,KH,KW,Ci]); xs: the forward's split x or None"""
+def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None):
+    """data and weight gradient of y = conv(x, wp) (NHWC, physical weight [Co,KH,KW,Ci]); xs: the forward's split x or None;
+    accum: GradMerge whose ``first`` (another consumer's gradient of x) the data gradient is added to in place"""
     N, H, W_, Ci = x.shape
     Co, KH, KW, _ = wp.shape
     _, Ho, Wo, _ = dy.shape
     dx = dw = None
     dys = None
     if need_dx:
-        dx = torch.empty_like(x)
+        beta = 0
+        if accum is not None and accum.first is not None and accum.first.shape == x.shape and accum.first.is_contiguous():
+            dx, beta, accum.merged = accum.first, 1, True
+        else:
+            dx = torch.empty_like(x)
         if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel()):
             dys = split_op(dy)
             wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
@@ -461,10 +514,10 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw):
                 if wcache is not None:
                     wcache[("wT", dys.scheme)] = wT
             _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
-                      ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+                      ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
         else:
             _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
-                   KW=KW, stride=stride, pad=pad, dil=dil, mode=1)
+                   KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
     if need_dw:
         dwp = torch.empty_like(wp)
         wsch = _wgrad_scheme(Ci, Co)
@@ -488,8 +541,8 @@ def conv_takes_split(x_shape, w, stride=1, pad=0, dil=1) -> bool:
     return _scheme_for(Ci) == "f16x2" and _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=N * H * W_ * Ci, free_a=True)
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None, bn_stats=False):
-    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache, bn_stats)
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None, bn_stats=False, grad_store=None, grad_accum=None):
+    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache, bn_stats, grad_store, grad_accum)
 
 
 class _PadLast(Function):
@@ -680,7 +733,8 @@ class _BnActSplit(Function):
     measured one, and the ReLU mask as one bit per element instead of the fp32 output.  emit_fwd / emit_bwd: whether the split
     operands will be read (else only the bound is attached as the max|.| hint)."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre, res_store=None):
+        ctx.res_store = res_store          # GradMerge: the residual's gradient is left there for conv1's data gradient to add to
         # pre: (partial, mm, G) -- first statistics stage already done by the producing conv's epilogue (conv2d bn_stats=True)
         x = x.contiguous()
         Cc = x.shape[-1]
@@ -732,16 +786,19 @@ class _BnActSplit(Function):
         dx._sp_amax = dhint
         if planes is not None:
             dx._sp_cache = {"f16x2": SplitOperand(planes, dhint, "f16x2")}
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        if ctx.res_store is not None and dres is not None:
+            ctx.res_store.first = dres
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
-def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True, emit_split=False):
+def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True, emit_split=False,
+           res_store=None):
     """emit_split: the output feeds a conv that runs on the 2xfp16 split path -- the BatchNorm pass writes that operand itself"""
     if (training and BN_SPLIT and x.shape[-1] % 4 == 0 and _amax_hint_active()
             and (residual is None or getattr(residual, "_sp_amax", None) is not None)):
         emit_bwd = getattr(x, "_sp_from_split", False)       # the producing conv's backward GEMMs read the split gradient
         return _BnActSplit.apply(x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_split, emit_bwd,
-                                 getattr(x, "_sp_bnstats", None))
+                                 getattr(x, "_sp_bnstats", None), res_store)
     return _BnAct.apply(x, gamma, beta, rmean, rvar, residual, training, momentum, eps, relu)
 
 

@@ -149,6 +149,10 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         if _lib.sp_abi_version() != 1:
             raise RuntimeError("libscanpaths_amd.so ABI version mismatch")
+        # every max|.| slot this host passes comes zeroed from functional._amax_hint's pool and is used once: the launchers add
+        # their reset node only while a stream is being captured (graph replays re-use the slot)
+        if not os.environ.get("SP_ALWAYS_RESET_AMAX"):
+            check(_lib.sp_set_tuning(b"amax_reset", 1), "sp_set_tuning")
         for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant")):      # A/B timing / profiling only
             if os.environ.get(env):
                 check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")

@@ -414,6 +414,42 @@ def test_state_dict_roundtrip_and_no_cpu_path():
         assert torch.equal(v.cpu(), sd[k])
 
 
+def test_encoder_fusions_do_not_change_the_training_step(monkeypatch):
+    """Round-2 fusions of the encoder -- BatchNorm passes that emit split operands / bit masks / take their statistics from the conv
+    epilogue (F.BN_SPLIT), conv1's data gradient accumulated into the other consumer's gradient of the block input (F.GRAD_MERGE),
+    ConvLSTM cell in the h-gate conv epilogue (F.FUSE_GATE_LSTM) -- against the plain kernels: same loss and gradients to fp32
+    rounding (operand scales from bounds instead of measured maxima, fused multiply-adds in the BN affine map)."""
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    T = 3
+    b = {k: v.to(DEV) for k, v in make_batch("AiR", 4, 256, 512, T, seed=5).items()}       # 32 x 64 map: 2048 pixels, P % 256 == 0
+
+    def run(on):
+        for flag in ("BN_SPLIT", "GRAD_MERGE", "FUSE_GATE_LSTM"):
+            monkeypatch.setattr(F, flag, on)
+        m = baseline(convLSTM_length=T, map_width=64, map_height=32)
+        fill_module(m, 5, family="tame")
+        m = m.to(DEV).train()
+        pred = m(b["images"], b["attention_maps"], b["performances"])
+        loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, \
+            {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+
+    l1, g1, s1 = run(True)
+    l0, g0, s0 = run(False)
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l1, l0)
+    assert g1.keys() == g0.keys() and s1.keys() == s0.keys()
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    worst = max((float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-3 * gmax), k) for k in g0)
+    assert worst[0] <= 2e-4, worst
+    for k in s0:
+        assert torch.allclose(s1[k].float(), s0[k].float(), rtol=1e-5, atol=1e-6), k
+
+
 def test_full_size_train_step_is_reproducible_and_finite():
     """BASELINE.json config 2 EXACTLY (AiR train step, 320x512, per-GPU batch 32, T = 16 decode steps): two steps from the
     same initial state give BIT-IDENTICAL losses, gradient norms and parameters (every reduction in the path has a fixed order,
