@@ -204,7 +204,8 @@ int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, vo
 /* dx = dy * (y > 0)  (ReLU fused into a conv epilogue, e.g. F.relu(sal_conv(x)) baseline_attention.py:270) */
 /* out = inputs[0] + ... + inputs[count-1] in list order (count <= 32 host array of device pointers, n % 4 == 0): the gradient
  * fan-in of a tensor consumed by every decode step (x-gate pre-activations), one pass instead of count-1 adds */
-int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, void* stream);
+int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out,
+             unsigned* out_amax /* nullable: float bits of max|out|, as sp_bn_apply's y_amax */, void* stream);
 int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
 /* out = a + b (residual joins in backward), n elements */
 int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream);
@@ -240,6 +241,14 @@ int sp_sempool_bwd(const float* dout, const float* out, const float* a, const fl
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
                           unsigned* dpre_amax /* nullable, as y_amax */, void* stream);
+/* as above, and (planes != NULL) dpre also as the 2xfp16 split operand of the h-gate conv's backward GEMMs, scale from the bound
+ * max(D, max|dh| * c_bound / 4, D * cprev_bound / 4), D = max|dh| + max|dc|  (dh_amax / dc_amax: device words with the float bits
+ * of (bounds of) the maxima; c_bound >= max|c_out|, cprev_bound >= max|c_prev|: t + 1 and t after t + 1 steps).  dcp_amax
+ * (nullable) receives max|dc_prev|.  planes: 2 * rows * 4C fp16 + 64 zero bytes; dpre_scale [2] = {scale, bound}.  C % 256 == 0. */
+int sp_lstm_pointwise_bwd_split(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* c_out,
+                                int64_t rows, int C, float* dpre, float* dc_prev, unsigned* dpre_amax, unsigned* dcp_amax,
+                                const unsigned* dh_amax, const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
+                                float* dpre_scale, void* stream);
 
 /* 3x3 zero-padded im2col of single-channel maps [R][H][W] into columns [koff,koff+9) of col[r][p][ldk], and adjoint.
  * Feeds the rank-1 gate convolutions conv3x3(W, spatial (x) semantic) (baseline_attention.py:40-50) and the

@@ -709,7 +709,9 @@ struct SumList {
     const float* p[32];
     int n;
 };
-__global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t n4) {
+__global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t n4, unsigned* amax) {
+    __shared__ float sh4[4];
+    float mx = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 acc = reinterpret_cast<const float4*>(l.p[0])[i];
         for (int k = 1; k < l.n; ++k) {
@@ -717,7 +719,9 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         reinterpret_cast<float4*>(o)[i] = acc;
+        mx = amax4(mx, acc.x, acc.y, acc.z, acc.w);
     }
+    if (amax) block_amax_commit(mx, amax, sh4);
 }
 __global__ __launch_bounds__(256) void add_tail_kernel(const float* a, const float* b, float* o, int64_t start, int64_t n) {
     const int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -959,7 +963,7 @@ extern "C" int sp_add(const float* a, const float* b, float* out, int64_t n, voi
     return SP_OK;
 }
 
-extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, void* stream) {
+extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, unsigned* out_amax, void* stream) {
     if (!inputs || !out) return SP_ENULL;
     if (count < 1 || count > 32 || n % 4) return SP_EINVAL;
     SumList l;
@@ -968,7 +972,8 @@ extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float*
         if (!inputs[k]) return SP_ENULL;
         l.p[k] = inputs[k];
     }
-    hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4);
+    SP_RESET_AMAX(out_amax, stream);
+    hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4, out_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -268,6 +268,31 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     const unsigned char *pc_baseA = nullptr, *pc_baseB = nullptr;
     int pc_stage = 0;
     auto prepare_tile = [&](int stage) {
+        if constexpr (CBM) {
+            const int step = (ld_ky * p.Wi + ld_kx) * p.dil;
+            const uint32_t delta = (uint32_t)(MODE == 0 ? step : -step) * (uint32_t)rowbytes;
+            const uint32_t koffA = (uint32_t)ld_cblk * 128u;
+            pc_baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
+            const uint32_t zrelA = p.x_bytes - koffA;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pc_off[j] = ((a_mask[j] >> ld_tap) & 1u) ? a_base0[j] + delta : zrelA;
+            const uint32_t koffB = (uint32_t)(ld_tap * p.ncblk + ld_cblk) * 128u;
+            pc_baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
+            const uint32_t zrelB = p.w_bytes - koffB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pc_off[4 + j] = b_ok[j] ? b_voff[j] : zrelB;
+            pc_stage = stage;
+            ++ld_tap;
+            if (++ld_kx == p.KW) {
+                ld_kx = 0;
+                if (++ld_ky == p.KH) {
+                    ld_ky = 0;
+                    ld_tap = 0;
+                    ++ld_cblk;
+                }
+            }
+            return;
+        }
         if (ld_cblk == 0) tap_update();
         const uint32_t koffA = (uint32_t)ld_cblk * 128u;
         pc_baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
@@ -460,10 +485,56 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
+    // the 48 MFMAs of a K-tile with the six prepared LDS-DMA pieces issued one after every eighth (an issue among queued MFMAs
+    // costs ~60 cycles and the matrix pipe keeps draining its backlog meanwhile; as a block the six cost 100-185 cycles each)
+    auto mma_spread = [&](bool pre_) {
+        if constexpr (M16 && do_mma) {
+#pragma unroll
+            for (int pr = 0; pr < 16; ++pr) {
+                const int i = pr >> 2, j = pr & 3;
+                f32x4& a4 = acc4[i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                if (((pr + 1) * 6) / 16 != (pr * 6) / 16 && pre_) issue_piece((pr * 6) / 16);
+            }
+        }
+    };
+
     int stage = 0;
-    const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
-    if ((VAR == 3 || VAR == 5) && late) __builtin_amdgcn_s_setprio(1);
-    if constexpr (VAR == 4 && M16 && do_mma && do_load) {
+    const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5 || VAR == 6) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
+    if ((VAR == 3 || VAR == 5 || VAR == 6) && late) __builtin_amdgcn_s_setprio(1);
+    if constexpr (VAR == 6 && M16 && do_mma && do_load) {
+        // VAR 6: ping-pong (as 3) with the LDS-DMA pieces spread through each wave's OWN matrix segment
+        if (!late) {
+            for (int kt = 0; kt < p.nkt; ++kt) {
+                const bool pre = kt + HNSTAGE - 1 < p.nkt;
+                read_frags(stage, kt);
+                if (pre) prepare_tile(prev_stage(stage));
+                mma_spread(pre);
+                fold(kt);
+                wait_barrier(kt);
+                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+            }
+        } else {
+            for (int kt = 0; kt < p.nkt; ++kt) {
+                const bool pre = kt + HNSTAGE - 1 < p.nkt;
+                if (pre) prepare_tile(prev_stage(stage));
+                if (kt > 0) {
+                    mma_spread(pre);                        // tile kt-1 (fragments read before the last barrier) + loads of tile kt+2
+                    fold(kt - 1);
+                } else if (pre) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) issue_piece(q);
+                }
+                read_frags(stage, kt);
+                wait_barrier(kt);
+                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+            }
+            mma_spread(false);
+            fold(p.nkt - 1);
+        }
+    } else if constexpr (VAR == 4 && M16 && do_mma && do_load) {
         for (int kt = 0; kt < p.nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < p.nkt;
             if (pre) prepare_tile(prev_stage(stage));
@@ -528,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         mma_group(1);
         fold(p.nkt - 1);
     }
-    if ((VAR == 3 || VAR == 5) && late) __builtin_amdgcn_s_setprio(0);
+    if ((VAR == 3 || VAR == 5 || VAR == 6) && late) __builtin_amdgcn_s_setprio(0);
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
@@ -892,6 +963,55 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         }
         ++ld_kt;
     };
+    // VAR 5: the same six pieces prepared up front (addresses, coordinate advance) and issued one at a time between MFMAs
+    uint32_t pc_off[6];
+    const unsigned char* pc_baseA = nullptr;
+    int pc_stage = 0;
+    auto prepare_tile = [&](int stage) {
+        const int64_t mt = m_begin + (int64_t)ld_kt * 32;
+        pc_baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (4 * (int64_t)p.Co);
+        const uint32_t zrelA = (uint32_t)((int64_t)p.y_bytes - mt * (4 * (int64_t)p.Co));
+        const int rows_left = (int)min((int64_t)32, m_end - mt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pc_off[j] = (a_cok[j] && a_r[j] < rows_left) ? a_voff[j] : zrelA;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)b_iy[j] < (unsigned)p.Hi && (unsigned)b_ix[j] < (unsigned)p.Wi;
+            pc_off[4 + j] = ok ? b_off[j] : p.x_bytes;
+            b_x[j] += x_adv;
+            b_y[j] += y_adv;
+            b_ix[j] += adv_ix;
+            b_iy[j] += adv_iy;
+            b_off[j] += adv_off;
+            if (b_x[j] >= p.Wo) {
+                b_x[j] -= p.Wo;
+                ++b_y[j];
+                b_ix[j] -= wrapx_ix;
+                b_iy[j] += p.stride;
+                b_off[j] += wrapx_off;
+            }
+            if (b_y[j] >= p.Ho) {
+                b_y[j] -= p.Ho;
+                b_iy[j] -= wrapy_iy;
+                b_off[j] += wrapy_off;
+            }
+            if (tiny_map)
+                while (b_y[j] >= p.Ho) {
+                    b_y[j] -= p.Ho;
+                    b_iy[j] -= wrapy_iy;
+                    b_off[j] += wrapy_off;
+                }
+        }
+        pc_stage = stage;
+        ++ld_kt;
+    };
+    auto issue_piece = [&](int q) {
+        unsigned char* st = smem + pc_stage * HWSTAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < 4) SP_GLDS16(pc_baseA + pc_off[q], st + (wave + 8 * q) * 1024);
+        else SP_GLDS16(reinterpret_cast<const unsigned char*>(p.X) + pc_off[q], st + HWA_BYTES + (wave + 8 * (q - 4)) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // transposed-read offsets.  32x32x16: k-group kk adds 16 pixel rows; lane (g4 = (lane>>4)&1, q = (lane>>2)&3, pp = lane&3)
     // addresses pixel row 8h + 4s + q, channels cbase + 16*g4 + 4pp .. +3 of plane pl.  16x16x32: the 16-lane group kg = lane>>4
@@ -1053,10 +1173,57 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
+    auto mma_spread = [&](bool pre_) {
+        if constexpr (M16 && do_mma && NPROD == 3) {
+#pragma unroll
+            for (int pr = 0; pr < 16; ++pr) {
+                const int i = pr >> 2, j = pr & 3;
+                f32x4& a4 = acc4[i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
+                if (((pr + 1) * 6) / 16 != (pr * 6) / 16 && pre_) issue_piece((pr * 6) / 16);
+            }
+        }
+    };
+
     int stage = 0;
     const bool late = VAR != 0 && wave >= 4;
-    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(1);
-    if (!late) {
+    if (VAR >= 3 && VAR != 5 && late) __builtin_amdgcn_s_setprio(1);
+    if constexpr (VAR == 5 && M16 && do_mma && do_load && NPROD == 3 && DBG == 0) {
+        if (!late) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool pre = kt + HNSTAGE - 1 < nkt;
+                read_group(stage, 0);
+                read_group(stage, 1);
+                if (pre) prepare_tile(prev_stage(stage));
+                mma_spread(pre);
+                fold(kt);
+                wait_barrier(kt);
+                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+            }
+        } else {
+            for (int kt = 0; kt < nkt; ++kt) {
+                const bool pre = kt + HNSTAGE - 1 < nkt;
+                if (pre) prepare_tile(prev_stage(stage));
+                if (kt > 0) {
+                    mma_spread(pre);
+                    fold(kt - 1);
+                } else if (pre) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) issue_piece(q);
+                }
+                read_group(stage, 0);
+                read_group(stage, 1);
+                wait_barrier(kt);
+                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+            }
+            if (nkt > 0) {
+                mma_spread(false);
+                fold(nkt - 1);
+            }
+        }
+    } else if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
             if (VAR >= 2 && VAR != 4 && pre) issue_tile(prev_stage(stage));
@@ -1097,7 +1264,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             fold(nkt - 1);
         }
     }
-    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(0);
+    if (VAR >= 3 && VAR != 5 && late) __builtin_amdgcn_s_setprio(0);
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
@@ -1367,11 +1534,12 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
     // bit 3 = channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
     const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
-    if (variant == 17 && !cbm_ok) variant = 7;
+    if ((variant == 17 || variant == 18) && !cbm_ok) variant = 7;
     if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
     switch (variant) {
         case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
         case 17: return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);      // = 15, reads before the issue block
+        case 18: return f ? launch_h2<0, 0, 6, 3, true, true>(a, st) : launch_h2<1, 0, 6, 3, true, true>(a, st);      // ping-pong + LDS-DMA pieces spread through the matrix segment
         case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
         case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
         case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
@@ -1494,6 +1662,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
         case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
         case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
         case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
+        case 9: rc = launch_hw<5, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, LDS-DMA pieces spread through the matrix segment
         default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
     }
     if (rc != SP_OK) return rc;

@@ -297,25 +297,44 @@ __global__ __launch_bounds__(256) void rank1_dwc_reduce_kernel(const float* __re
     }
 }
 
+// planes != NULL: also writes dpre as the 2xfp16 split operand of the two h-gate GEMMs that consume it (data and weight gradient),
+// with the operand scale from an upper bound of max|dpre| (bn_pool.hip explains why a bound is enough): gates lie in (0,1), |g| < 1,
+// |c_t| <= t + 1, so with D = max|dc| + max|dh| (>= |dc + dh*o|):  |d_g|, |d_i| <= D,  |d_o| <= max|dh| * c_bound / 4,
+// |d_f| <= D * cprev_bound / 4.  The separate split pass re-read the 671 MB tensor every step.
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const float* dc, const float* gates,
                                                        const float* c_prev, const float* c_out, int64_t rows, int C,
-                                                       float* dpre, float* dc_prev, unsigned* dpre_amax) {
+                                                       float* dpre, float* dc_prev, unsigned* dpre_amax, unsigned* dcp_amax,
+                                                       const unsigned* dh_amax, const unsigned* dc_amax, float c_bound,
+                                                       float cprev_bound, uint16_t* planes, float* dpre_scale) {
     __shared__ float sh4[4];
-    float dmx = 0.f;
+    float dmx = 0.f, cmx = 0.f;
     const int C4 = C / 4;
     const int64_t total = rows * C4;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / C4;
-        const int c = (int)(idx - r * C4) * 4;
-        const float* pgt = gates + r * 4 * C + c;
-        const float4 gi = *reinterpret_cast<const float4*>(pgt), gf = *reinterpret_cast<const float4*>(pgt + C);
-        const float4 go = *reinterpret_cast<const float4*>(pgt + 2 * C), gg = *reinterpret_cast<const float4*>(pgt + 3 * C);
-        const float4 cn = *reinterpret_cast<const float4*>(c_out + r * C + c);
-        float4 cp = make_float4(0.f, 0.f, 0.f, 0.f), vdh = cp, vdc = cp;
-        if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + r * C + c);
-        if (dh) vdh = *reinterpret_cast<const float4*>(dh + r * C + c);
-        if (dc) vdc = *reinterpret_cast<const float4*>(dc + r * C + c);
-        float4 di, df, dov, dg, dcp;
+    float s = 1.f, bound = 0.f;
+    if (planes) {
+        const float a_dh = dh_amax ? __uint_as_float(*dh_amax) : 0.f, a_dc = dc_amax ? __uint_as_float(*dc_amax) : 0.f;
+        const float D = a_dh + a_dc;
+        bound = fmaxf(D, 0.25f * fmaxf(a_dh * c_bound, D * cprev_bound)) * 1.0001f;
+        s = scale_of(__float_as_uint(bound));
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < total; base += stride) {     // wave-uniform
+        const int64_t idx = base + lane;
+        const bool live = idx < total;
+        const int64_t r = live ? idx / C4 : 0;
+        const int c = live ? (int)(idx - r * C4) * 4 : 0;
+        float4 di = make_float4(0.f, 0.f, 0.f, 0.f), df = di, dov = di, dg = di;
+        if (live) {
+            const float* pgt = gates + r * 4 * C + c;
+            const float4 gi = *reinterpret_cast<const float4*>(pgt), gf = *reinterpret_cast<const float4*>(pgt + C);
+            const float4 go = *reinterpret_cast<const float4*>(pgt + 2 * C), gg = *reinterpret_cast<const float4*>(pgt + 3 * C);
+            const float4 cn = *reinterpret_cast<const float4*>(c_out + r * C + c);
+            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f), vdh = cp, vdc = cp;
+            if (c_prev) cp = *reinterpret_cast<const float4*>(c_prev + r * C + c);
+            if (dh) vdh = *reinterpret_cast<const float4*>(dh + r * C + c);
+            if (dc) vdc = *reinterpret_cast<const float4*>(dc + r * C + c);
+            float4 dcp;
 #define CELLB(k)                                              \
         {                                                     \
             const float dct = vdc.k + vdh.k * go.k;           \
@@ -325,18 +344,39 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const fl
             dg.k = dct * gi.k * (1.f - gg.k * gg.k);          \
             dcp.k = dct * gf.k;                               \
         }
-        CELLB(x) CELLB(y) CELLB(z) CELLB(w)
+            CELLB(x) CELLB(y) CELLB(z) CELLB(w)
 #undef CELLB
-        float* pd = dpre + r * 4 * C + c;
-        *reinterpret_cast<float4*>(pd) = di;
-        *reinterpret_cast<float4*>(pd + C) = df;
-        *reinterpret_cast<float4*>(pd + 2 * C) = dov;
-        *reinterpret_cast<float4*>(pd + 3 * C) = dg;
-        *reinterpret_cast<float4*>(dc_prev + r * C + c) = dcp;
-        dmx = amax4(amax4(dmx, di.x, di.y, di.z, di.w), df.x, df.y, df.z, df.w);
-        dmx = amax4(amax4(dmx, dov.x, dov.y, dov.z, dov.w), dg.x, dg.y, dg.z, dg.w);
+            float* pd = dpre + r * 4 * C + c;
+            *reinterpret_cast<float4*>(pd) = di;
+            *reinterpret_cast<float4*>(pd + C) = df;
+            *reinterpret_cast<float4*>(pd + 2 * C) = dov;
+            *reinterpret_cast<float4*>(pd + 3 * C) = dg;
+            *reinterpret_cast<float4*>(dc_prev + r * C + c) = dcp;
+            dmx = amax4(amax4(dmx, di.x, di.y, di.z, di.w), df.x, df.y, df.z, df.w);
+            dmx = amax4(amax4(dmx, dov.x, dov.y, dov.z, dov.w), dg.x, dg.y, dg.z, dg.w);
+            cmx = amax4(cmx, dcp.x, dcp.y, dcp.z, dcp.w);
+        }
+        if (planes) {                  // (wave-uniform; the 64 lanes of a wave own 64 consecutive float4 of ONE row: C % 256 == 0)
+            const float4 v4[4] = {di, df, dov, dg};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ushort4 pa, pb;
+                split2(v4[g].x, s, pa.x, pb.x);
+                split2(v4[g].y, s, pa.y, pb.y);
+                split2(v4[g].z, s, pa.z, pb.z);
+                split2(v4[g].w, s, pa.w, pb.w);
+                store_planes_quad(planes, r * C + g * C4 + (c >> 2), live, pa, pb);
+            }
+        }
     }
     if (dpre_amax) block_amax_commit(dmx, dpre_amax, sh4);
+    if (dcp_amax) block_amax_commit(cmx, dcp_amax, sh4);
+    if (planes && blockIdx.x == 0 && threadIdx.x < 8)
+        reinterpret_cast<uint2*>(planes + 8 * (rows * C))[threadIdx.x] = make_uint2(0u, 0u);       // 64-byte zero block after 2*4C*rows halves
+    if (planes && blockIdx.x == 0 && threadIdx.x == 0) {
+        dpre_scale[0] = s;
+        dpre_scale[1] = bound;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,11 +751,23 @@ extern "C" int sp_sempool_bwd(const float* dout, const float* out, const float* 
 extern "C" int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                                      const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev, unsigned* dpre_amax,
                                      void* stream) {
+    return sp_lstm_pointwise_bwd_split(dh, dc, gates, c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax, nullptr, nullptr, nullptr,
+                                       0.f, 0.f, nullptr, nullptr, stream);
+}
+
+extern "C" int sp_lstm_pointwise_bwd_split(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
+                                           unsigned* dpre_amax, unsigned* dcp_amax, const unsigned* dh_amax,
+                                           const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
+                                           float* dpre_scale, void* stream) {
     if (!gates || !c_out || !dpre || !dc_prev) return SP_ENULL;
     if (C % 4) return SP_EINVAL;
+    if (planes && (!dpre_scale || C % 256 || ((uintptr_t)planes & 15) || (dh && !dh_amax) || (dc && !dc_amax))) return SP_EINVAL;
     SP_RESET_AMAX(dpre_amax, stream);
+    SP_RESET_AMAX(dcp_amax, stream);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
-                       c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax);
+                       c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax, dcp_amax, dh_amax, dc_amax, c_bound, cprev_bound,
+                       (uint16_t*)planes, dpre_scale);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

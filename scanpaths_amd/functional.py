@@ -329,7 +329,10 @@ class _FanOut(Function):
                 acc = _add_raw(acc, g)
             return acc, None
         arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
-        check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), hip.stream()), "sp_sum_n")
+        hint = _amax_hint(out.device)          # max|sum|: the LSTM cell's backward bounds its split operand with it
+        check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n")
+        if hint is not None:
+            out._sp_amax = hint
         return out, None
 
 
@@ -981,6 +984,8 @@ class _LstmCellRank1(Function):
             h._sp_amax = hint
         h._sp_cache = {}                  # h feeds the saliency tap GEMM of this step and the h-gate conv of the next: split once
         ctx.has = (hg is not None, c_prev is not None)
+        ctx.set_materialize_grads(False)          # the last step's dc stays None instead of a zero tensor the kernel would read
+        ctx.cbounds = _cell_bounds(c_prev, c)
         ctx.save_for_backward(gates, c_prev, c, spcol, wc)
         return h, c
 
@@ -988,13 +993,29 @@ class _LstmCellRank1(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[3],
-                                                   ctx.needs_input_grad[4])
+                                                   ctx.needs_input_grad[4], ctx.cbounds)
         has_hg, has_c = ctx.has
         return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
 
 
-def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc):
-    """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint), c_prev, spcol and wc"""
+def _cell_bounds(c_prev, c):
+    """(bound of max|c|, bound of max|c_prev|) from |c_t| <= |c_{t-1}| + 1 (gates in (0,1), |g| < 1); travels on the state tensor"""
+    cbp = 0.0 if c_prev is None else getattr(c_prev, "_sp_cbound", None)
+    cb = None if cbp is None else cbp + 1.0
+    if cb is not None:
+        c._sp_cbound = cb
+    return cb, cbp
+
+
+LSTM_BWD_SPLIT = os.environ.get("SP_LSTM_BWD_SPLIT", "1") != "0"
+FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0}      # how often a pass emitted its consumer's operand (tests)
+
+
+def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None)):
+    """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint or -- when bounds of max|dh|, max|dc| and
+    max|c| are known -- its 2xfp16 split operand, written by the same pass), c_prev, spcol and wc"""
+    dh_h = getattr(dh, "_sp_amax", None) if dh is not None else None
+    dc_h = getattr(dc, "_sp_amax", None) if dc is not None else None
     dh = dh.contiguous() if dh is not None else None
     dc = dc.contiguous() if dc is not None else None
     B, P, KP = spcol.shape
@@ -1004,11 +1025,26 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     rows = gates.numel() // C4
     dpre = torch.empty_like(gates)
     dcp = torch.empty_like(c)
-    hint = _amax_hint(gates.device)
-    check(hip.lib().sp_lstm_pointwise_bwd(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre),
-                                          ptr(dcp), _hint_ptr(hint), hip.stream()), "sp_lstm_pointwise_bwd")
-    if hint is not None:
+    hint, chint = _amax_hint(gates.device), _amax_hint(gates.device)
+    emit = (LSTM_BWD_SPLIT and hint is not None and Cc % 256 == 0 and cbounds[0] is not None and (dh is None or dh_h is not None)
+            and (dc is None or dc_h is not None) and _scheme_for(C4) == "f16x2")
+    if emit:
+        FUSION_COUNTS["lstm_bwd_split"] += 1
+        planes = torch.empty(2 * dpre.numel() + 32, dtype=torch.float16, device=dpre.device)
+        check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre), ptr(dcp),
+                                                    None, _hint_ptr(chint), _hint_ptr(dh_h), _hint_ptr(dc_h), float(cbounds[0]),
+                                                    float(cbounds[1]), ptr(planes), ptr(hint), hip.stream()),
+              "sp_lstm_pointwise_bwd_split")
         dpre._sp_amax = hint
+        dpre._sp_cache = {"f16x2": SplitOperand(planes, hint, "f16x2")}
+    else:
+        check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre), ptr(dcp),
+                                                    _hint_ptr(hint), _hint_ptr(chint), None, None, 0.0, 0.0, None, None,
+                                                    hip.stream()), "sp_lstm_pointwise_bwd_split")
+        if hint is not None:
+            dpre._sp_amax = hint
+    if chint is not None:
+        dcp._sp_amax = chint               # max|dc_prev|: the previous step's cell backward bounds its operand with it
     dsp = dwc = None
     if need_dsp:
         dsp = torch.empty_like(spcol)
@@ -1081,6 +1117,8 @@ class _GateConvLstm(Function):
         if hint is not None:
             h._sp_amax = hint
         h._sp_cache = {}
+        ctx.set_materialize_grads(False)
+        ctx.cbounds = _cell_bounds(c_prev, c)
         keep = ctx.needs_input_grad[1] and _w3_pays(N * P, Co, KH * KW * Ci, Ci, free_splits=True) \
             and xs.scheme == _wgrad_scheme(Ci, Co)
         ctx.xs_scheme = xs.scheme if keep else None
@@ -1092,7 +1130,7 @@ class _GateConvLstm(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc, h_prev, wp, xs_buf, xs_scale = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
-                                                   ctx.needs_input_grad[5])
+                                                   ctx.needs_input_grad[5], ctx.cbounds)
         xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
         dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dhp, dw, dpre, dcp, dsp, dwc, None

@@ -71,7 +71,7 @@ SIGNATURES = {
     "sp_conv_stats_tiles": (_L, [_L]),
     "sp_conv_igemm_f16x2_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_bn_bwd_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "sp_sum_n": (_I, [_P, _I, _L, _P, _P]),
+    "sp_sum_n": (_I, [_P, _I, _L, _P, _P, _P]),
     "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
     "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sp_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -86,6 +86,7 @@ SIGNATURES = {
     "sp_sempool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_sempool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "sp_lstm_pointwise_bwd_split": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
     "sp_im2col3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_col2im3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_listatt_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),

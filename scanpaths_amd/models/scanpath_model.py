@@ -356,8 +356,8 @@ class ScanpathModel(nn.Module):
         Wsal = torch.cat([Gp[:, :2].reshape(nsrc * 50, 512), torch.zeros(R - nsrc * 50, 512, device=dev)], 0).view(R, 512, 1, 1)
         W11, cbsum = F.compose11(G, cbt if per_sample else cb, nsrc, HC, (Hm, Wm))
         w2, b2 = self.object_head.drt_layer_2.weight, self.object_head.drt_layer_2.bias
-        sp_list: List[torch.Tensor] = []
-        se_list: List[torch.Tensor] = []
+        sp_list: List[List[torch.Tensor]] = []      # per memory entry: its remaining aliases (see push)
+        se_list: List[List[torch.Tensor]] = []
 
         def rep(t, n):
             """n aliases of a tensor that every decode step (or memory push) uses once: its T (+1) gradient contributions are
@@ -370,19 +370,22 @@ class ScanpathModel(nn.Module):
         Wrs = [rep(w, T) for w in Wr]
         Wsals, W11s, cbsums, cbs, w2s, b2s = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T), rep(w2, T), rep(b2, T)
 
-        def push(amaps):          # amaps [S,B,P]; memory update :277-296 / :317-336
+        def push(amaps, k):       # amaps [S,B,P]; memory update number k (:277-296 / :317-336)
+            # entry k of the two memory lists is stacked by this update and every later one (T - k of them: the update after the
+            # last step feeds nothing and is not run): T - k aliases -> ONE fan-in pass for its gradient instead of the
+            # T - k - 1 small adds autograd issues for a tensor that sits in T - k stacks (~250 launches per step over both lists)
             spf = F.mul_relu(amaps, mvfs.pop())
-            sp_list.append(F.linear(spf.view(S * B, P), spw.pop(), spb.pop()))
+            sp_list.append(rep(F.linear(spf.view(S * B, P), spw.pop(), spb.pop()), T - k))
             vf3 = vfs.pop().view(B, P, Cc)
             pooled = F.semantic_pool(amaps, vf3) if (S <= 2 and Cc <= 512) else \
                 F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
-            se_list.append(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop()))
-            sp_mem = F.list_attention(torch.stack(sp_list, 0), u_spas.pop())        # [S*B,P]
-            se_mem = F.list_attention(torch.stack(se_list, 0), u_sems.pop())        # [S*B,C]
+            se_list.append(rep(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop()), T - k))
+            sp_mem = F.list_attention(torch.stack([a.pop() for a in sp_list], 0), u_spas.pop())        # [S*B,P]
+            se_mem = F.list_attention(torch.stack([a.pop() for a in se_list], 0), u_sems.pop())        # [S*B,C]
             return sp_mem, se_mem
 
         a0 = attention_maps.reshape(1, B, P).to(torch.float32)
-        sp_mem, se_mem = push(a0.expand(S, B, P).contiguous())
+        sp_mem, se_mem = push(a0.expand(S, B, P).contiguous(), 0)
         h = c = None
         outs = {"logits": [], "amap": [], "mu": [], "s2": []}
         zpad = torch.zeros(B, 3 * 512, KP - 9 * S, device=dev) if KP > 9 * S else None
@@ -409,7 +412,8 @@ class ScanpathModel(nn.Module):
             outs["amap"].append(amap)
             outs["mu"].append(mu)
             outs["s2"].append(s2)
-            sp_mem, se_mem = push(amap)
+            if t + 1 < T:
+                sp_mem, se_mem = push(amap, t + 1)
         return {k: torch.stack(v, 2) for k, v in outs.items()}
 
     # ------------------------------------------------------------------------------------------------
