@@ -120,9 +120,9 @@ int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d);
 int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                         const float* y_scale, float* dW, void* workspace, void* stream);
 /* forward conv whose epilogue also writes the first reduction stage of the BatchNorm behind it (per 256-row tile and output column:
- * sum, sum of squares in fp64; min, max in fp32): st_partial [tiles][2][Nout], st_mm [tiles][2][Nout], tiles = sp_conv_stats_tiles(M).
+ * sum, sum of squares in fp64; min, max in fp32): st_partial [tiles][2][Nout], st_mm [tiles][2][Nout], tiles = sp_conv_stats_tiles(d).
  * No bias / relu / beta.  models/resnet.py:57-93 (conv -> bn). */
-int64_t sp_conv_stats_tiles(int64_t M);
+int64_t sp_conv_stats_tiles(const sp_conv_desc* d);      /* M-tiles of the kernel that will run d: 256 rows, 128 for the short-K pointwise kernel */
 int sp_conv_igemm_f16x2_stats(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit,
                               const float* w_scale, float* out, double* st_partial, float* st_mm, void* stream);
 /* THROUGHPUT MODE (SURVEY.md §7 hard part 1 / BASELINE.md §4 "bf16-MFMA mode", reported separately from the fp32-faithful

@@ -762,6 +762,210 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 }
 
 // ================================================================================================================
+// Short-K pointwise GEMM (1x1 convolutions of the ResNet bottlenecks with K <= 512, forward and stride-1 data gradient):
+//   C[m][n] = sum_k A[row(m)][k] * W[n][k],   row(m) = the input pixel of output pixel m (stride), same split operands and arithmetic
+//   as h2_kernel (16x16x32 MFMAs, 3 products, fold every 256 k).
+// These launches move 0.3-0.8 GB for 20-90 GFLOP: they are HBM-bound, and h2_kernel's 256x128 tile with a 144 KB ring (one
+// workgroup per CU, nothing to overlap its prologue latency and its 128 KB epilogue with) runs them at ~1.2 TB/s.  Here: 128x128 tile,
+// 4 waves (2x2, wave tile 64x64), two 32 KB stages -> 64 KB LDS, TWO workgroups per CU whose load / matrix / store phases overlap.
+// MEASURED (round 2, encoder at bs 32, 320x512): SLOWER than h2_kernel on the same launches (666 vs 540 us on the M = 327 680,
+// N = 512, K = 128 shape; encoder forward + backward 94.4 vs 91.8 ms) -- occupancy is not what holds these launches back.  Kept as
+// an opt-in experiment (sp_set_tuning("s2", 1)); the default path does not use it.
+struct S2Args {
+    const uint16_t* A;    // [rows][K/16][2][16]
+    const uint16_t* W;    // [Nout][K/16][2][16]
+    const float* bias;
+    float* C;
+    const float* sx;
+    const float* sw;
+    int64_t M;
+    int K, Nout, ldc;
+    int Ho, Wo, Hi, Wi, stride;
+    int nkt, tiles_n;
+    float alpha;
+    int beta, relu;
+    uint32_t a_bytes, w_bytes;
+    double* st_partial;   // [M / 128 tiles][2][Nout] (see H2Args)
+    float* st_mm;
+};
+constexpr int S2_BM = 128, S2_BN = 128;
+constexpr int S2_A_BYTES = S2_BM * 128, S2_STAGE = (S2_BM + S2_BN) * 128;      // 16384, 32768
+
+__global__ __launch_bounds__(256, 2) void s2_kernel(S2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;        // N-tiles of one M-tile are neighbours: its A panel is read once
+    const int64_t m0 = (int64_t)tmi * S2_BM;
+    const int n0 = tn * S2_BN;
+    const uint32_t rowbytes = (uint32_t)p.K * 4u;
+
+    // loader: LDS chunk g = t + 256 j -> row g/8, position g%8; source chunk = position ^ ((row>>1)&7)  (h2_kernel's layout)
+    uint32_t a_voff[4], b_voff[4];
+    bool a_ok[4], b_ok[4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = t + 256 * j;
+        const int row = idx >> 3, pos = idx & 7;
+        const uint32_t c8 = (uint32_t)((pos ^ ((row >> 1) & 7)) * 16);
+        const int64_t m = m0 + row;
+        a_ok[j] = m < p.M;
+        int64_t src = a_ok[j] ? m : 0;
+        if (p.stride != 1) {
+            const int b = (int)(src / HoWo);
+            const int rem = (int)(src - (int64_t)b * HoWo);
+            const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+            src = ((int64_t)b * p.Hi + yo * p.stride) * p.Wi + xo * p.stride;
+        }
+        a_voff[j] = (uint32_t)src * rowbytes + c8;
+        b_ok[j] = n0 + row < p.Nout;
+        b_voff[j] = b_ok[j] ? (uint32_t)(n0 + row) * rowbytes + c8 : 0u;
+    }
+    int ld_kt = 0;
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * S2_STAGE;
+        const uint32_t koff = (uint32_t)ld_kt * 128u;
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.A) + koff;
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koff;
+        const uint32_t zrelA = p.a_bytes - koff, zrelB = p.w_bytes - koff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 4 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + S2_A_BYTES + (wave + 4 * j) * 1024);
+        ++ld_kt;
+    };
+
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = S2_A_BYTES + (wn * 64 + l16) * 128 + pos * 16;
+    }
+    f32x4 tot4[4][4], acc4[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                tot4[i][j][r] = 0.f;
+                acc4[i][j][r] = 0.f;
+            }
+
+    issue_tile(0);
+    if (p.nkt > 1) issue_tile(1);
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        if (kt + 1 < p.nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile kt landed, tile kt+1 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* st = smem + (kt & 1) * S2_STAGE;
+        f16x8 af[4][2], bf[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + i * 16 * 128);
+                bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + i * 16 * 128);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4& a4 = acc4[i][j];
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], a4, 0, 0, 0);
+            }
+        if ((kt & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tot4[i][j] += acc4[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
+                }
+        }
+        if (kt + 2 < p.nkt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // every wave has read stage kt & 1: refill it with tile kt + 2
+            issue_tile(kt & 1);
+        }
+    }
+
+    const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
+    const bool stats = p.st_partial != nullptr;
+    if (stats) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // the stages are about to be reused for the statistics
+    }
+    double* sh_s = reinterpret_cast<double*>(smem);                  // [2 wm][128 col][2]
+    float* sh_m = reinterpret_cast<float*>(smem + 2 * S2_BN * 2 * sizeof(double));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + l16;
+        const bool n_ok = n < p.Nout;
+        const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
+        double cs = 0.0, cq = 0.0;
+        float cmn = INFINITY, cmx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                if (n_ok && m < p.M) {
+                    float* dst = p.C + m * p.ldc + n;
+                    float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
+                    if (p.beta) v += *dst;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    *dst = v;
+                    if (stats) {
+                        cs += (double)v;
+                        cq += (double)v * (double)v;
+                        cmn = fminf(cmn, v);
+                        cmx = fmaxf(cmx, v);
+                    }
+                }
+            }
+        if (stats) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                cs += __shfl_xor(cs, off);
+                cq += __shfl_xor(cq, off);
+                cmn = fminf(cmn, __shfl_xor(cmn, off));
+                cmx = fmaxf(cmx, __shfl_xor(cmx, off));
+            }
+            if (g4 == 0) {
+                const int col = wn * 64 + j * 16 + l16;
+                sh_s[(wm * S2_BN + col) * 2 + 0] = cs;
+                sh_s[(wm * S2_BN + col) * 2 + 1] = cq;
+                sh_m[(wm * S2_BN + col) * 2 + 0] = cmn;
+                sh_m[(wm * S2_BN + col) * 2 + 1] = cmx;
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (t < S2_BN && n0 + t < p.Nout) {
+            const double a = sh_s[t * 2 + 0] + sh_s[(S2_BN + t) * 2 + 0], b = sh_s[t * 2 + 1] + sh_s[(S2_BN + t) * 2 + 1];
+            const float mn = fminf(sh_m[t * 2 + 0], sh_m[(S2_BN + t) * 2 + 0]), mx = fmaxf(sh_m[t * 2 + 1], sh_m[(S2_BN + t) * 2 + 1]);
+            const int64_t g = tmi;
+            p.st_partial[(g * 2 + 0) * p.Nout + n0 + t] = a;
+            p.st_partial[(g * 2 + 1) * p.Nout + n0 + t] = b;
+            p.st_mm[(g * 2 + 0) * p.Nout + n0 + t] = mn;
+            p.st_mm[(g * 2 + 1) * p.Nout + n0 + t] = mx;
+        }
+    }
+}
+
+// ================================================================================================================
 // Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pix(m,tap)][ci]   (K = pixels), the structure of w3_kernel:
 // K-tiles of 32 pixels staged as [pixel][channel chunks] rows by LDS-DMA, K-major fragments by ds_read_b64_tr_b16.
 // Pixel rows are 1024 B (A: 256 co) / 512 B (B: 128 ci), both = 0 mod 256, so the four pixel rows of a transposed-read block
@@ -963,55 +1167,6 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         }
         ++ld_kt;
     };
-    // VAR 5: the same six pieces prepared up front (addresses, coordinate advance) and issued one at a time between MFMAs
-    uint32_t pc_off[6];
-    const unsigned char* pc_baseA = nullptr;
-    int pc_stage = 0;
-    auto prepare_tile = [&](int stage) {
-        const int64_t mt = m_begin + (int64_t)ld_kt * 32;
-        pc_baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (4 * (int64_t)p.Co);
-        const uint32_t zrelA = (uint32_t)((int64_t)p.y_bytes - mt * (4 * (int64_t)p.Co));
-        const int rows_left = (int)min((int64_t)32, m_end - mt);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pc_off[j] = (a_cok[j] && a_r[j] < rows_left) ? a_voff[j] : zrelA;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool ok = b_live[j] && b_r[j] < rows_left && (unsigned)b_iy[j] < (unsigned)p.Hi && (unsigned)b_ix[j] < (unsigned)p.Wi;
-            pc_off[4 + j] = ok ? b_off[j] : p.x_bytes;
-            b_x[j] += x_adv;
-            b_y[j] += y_adv;
-            b_ix[j] += adv_ix;
-            b_iy[j] += adv_iy;
-            b_off[j] += adv_off;
-            if (b_x[j] >= p.Wo) {
-                b_x[j] -= p.Wo;
-                ++b_y[j];
-                b_ix[j] -= wrapx_ix;
-                b_iy[j] += p.stride;
-                b_off[j] += wrapx_off;
-            }
-            if (b_y[j] >= p.Ho) {
-                b_y[j] -= p.Ho;
-                b_iy[j] -= wrapy_iy;
-                b_off[j] += wrapy_off;
-            }
-            if (tiny_map)
-                while (b_y[j] >= p.Ho) {
-                    b_y[j] -= p.Ho;
-                    b_iy[j] -= wrapy_iy;
-                    b_off[j] += wrapy_off;
-                }
-        }
-        pc_stage = stage;
-        ++ld_kt;
-    };
-    auto issue_piece = [&](int q) {
-        unsigned char* st = smem + pc_stage * HWSTAGE;
-        __builtin_amdgcn_sched_barrier(0);
-        if (q < 4) SP_GLDS16(pc_baseA + pc_off[q], st + (wave + 8 * q) * 1024);
-        else SP_GLDS16(reinterpret_cast<const unsigned char*>(p.X) + pc_off[q], st + HWA_BYTES + (wave + 8 * (q - 4)) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-    };
 
     // transposed-read offsets.  32x32x16: k-group kk adds 16 pixel rows; lane (g4 = (lane>>4)&1, q = (lane>>2)&3, pp = lane&3)
     // addresses pixel row 8h + 4s + q, channels cbase + 16*g4 + 4pp .. +3 of plane pl.  16x16x32: the 16-lane group kg = lane>>4
@@ -1173,57 +1328,10 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
-    auto mma_spread = [&](bool pre_) {
-        if constexpr (M16 && do_mma && NPROD == 3) {
-#pragma unroll
-            for (int pr = 0; pr < 16; ++pr) {
-                const int i = pr >> 2, j = pr & 3;
-                f32x4& a4 = acc4[i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                if (((pr + 1) * 6) / 16 != (pr * 6) / 16 && pre_) issue_piece((pr * 6) / 16);
-            }
-        }
-    };
-
     int stage = 0;
     const bool late = VAR != 0 && wave >= 4;
-    if (VAR >= 3 && VAR != 5 && late) __builtin_amdgcn_s_setprio(1);
-    if constexpr (VAR == 5 && M16 && do_mma && do_load && NPROD == 3 && DBG == 0) {
-        if (!late) {
-            for (int kt = 0; kt < nkt; ++kt) {
-                const bool pre = kt + HNSTAGE - 1 < nkt;
-                read_group(stage, 0);
-                read_group(stage, 1);
-                if (pre) prepare_tile(prev_stage(stage));
-                mma_spread(pre);
-                fold(kt);
-                wait_barrier(kt);
-                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
-            }
-        } else {
-            for (int kt = 0; kt < nkt; ++kt) {
-                const bool pre = kt + HNSTAGE - 1 < nkt;
-                if (pre) prepare_tile(prev_stage(stage));
-                if (kt > 0) {
-                    mma_spread(pre);
-                    fold(kt - 1);
-                } else if (pre) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) issue_piece(q);
-                }
-                read_group(stage, 0);
-                read_group(stage, 1);
-                wait_barrier(kt);
-                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
-            }
-            if (nkt > 0) {
-                mma_spread(false);
-                fold(nkt - 1);
-            }
-        }
-    } else if (!late) {
+    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(1);
+    if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
             if (VAR >= 2 && VAR != 4 && pre) issue_tile(prev_stage(stage));
@@ -1264,7 +1372,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             fold(nkt - 1);
         }
     }
-    if (VAR >= 3 && VAR != 5 && late) __builtin_amdgcn_s_setprio(0);
+    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(0);
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
@@ -1446,6 +1554,24 @@ int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
     return SP_OK;
 }
 
+int launch_s2(const S2Args& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S2_STAGE);
+        attr_set = true;
+    }
+    const int64_t grid = sp_cdiv(a.M, S2_BM) * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
+    hipLaunchKernelGGL(s2_kernel, dim3((unsigned)grid), dim3(256), 2 * S2_STAGE, s, a);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+// the short-K pointwise kernel applies: 1x1, no padding, K <= 512, forward (any stride) or stride-1 data gradient
+bool s2_applies(const sp_conv_desc* d) {
+    return sp_tuning_get(SP_TUNE_S2, 0) == 1 && d->KH * d->KW == 1 && d->pad == 0 && d->Kc <= 512 && (d->mode == 0 || d->stride == 1);
+}
+
 int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
     SP_RESET_AMAX_ALWAYS(amax, s);   // scratch word of the caller's scale buffer (not a pooled slot); a kernel node, not a memset node: see common.h
     const int64_t n4 = n / 4;
@@ -1515,6 +1641,18 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     static const int dbg = getenv("SP_H2_DBG") ? atoi(getenv("SP_H2_DBG")) : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool f = d->mode == 0;
+    if (nprod == 3 && dbg == 0 && s2_applies(d)) {
+        if (st_partial && (!f || !st_mm || d->beta || d->relu || bias)) return SP_EINVAL;
+        S2Args q{};
+        q.A = a.X; q.W = a.W; q.bias = bias; q.C = out; q.sx = x_scale; q.sw = w_scale;
+        q.M = a.M; q.K = d->Kc; q.Nout = d->Nout; q.ldc = d->ldc;
+        q.Ho = d->Ho; q.Wo = d->Wo; q.Hi = d->Hi; q.Wi = d->Wi; q.stride = f ? d->stride : 1;
+        q.nkt = d->Kc / 32; q.tiles_n = (int)sp_cdiv(d->Nout, S2_BN);
+        q.alpha = d->alpha; q.beta = d->beta; q.relu = d->relu;
+        q.a_bytes = a.x_bytes; q.w_bytes = a.w_bytes;
+        q.st_partial = st_partial; q.st_mm = st_mm;
+        return launch_s2(q, st);
+    }
     if (st_partial) {        // fused BatchNorm statistics: forward, fp32-faithful, the 16x16x32 build only
         if (!f || !st_mm || nprod != 3 || d->beta || d->relu || bias) return SP_EINVAL;
         a.st_partial = st_partial; a.st_mm = st_mm;
@@ -1563,7 +1701,10 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
 
 // forward conv + the first reduction stage of the BatchNorm behind it: st_partial [tiles][2][Nout] doubles (sum, sum of squares),
 // st_mm [tiles][2][Nout] floats (min, max), tiles = sp_conv_stats_tiles(M) -- the layout sp_bn_fwd_split accepts as pre_partial
-extern "C" int64_t sp_conv_stats_tiles(int64_t M) { return sp_cdiv(M, HBM); }
+extern "C" int64_t sp_conv_stats_tiles(const sp_conv_desc* d) {
+    if (!d) return 0;
+    return sp_cdiv((int64_t)d->N_img * d->Ho * d->Wo, s2_applies(d) ? S2_BM : HBM);
+}
 extern "C" int sp_conv_igemm_f16x2_stats(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
                                          const float* w_scale, float* out, double* st_partial, float* st_mm, void* stream) {
     if (!st_partial || !st_mm) return SP_ENULL;
@@ -1662,7 +1803,6 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
         case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
         case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
         case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
-        case 9: rc = launch_hw<5, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, LDS-DMA pieces spread through the matrix segment
         default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
     }
     if (rc != SP_OK) return rc;

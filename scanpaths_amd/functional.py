@@ -454,7 +454,8 @@ class _Conv2d(Function):
             stats = None
             if bn_stats and BN_SPLIT and xs.scheme == "f16x2" and not THROUGHPUT_MODE and bias is None and not relu:
                 # bn_stats: a train-mode BatchNorm follows -- the epilogue writes the first stage of its batch statistics
-                G = hip.lib().sp_conv_stats_tiles(N * Ho * Wo)
+                dd = ConvDesc(N, H, W_, Ci, Ci, Ho, Wo, Co, Co, KH, KW, stride, pad, dil, 0, KH * KW * Ci, 1.0, 0, 0, 1, 0, 0, 0, 0, None)
+                G = hip.lib().sp_conv_stats_tiles(C.byref(dd))         # M-tiles of the kernel that will run this conv
                 stats = (torch.empty((G, 2, Co), dtype=torch.float64, device=x.device),
                          torch.empty((G, 2, Co), dtype=torch.float32, device=x.device), G)
             _igemm_b3(xs, wsplit, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co,

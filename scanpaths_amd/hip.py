@@ -68,7 +68,7 @@ SIGNATURES = {
     "sp_bn_split_workspace": (_L, [_L, _I]),
     "sp_bn_mask_words": (_L, [_L, _I]),
     "sp_bn_fwd_split": (_I, [_P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "sp_conv_stats_tiles": (_L, [_L]),
+    "sp_conv_stats_tiles": (_L, [C.POINTER(ConvDesc)]),
     "sp_conv_igemm_f16x2_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_bn_bwd_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_sum_n": (_I, [_P, _I, _L, _P, _P, _P]),

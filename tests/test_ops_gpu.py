@@ -38,6 +38,8 @@ CONV_CASES = [
     (2, 12, 16, 32, 128, 5, 1, 2, 1, True, False),
     (3, 10, 12, 160, 192, 3, 1, 1, 1, True, False),
     (2, 17, 21, 32, 64, 3, 2, 1, 1, False, False),
+    (2, 17, 23, 128, 192, 1, 1, 0, 1, False, False),       # pointwise convs: ragged M and N tiles
+    (2, 18, 22, 256, 64, 1, 2, 0, 1, True, True),          # ... strided rows, bias, relu
     (2, 14, 18, 128, 288, 3, 1, 1, 1, True, False),      # Ci % 128 == 0: exercises the split-scheme wgrad (tr reads)
     (3, 9, 13, 256, 64, 3, 1, 2, 2, False, False),
     (2, 16, 20, 128, 256, 1, 2, 0, 1, False, False),
@@ -589,24 +591,33 @@ def test_bn_act_emits_the_split_operand_and_the_bit_mask(relu, monkeypatch):
         assert float((_decode_split(opd, dxs.shape) - dxs).abs().max()) <= 2.0 ** -21 * b2
 
 
-def test_conv_epilogue_writes_the_batchnorm_statistics():
-    """conv2d(bn_stats=True) on the 2xfp16 path: per 256-row tile and output column the epilogue leaves sum / sum of squares (fp64)
-    and min / max (fp32) of the conv output -- exactly the first stage of bn_pool.hip's statistics; the BatchNorm behind it gives
-    the same result with and without them (ragged last tile: 2 x 63 x 65 = 8190 pixels)"""
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_epilogue_writes_the_batchnorm_statistics(k, monkeypatch, request):
+    """conv2d(bn_stats=True) on the 2xfp16 path: per M-tile (256 rows; 128 for the short-K pointwise kernel, k = 1) and output
+    column the epilogue leaves sum / sum of squares (fp64) and min / max (fp32) of the conv output -- exactly the first stage of
+    bn_pool.hip's statistics; the BatchNorm behind it gives the same result with and without them (ragged last tile: 2 x 63 x 65 =
+    8190 pixels)"""
     from scanpaths_amd import functional as F
     if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3:
         pytest.skip("2xfp16 back-end not active")
     dev = _dev()
     N, H, W, Ci, Co = 2, 63, 65, 128, 160
+    TM = 256 if k == 3 else 128
     x = _rand(N, H, W, Ci, seed=51).to(dev)
-    w = (_rand(Co, Ci, 3, 3, seed=52, scale=0.05)).to(dev).contiguous(memory_format=torch.channels_last)
-    assert F.conv_takes_split(x.shape, w, pad=1)
-    y = F.conv2d(x, w, None, pad=1, bn_stats=True)
+    w = (_rand(Co, Ci, k, k, seed=52, scale=0.05)).to(dev).contiguous(memory_format=torch.channels_last)
+    if k == 1:
+        from scanpaths_amd import hip
+        monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1, **kw: True)        # small for the cost model
+        hip.check(hip.lib().sp_set_tuning(b"s2", 1), "sp_set_tuning")                        # the opt-in short-K pointwise kernel
+        request.addfinalizer(lambda: hip.lib().sp_set_tuning(b"s2", -1))
+    assert F.conv_takes_split(x.shape, w, pad=k // 2)
+    y = F.conv2d(x, w, None, pad=k // 2, bn_stats=True)
     st = getattr(y, "_sp_bnstats", None)
-    assert st is not None and st[2] == (N * H * W + 255) // 256
+    assert st is not None and st[2] == (N * H * W + TM - 1) // TM
     y2 = y.reshape(-1, Co)
+    _close(y.permute(0, 3, 1, 2), TF.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=k // 2), 2e-6, "y")
     for t in (0, 7, st[2] - 1):
-        rows = y2[256 * t:256 * (t + 1)]
+        rows = y2[TM * t:TM * (t + 1)]
         assert torch.equal(st[1][t, 0], rows.min(0).values) and torch.equal(st[1][t, 1], rows.max(0).values)
         _close(st[0][t, 0], rows.double().sum(0), 1e-12, "tile sum")
         _close(st[0][t, 1], (rows.double() ** 2).sum(0), 1e-12, "tile sum of squares")
