@@ -637,31 +637,57 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     tot4[i][2][r] += sv * w2;
                 }
         }
+        // The x-gate tile comes in and the activated gates leave through the LDS ring as float4 per lane: per (row, gate) the 32
+        // channels of the workgroup are 128 contiguous bytes; read / written 4 bytes per lane straight from the MFMA layout they were
+        // 64-byte runs, and this epilogue (1.85 GB per launch) ran 0.47 ms with the matrix pipe idle.  xs [256 rows][4 gates][32 ch].
+        __syncthreads();                                   // sp_s / wc_s are dead
+        float* xs = reinterpret_cast<float*>(smem);
+        {
+            float4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
+                const int64_t m = m0 + row;
+                v[k] = (m < p.M && n0 + c4 * 4 < C) ? *reinterpret_cast<const float4*>(p.l_xg + m * 4 * C + q * C + n0 + c4 * 4)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) reinterpret_cast<float4*>(xs)[t + 512 * k] = v[k];
+        }
+        __syncthreads();
         float hmx = 0.f;
         if (ch < C) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                    const int row = wm * 64 + i * 16 + 4 * g4 + r;
+                    const int64_t m = m0 + row;
                     if (m >= p.M) continue;
-                    const float* px = p.l_xg + m * 4 * C + ch;
+                    float* px = xs + row * 128 + cl;
                     const float gi = h2_sigmoid(tot4[i][0][r] + px[0]);
-                    const float gf = h2_sigmoid(tot4[i][1][r] + px[C]);
-                    const float go = h2_sigmoid(tot4[i][2][r] + px[2 * C]);
-                    const float gg = tanhf(tot4[i][3][r] + px[3 * C]);
+                    const float gf = h2_sigmoid(tot4[i][1][r] + px[32]);
+                    const float go = h2_sigmoid(tot4[i][2][r] + px[64]);
+                    const float gg = tanhf(tot4[i][3][r] + px[96]);
                     const float cp = p.l_cprev ? p.l_cprev[m * C + ch] : 0.f;
                     const float cn = gf * cp + gi * gg;
                     const float hn = go * cn;
-                    float* pg = p.l_gates + m * 4 * C + ch;
-                    pg[0] = gi;
-                    pg[C] = gf;
-                    pg[2 * C] = go;
-                    pg[3 * C] = gg;
+                    px[0] = gi;
+                    px[32] = gf;
+                    px[64] = go;
+                    px[96] = gg;
                     p.l_c[m * C + ch] = cn;
                     p.l_h[m * C + ch] = hn;
                     hmx = fmaxf(hmx, fabsf(hn));
                 }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
+            const int64_t m = m0 + row;
+            if (m < p.M && n0 + c4 * 4 < C)
+                *reinterpret_cast<float4*>(p.l_gates + m * 4 * C + q * C + n0 + c4 * 4) = reinterpret_cast<const float4*>(xs)[e];
         }
         if (p.l_hamax) {
 #pragma unroll
@@ -671,54 +697,92 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         return;
     }
     if constexpr (M16) {
-        // C/D layout of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg
+        // C/D layout of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg.  Stored straight from the registers every instruction
+        // writes 4 bytes per lane in 64-byte runs (16 columns of one row): 671 MB of output took ~0.4 ms, and the short-K pointwise
+        // convs of the encoder -- whose run time IS their epilogue -- ran at 1.2 TB/s.  The wave's 64 x 64 tile is therefore staged
+        // through its private slice of the idle LDS ring (row pitch 68 floats: the four row groups of a write land on banks
+        // 0/16/32/48 + column, a 16-lane phase of the float4 read-back covers one whole row: no conflicts either way) and leaves as
+        // float4 per lane, 256 contiguous bytes per row, a quarter of the store instructions; beta re-reads the same way.
         const bool stats = MODE == 0 && p.st_partial != nullptr;        // scalar
-        double* sh_s = reinterpret_cast<double*>(smem);                  // [4 wm][128 col][2]  (the ring is idle: see the LSTM epilogue)
-        float* sh_m = reinterpret_cast<float*>(smem + 4 * HBN * 2 * sizeof(double));
+        const bool wide = (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+        float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 68);
+        double cs[4], cq[4];
+        float cmn[4], cmx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l16;
             const bool n_ok = n < p.Nout;
             const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
-            double cs = 0.0, cq = 0.0;
-            float cmn = INFINITY, cmx = -INFINITY;
+            cs[j] = 0.0;
+            cq[j] = 0.0;
+            cmn[j] = INFINITY;
+            cmx[j] = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
-                    if (n_ok && m < p.M) {
+                    const int row = i * 16 + 4 * g4 + r;
+                    const int64_t m = m0 + wm * 64 + row;
+                    float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
+                    if (wide) {
+                        stg[row * 68 + j * 16 + l16] = v;
+                    } else if (n_ok && m < p.M) {
                         float* dst = p.C + m * p.ldc + n;
-                        float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
                         if (p.beta) v += *dst;
                         if (p.relu) v = fmaxf(v, 0.f);
                         *dst = v;
-                        if (stats) {
-                            cs += (double)v;
-                            cq += (double)v * (double)v;
-                            cmn = fminf(cmn, v);
-                            cmx = fmaxf(cmx, v);
-                        }
+                    }
+                    if (stats && n_ok && m < p.M) {          // (statistics are only taken without beta / relu / bias: v is final)
+                        cs[j] += (double)v;
+                        cq[j] += (double)v * (double)v;
+                        cmn[j] = fminf(cmn[j], v);
+                        cmx[j] = fmaxf(cmx[j], v);
                     }
                 }
-            if (stats) {                       // the four 16-lane groups hold rows 4*g4 + r of the same column
+        }
+        if (wide) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private staging: no barrier
+            const int cq4 = lane & 15, rsub = lane >> 4;
+            const int n = n0 + wn * 64 + 4 * cq4;
 #pragma unroll
-                for (int off = 16; off <= 32; off <<= 1) {
-                    cs += __shfl_xor(cs, off);
-                    cq += __shfl_xor(cq, off);
-                    cmn = fminf(cmn, __shfl_xor(cmn, off));
-                    cmx = fmaxf(cmx, __shfl_xor(cmx, off));
-                }
-                if (g4 == 0) {
-                    const int col = wn * 64 + j * 16 + l16;
-                    sh_s[(wm * HBN + col) * 2 + 0] = cs;
-                    sh_s[(wm * HBN + col) * 2 + 1] = cq;
-                    sh_m[(wm * HBN + col) * 2 + 0] = cmn;
-                    sh_m[(wm * HBN + col) * 2 + 1] = cmx;
+            for (int ps = 0; ps < 16; ++ps) {
+                const int row = ps * 4 + rsub;
+                const int64_t m = m0 + wm * 64 + row;
+                if (m < p.M && n < p.Nout) {
+                    float4 v = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
+                    float4* dst = reinterpret_cast<float4*>(p.C + m * p.ldc + n);
+                    if (p.beta) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *dst = v;
                 }
             }
         }
         if (stats) {
+            __syncthreads();                                         // every wave is done with its staging slice
+            double* sh_s = reinterpret_cast<double*>(smem);          // [4 wm][128 col][2]
+            float* sh_m = reinterpret_cast<float*>(smem + 4 * HBN * 2 * sizeof(double));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                            // the four 16-lane groups hold rows 4*g4 + r of the same column
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    cs[j] += __shfl_xor(cs[j], off);
+                    cq[j] += __shfl_xor(cq[j], off);
+                    cmn[j] = fminf(cmn[j], __shfl_xor(cmn[j], off));
+                    cmx[j] = fmaxf(cmx[j], __shfl_xor(cmx[j], off));
+                }
+                if (g4 == 0) {
+                    const int col = wn * 64 + j * 16 + l16;
+                    sh_s[(wm * HBN + col) * 2 + 0] = cs[j];
+                    sh_s[(wm * HBN + col) * 2 + 1] = cq[j];
+                    sh_m[(wm * HBN + col) * 2 + 0] = cmn[j];
+                    sh_m[(wm * HBN + col) * 2 + 1] = cmx[j];
+                }
+            }
             __syncthreads();
             if (t < HBN && n0 + t < p.Nout) {
                 double a = 0.0, b = 0.0;
@@ -1379,6 +1443,38 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     const float isx = 1.f / p.sx[0], isy = 1.f / p.sy[0];
     if constexpr (M16) {
         const int l16 = lane & 15;
+        // float4 stores through a wave-private LDS staging tile (see h2_kernel's epilogue): 256-byte runs instead of 64-byte ones
+        const bool wide = (p.ldo & 3) == 0 && (p.Ntot & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        if (wide) {
+            float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 68);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = tot4[i][j][r] + acc4[i][j][r];
+                        stg[(i * 16 + 4 * kg + r) * 68 + j * 16 + l16] = direct ? p.alpha * ((v * isx) * isy) : v;
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int cq4 = lane & 15, rsub = lane >> 4;
+            const int n = n0 + wn * 64 + 4 * cq4;
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                const int row = ps * 4 + rsub;
+                const int co = co0 + wm * 64 + row;
+                if (co < p.Co && n < p.Ntot) {
+                    float4 v = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
+                    float4* dst = reinterpret_cast<float4*>(out + (int64_t)co * p.ldo + n);
+                    if (direct && p.beta) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *dst = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l16;

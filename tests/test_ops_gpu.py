@@ -603,7 +603,7 @@ def test_conv_epilogue_writes_the_batchnorm_statistics(k, monkeypatch, request):
     dev = _dev()
     N, H, W, Ci, Co = 2, 63, 65, 128, 160
     TM = 256 if k == 3 else 128
-    x = _rand(N, H, W, Ci, seed=51).to(dev)
+    x = _rand(N, H, W, Ci, seed=51).to(dev).requires_grad_(True)
     w = (_rand(Co, Ci, k, k, seed=52, scale=0.05)).to(dev).contiguous(memory_format=torch.channels_last)
     if k == 1:
         from scanpaths_amd import hip
@@ -614,8 +614,15 @@ def test_conv_epilogue_writes_the_batchnorm_statistics(k, monkeypatch, request):
     y = F.conv2d(x, w, None, pad=k // 2, bn_stats=True)
     st = getattr(y, "_sp_bnstats", None)
     assert st is not None and st[2] == (N * H * W + TM - 1) // TM
-    y2 = y.reshape(-1, Co)
-    _close(y.permute(0, 3, 1, 2), TF.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=k // 2), 2e-6, "y")
+    y2 = y.detach().reshape(-1, Co)
+    xr = x.detach().permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    yr = TF.conv2d(xr, w.double().cpu(), padding=k // 2)
+    _close(y.permute(0, 3, 1, 2), yr, 2e-6, "y")
+    gy = _rand(*y.shape, seed=55).to(dev)
+    (dx,) = torch.autograd.grad(y, x, gy)                      # k = 1: the pointwise kernel's data-gradient form
+    yr.backward(gy.permute(0, 3, 1, 2).double().cpu())
+    _close(dx.permute(0, 3, 1, 2), xr.grad, 2e-6, "dx")
+    y = y.detach()
     for t in (0, 7, st[2] - 1):
         rows = y2[TM * t:TM * (t + 1)]
         assert torch.equal(st[1][t, 0], rows.min(0).values) and torch.equal(st[1][t, 1], rows.max(0).values)
