@@ -140,7 +140,10 @@ int sp_conv_wgrad_f16x1(const sp_wgrad_desc* d, const void* Xsplit, const float*
  * xg / gates [B*P][4C], c_prev / c_out / h_out [B*P][C], spcol [B*P][KP], wc [B][3C][KP]; h_amax may be NULL. */
 int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hsplit, const float* h_scale, const void* Wsplit, const float* w_scale,
                            const float* xg, const float* c_prev, const float* spcol, const float* wc, int P, int KP, float* gates,
-                           float* c_out, float* h_out, unsigned* h_amax, void* stream);
+                           float* c_out, float* h_out, unsigned* h_amax,
+                           void* hout_planes /* nullable: h_out also as a split operand (2*B*P*C fp16 + 64 zero bytes), scale from */,
+                           float* hout_scale /* [2] {scale, bound} */, float hout_bound /* >= max|h_out|: t + 1 after t + 1 steps */,
+                           void* stream);
 
 
 /* column sums of a row-major [M][C] matrix (ld = row stride): out[c] = beta*out[c] + sum_m x[m][c]
@@ -198,6 +201,12 @@ int sp_bn_bwd_split(const float* dy, const float* x, const unsigned long long* m
 int sp_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int Ho, int Wo, void* stream);
 int sp_maxpool3s2_bwd(const float* dy, const float* x, const float* y, int N, int H, int W, int C, float* dx, int Ho,
                       int Wo, void* stream);
+/* the same with the window position (ky*3 + kx) of the first maximum saved by the forward pass (one byte per output element):
+ * the backward pass reads neither x nor y and makes no value comparisons */
+int sp_maxpool3s2_fwd_idx(const float* x, int N, int H, int W, int C, float* y, unsigned char* argmax /* nullable */, int Ho, int Wo,
+                          void* stream);
+int sp_maxpool3s2_bwd_idx(const float* dy, const unsigned char* argmax, int N, int H, int W, int C, float* dx, int Ho, int Wo,
+                          void* stream);
 /* NCHW [N,C,H,W] -> NHWC [N,H,W,Cp] (Cp >= C, extra channels zero) and generic last-dim pad/crop copy */
 int sp_nchw_to_nhwc_pad(const float* x, int N, int C, int H, int W, int Cp, float* y, void* stream);
 int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, void* stream);

@@ -385,17 +385,30 @@ __global__ __launch_bounds__(256) void bn_apply_split_kernel(const float* __rest
     const float s = scale_of(__float_as_uint(total));
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // when the grid stride is a multiple of the row length (in float4) a thread meets the same four channels in every iteration:
+    // their parameters are loaded once (four 16-byte parameter loads per 16 bytes of data kept the L1 path, not HBM, busy)
+    const bool hoist = stride % (C / 4) == 0;
+    float4 mu, is, ga, be;
+    if (hoist) {
+        const int c = (int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4) % C);
+        mu = *reinterpret_cast<const float4*>(mean + c);
+        is = *reinterpret_cast<const float4*>(invstd + c);
+        ga = *reinterpret_cast<const float4*>(gamma + c);
+        be = *reinterpret_cast<const float4*>(beta + c);
+    }
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n4; base += stride) {
         const int64_t i = base + lane;
         const bool live = i < n4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
-            const int c = (int)((i * 4) % C);
             const float4 a = reinterpret_cast<const float4*>(x)[i];
-            const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-            const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 be = *reinterpret_cast<const float4*>(beta + c);
+            if (!hoist) {
+                const int c = (int)((i * 4) % C);
+                mu = *reinterpret_cast<const float4*>(mean + c);
+                is = *reinterpret_cast<const float4*>(invstd + c);
+                ga = *reinterpret_cast<const float4*>(gamma + c);
+                be = *reinterpret_cast<const float4*>(beta + c);
+            }
             o.x = bn_affine(a.x, mu.x, is.x, ga.x, be.x);
             o.y = bn_affine(a.y, mu.y, is.y, ga.y, be.y);
             o.z = bn_affine(a.z, mu.z, is.z, ga.z, be.z);
@@ -539,21 +552,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const float* __
     const float s = scale_of(*bound);
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool hoist = stride % (C / 4) == 0;            // see bn_apply_split_kernel
+    float4 is, ga, mu, k1, k2;
+    if (hoist) {
+        const int c = (int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4) % C);
+        is = *reinterpret_cast<const float4*>(invstd + c);
+        ga = *reinterpret_cast<const float4*>(gamma + c);
+        mu = *reinterpret_cast<const float4*>(mean + c);
+        k1 = *reinterpret_cast<const float4*>(coef + c);
+        k2 = *reinterpret_cast<const float4*>(coef + C + c);
+    }
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n4; base += stride) {      // wave-uniform
         const int64_t i = base + lane;
         const bool live = i < n4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
-            const int c = (int)((i * 4) % C);
             float4 d = reinterpret_cast<const float4*>(dy)[i];
             if (mask) d = mask_select(mask, i, d);
             if (dres) reinterpret_cast<float4*>(dres)[i] = d;
-            const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
             const float4 a = reinterpret_cast<const float4*>(x)[i];
-            const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-            const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
-            const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
+            if (!hoist) {
+                const int c = (int)((i * 4) % C);
+                is = *reinterpret_cast<const float4*>(invstd + c);
+                ga = *reinterpret_cast<const float4*>(gamma + c);
+                mu = *reinterpret_cast<const float4*>(mean + c);
+                k1 = *reinterpret_cast<const float4*>(coef + c);
+                k2 = *reinterpret_cast<const float4*>(coef + C + c);
+            }
             o.x = ga.x * is.x * (d.x - k1.x - (a.x - mu.x) * is.x * k2.x);
             o.y = ga.y * is.y * (d.y - k1.y - (a.y - mu.y) * is.y * k2.y);
             o.z = ga.z * is.z * (d.z - k1.z - (a.z - mu.z) * is.z * k2.z);
@@ -618,7 +643,7 @@ __global__ __launch_bounds__(256) void rowsum_bwd_kernel(const float* dout, int6
 // ---------------------------------------------------------------- maxpool 3x3 s2 ceil, NHWC
 // argmax rule = first maximum in row-major window order (strict >), as ATen's CPU max_pool2d.
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int N, int H, int W, int C, float* y, int Ho,
-                                                          int Wo) {
+                                                          int Wo, unsigned char* amx) {
     const int C4 = C / 4;
     const int64_t total = (int64_t)N * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -628,6 +653,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int N,
         const int yo = (int)(r % Ho);
         const int n = (int)(r / Ho);
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 am = make_uchar4(0, 0, 0, 0);                  // window position (ky*3 + kx) of the FIRST maximum per channel
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = yo * 2 + ky;
             if (iy >= H) break;
@@ -635,11 +661,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int N,
                 const int ix = xo * 2 + kx;
                 if (ix >= W) break;
                 const float4 a = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + iy) * W + ix) * C + c4 * 4);
-                m.x = a.x > m.x ? a.x : m.x; m.y = a.y > m.y ? a.y : m.y;
-                m.z = a.z > m.z ? a.z : m.z; m.w = a.w > m.w ? a.w : m.w;
+                const unsigned char q = (unsigned char)(ky * 3 + kx);
+                if (a.x > m.x) { m.x = a.x; am.x = q; }
+                if (a.y > m.y) { m.y = a.y; am.y = q; }
+                if (a.z > m.z) { m.z = a.z; am.z = q; }
+                if (a.w > m.w) { m.w = a.w; am.w = q; }
             }
         }
         reinterpret_cast<float4*>(y)[i] = m;
+        if (amx) reinterpret_cast<uchar4*>(amx)[i] = am;
     }
 }
 
@@ -674,6 +704,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const
             }
         }
         dx[i] = g;
+    }
+}
+
+// the same with the forward's saved window positions: no value comparisons, no reads of x / y; float4 over the channels
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const float* dy, const unsigned char* amx, int N, int H, int W,
+                                                              int C, float* dx, int Ho, int Wo) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t r = i / C4;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int n = (int)(r / H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int oy_lo = max(0, (iy - 1) / 2), oy_hi = min(Ho - 1, iy / 2);
+        const int ox_lo = max(0, (ix - 1) / 2), ox_hi = min(Wo - 1, ix / 2);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (iy - 2 * oy > 2) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ix - 2 * ox > 2) continue;
+                const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C4 + c4;
+                const uchar4 a = reinterpret_cast<const uchar4*>(amx)[o];
+                const unsigned char mine = (unsigned char)((iy - 2 * oy) * 3 + (ix - 2 * ox));
+                if (a.x == mine || a.y == mine || a.z == mine || a.w == mine) {
+                    const float4 d = reinterpret_cast<const float4*>(dy)[o];
+                    g.x += a.x == mine ? d.x : 0.f;
+                    g.y += a.y == mine ? d.y : 0.f;
+                    g.z += a.z == mine ? d.z : 0.f;
+                    g.w += a.w == mine ? d.w : 0.f;
+                }
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = g;
     }
 }
 
@@ -914,10 +978,27 @@ extern "C" int sp_rowsum_bwd(const float* dout, int64_t M, int C, float scale, f
 }
 
 extern "C" int sp_maxpool3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int Ho, int Wo, void* stream) {
+    return sp_maxpool3s2_fwd_idx(x, N, H, W, C, y, nullptr, Ho, Wo, stream);
+}
+
+extern "C" int sp_maxpool3s2_fwd_idx(const float* x, int N, int H, int W, int C, float* y, unsigned char* argmax, int Ho, int Wo,
+                                     void* stream) {
     if (!x || !y) return SP_ENULL;
     if (C % 4) return SP_EINVAL;
     const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, y, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, y, Ho, Wo,
+                       argmax);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_maxpool3s2_bwd_idx(const float* dy, const unsigned char* argmax, int N, int H, int W, int C, float* dx, int Ho,
+                                     int Wo, void* stream) {
+    if (!dy || !argmax || !dx) return SP_ENULL;
+    if (C % 4) return SP_EINVAL;
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(ew_blocks(total) * 4), dim3(256), 0, (hipStream_t)stream, dy, argmax, N, H, W,
+                       C, dx, Ho, Wo);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

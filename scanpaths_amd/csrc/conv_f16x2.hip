@@ -60,6 +60,9 @@ struct H2Args {
     float* l_c;             // [M][lC]
     float* l_h;             // [M][lC]
     unsigned* l_hamax;      // max |h| (float bits), reset by the launcher
+    uint16_t* l_hplanes;    // nullable: h as the 2xfp16 split operand of its consumers, scale from l_hbound >= max|h|
+    float* l_hscale;        // [2] {scale, bound}
+    float l_hbound;
     int lC, lP, lKP;
     // BatchNorm batch statistics of the output, fused into the epilogue (forward, 16x16x32 build): per M-tile and output column
     // the sum and the sum of squares (fp64) and min / max (fp32) of the tile's valid rows, in the [G = M-tiles][2][Nout] layout
@@ -656,31 +659,32 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
         __syncthreads();
         float hmx = 0.f;
-        if (ch < C) {
+        float hv[4][4], cv[4][4];                          // the lane's new hidden / cell values (stored below through the ring)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wm * 64 + i * 16 + 4 * g4 + r;
-                    const int64_t m = m0 + row;
-                    if (m >= p.M) continue;
-                    float* px = xs + row * 128 + cl;
-                    const float gi = h2_sigmoid(tot4[i][0][r] + px[0]);
-                    const float gf = h2_sigmoid(tot4[i][1][r] + px[32]);
-                    const float go = h2_sigmoid(tot4[i][2][r] + px[64]);
-                    const float gg = tanhf(tot4[i][3][r] + px[96]);
-                    const float cp = p.l_cprev ? p.l_cprev[m * C + ch] : 0.f;
-                    const float cn = gf * cp + gi * gg;
-                    const float hn = go * cn;
-                    px[0] = gi;
-                    px[32] = gf;
-                    px[64] = go;
-                    px[96] = gg;
-                    p.l_c[m * C + ch] = cn;
-                    p.l_h[m * C + ch] = hn;
-                    hmx = fmaxf(hmx, fabsf(hn));
-                }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + 4 * g4 + r;
+                const int64_t m = m0 + row;
+                hv[i][r] = 0.f;
+                cv[i][r] = 0.f;
+                if (ch >= C || m >= p.M) continue;
+                float* px = xs + row * 128 + cl;
+                const float gi = h2_sigmoid(tot4[i][0][r] + px[0]);
+                const float gf = h2_sigmoid(tot4[i][1][r] + px[32]);
+                const float go = h2_sigmoid(tot4[i][2][r] + px[64]);
+                const float gg = tanhf(tot4[i][3][r] + px[96]);
+                const float cp = p.l_cprev ? p.l_cprev[m * C + ch] : 0.f;
+                const float cn = gf * cp + gi * gg;
+                const float hn = go * cn;
+                px[0] = gi;
+                px[32] = gf;
+                px[64] = go;
+                px[96] = gg;
+                cv[i][r] = cn;
+                hv[i][r] = hn;
+                hmx = fmaxf(hmx, fabsf(hn));
+            }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -688,6 +692,47 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const int64_t m = m0 + row;
             if (m < p.M && n0 + c4 * 4 < C)
                 *reinterpret_cast<float4*>(p.l_gates + m * 4 * C + q * C + n0 + c4 * 4) = reinterpret_cast<const float4*>(xs)[e];
+        }
+        // h and c leave the same way ([256 rows][32 channels] each: 128-byte runs), and h also as the split operand of its consumers
+        // (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <= t + 1, so the operand scale needs no max|h| pass
+        __syncthreads();
+        float* hs = xs;
+        float* cs2 = xs + HBM * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + 4 * g4 + r;
+                hs[row * 32 + cl] = hv[i][r];
+                cs2[row * 32 + cl] = cv[i][r];
+            }
+        __syncthreads();
+        const float hsc = p.l_hplanes ? scale_of(__float_as_uint(p.l_hbound)) : 1.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                       // (wave-uniform: store_planes_quad)
+            const int e = t + 512 * k, row = e >> 3, c4 = e & 7;
+            const int64_t m = m0 + row;
+            const bool live = m < p.M && n0 + c4 * 4 < C;
+            const float4 h4 = reinterpret_cast<const float4*>(hs)[e];
+            if (live) {
+                *reinterpret_cast<float4*>(p.l_h + m * C + n0 + c4 * 4) = h4;
+                *reinterpret_cast<float4*>(p.l_c + m * C + n0 + c4 * 4) = reinterpret_cast<const float4*>(cs2)[e];
+            }
+            if (p.l_hplanes) {
+                ushort4 pa, pb;
+                split2(h4.x, hsc, pa.x, pb.x);
+                split2(h4.y, hsc, pa.y, pb.y);
+                split2(h4.z, hsc, pa.z, pb.z);
+                split2(h4.w, hsc, pa.w, pb.w);
+                store_planes_quad(p.l_hplanes, (m * C + n0) / 4 + c4, live, pa, pb);
+            }
+        }
+        if (p.l_hplanes && blockIdx.x == 0) {
+            if (t < 8) reinterpret_cast<uint2*>(p.l_hplanes + 2 * p.M * C)[t] = make_uint2(0u, 0u);      // 64-byte zero block
+            if (t == 0) {
+                p.l_hscale[0] = hsc;
+                p.l_hscale[1] = p.l_hbound;
+            }
         }
         if (p.l_hamax) {
 #pragma unroll
@@ -1539,6 +1584,31 @@ __global__ void hw_reduce_kernel(const float* slab, float* out, int Co, int Ntot
     }
 }
 
+// float4 form (Ntot, ldo and the slab stride multiples of 4; 16-byte aligned bases): one thread per 4 consecutive columns
+__global__ void hw_reduce4_kernel(const float* slab, float* out, int Co, int Ntot4, int ldo4, int splits, int64_t slab_stride4,
+                                  float alpha, const float* sx, const float* sy, int beta) {
+    const int64_t total = (int64_t)Co * Ntot4;
+    const float isx = 1.f / sx[0], isy = 1.f / sy[0];
+    const float4* S4 = reinterpret_cast<const float4*>(slab);
+    float4* O4 = reinterpret_cast<float4*>(out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Ntot4), n4 = (int)(i - (int64_t)co * Ntot4);
+        const int64_t off = (int64_t)co * ldo4 + n4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splits; ++k) {               // same per-element order as the scalar form
+            const float4 v = S4[(int64_t)k * slab_stride4 + off];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        s.x = alpha * ((s.x * isx) * isy); s.y = alpha * ((s.y * isx) * isy);
+        s.z = alpha * ((s.z * isx) * isy); s.w = alpha * ((s.w * isx) * isy);
+        if (beta) {
+            const float4 o = O4[off];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        O4[off] = s;
+    }
+}
+
 int hw_splits(const sp_wgrad_desc* d) {
     const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
     const int forced = sp_tuning_get(SP_TUNE_HW_SPLITS, 0);      // experiments only
@@ -1819,7 +1889,7 @@ extern "C" int sp_conv_igemm_f16x1(const sp_conv_desc* d, const void* Xs, const 
 extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, const float* h_scale, const void* Ws,
                                       const float* w_scale, const float* xg, const float* c_prev, const float* spcol,
                                       const float* wc, int P, int KP, float* gates, float* c_out, float* h_out, unsigned* h_amax,
-                                      void* stream) {
+                                      void* hout_planes, float* hout_scale, float hout_bound, void* stream) {
     if (!d || !Hs || !Ws || !h_scale || !w_scale || !xg || !spcol || !wc || !gates || !c_out || !h_out) return SP_ENULL;
     if (d->mode != 0 || d->Kc % 32 || d->ldx != d->Kc || d->nbatch != 1 || d->stride != 1 || d->dil < 1) return SP_EINVAL;
     if (d->Nout != 4 * d->Kc || d->Ho != d->Hi || d->Wo != d->Wi || d->KH * d->KW < 2 || d->KH * d->KW > 32) return SP_EINVAL;
@@ -1841,7 +1911,9 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32) || a.M <= 0) return SP_EINVAL;
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
     a.l_xg = xg; a.l_cprev = c_prev; a.l_spcol = spcol; a.l_wc = wc;
+    if (hout_planes && (!hout_scale || !(hout_bound > 0.f) || ((uintptr_t)hout_planes & 15))) return SP_EINVAL;
     a.l_gates = gates; a.l_c = c_out; a.l_h = h_out; a.l_hamax = h_amax;
+    a.l_hplanes = (uint16_t*)hout_planes; a.l_hscale = hout_scale; a.l_hbound = hout_bound;
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);
@@ -1904,9 +1976,15 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     if (rc != SP_OK) return rc;
     if (a.splits > 1) {
         const int64_t total = (int64_t)d->Co * a.Ntot;
-        const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);
-        hipLaunchKernelGGL(hw_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot, d->ldo,
-                           a.splits, a.slab_stride, d->alpha, x_scale, y_scale, d->beta);
+        if (a.Ntot % 4 == 0 && d->ldo % 4 == 0 && a.slab_stride % 4 == 0 && (((uintptr_t)workspace | (uintptr_t)dW) & 15) == 0) {
+            const int blocks = (int)std::min<int64_t>(sp_cdiv(total / 4, 256), 4096);
+            hipLaunchKernelGGL(hw_reduce4_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot / 4,
+                               d->ldo / 4, a.splits, a.slab_stride / 4, d->alpha, x_scale, y_scale, d->beta);
+        } else {
+            const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);
+            hipLaunchKernelGGL(hw_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot, d->ldo,
+                               a.splits, a.slab_stride, d->alpha, x_scale, y_scale, d->beta);
+        }
         SP_LAUNCH_CHECK();
     }
     return SP_OK;

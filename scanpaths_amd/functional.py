@@ -504,13 +504,14 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
     _, Ho, Wo, _ = dy.shape
     dx = dw = None
     dys = None
+    dy_cached = getattr(dy, "_sp_cache", None)       # the producer of dy (a BatchNorm / cell backward) already wrote its split form
     if need_dx:
         beta = 0
         if accum is not None and accum.first is not None and accum.first.shape == x.shape and accum.first.is_contiguous():
             dx, beta, accum.merged = accum.first, 1, True
         else:
             dx = torch.empty_like(x)
-        if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel()):
+        if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel(), free_a=dy_cached is not None):
             dys = split_op(dy)
             wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
             if wT is None:
@@ -525,6 +526,8 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
     if need_dw:
         dwp = torch.empty_like(wp)
         wsch = _wgrad_scheme(Ci, Co)
+        if dys is None and dy_cached is not None and wsch in dy_cached:
+            dys = dy_cached[wsch]
         free = xs is not None and (dys is not None and dys.scheme == wsch)
         if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=free):
             _wgrad_b3(xs if xs is not None else split_op(x, wsch),
@@ -818,19 +821,21 @@ class _MaxPool(Function):
         if (Wo - 1) * 2 >= W_:
             Wo -= 1
         y = torch.empty((N, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
-        check(hip.lib().sp_maxpool3s2_fwd(ptr(x), N, H, W_, Cc, ptr(y), Ho, Wo, hip.stream()), "sp_maxpool3s2_fwd")
-        ctx.save_for_backward(x, y)
+        # the window position of each maximum (1 byte per output) replaces x and y in the backward pass
+        amx = torch.empty((N, Ho, Wo, Cc), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        check(hip.lib().sp_maxpool3s2_fwd_idx(ptr(x), N, H, W_, Cc, ptr(y), ptr(amx), Ho, Wo, hip.stream()), "sp_maxpool3s2_fwd_idx")
+        ctx.shape = (N, H, W_, Cc, Ho, Wo)
+        ctx.save_for_backward(amx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y = ctx.saved_tensors
+        (amx,) = ctx.saved_tensors
         dy = dy.contiguous()
-        N, H, W_, Cc = x.shape
-        _, Ho, Wo, _ = y.shape
-        dx = torch.empty_like(x)
-        check(hip.lib().sp_maxpool3s2_bwd(ptr(dy), ptr(x), ptr(y), N, H, W_, Cc, ptr(dx), Ho, Wo, hip.stream()),
-              "sp_maxpool3s2_bwd")
+        N, H, W_, Cc, Ho, Wo = ctx.shape
+        dx = torch.empty((N, H, W_, Cc), dtype=torch.float32, device=dy.device)
+        check(hip.lib().sp_maxpool3s2_bwd_idx(ptr(dy), ptr(amx), N, H, W_, Cc, ptr(dx), Ho, Wo, hip.stream()),
+              "sp_maxpool3s2_bwd_idx")
         return dx
 
 
@@ -1106,20 +1111,27 @@ class _GateConvLstm(Function):
         h = torch.empty_like(c_prev)
         hint = _amax_hint(xg.device)
         d = ConvDesc(N, H, W_, Ci, Ci, H, W_, Co, Co, KH, KW, 1, 1, 1, 0, KH * KW * Ci, 1.0, 0, 0, 1, 0, 0, 0, 0, None)
+        cbounds = _cell_bounds(c_prev, c)
+        # |h| = |o * c| <= |c| <= t + 1: with that bound the epilogue writes h's split operand itself (no max|h| pass, no split pass)
+        hplanes = torch.empty(2 * h.numel() + 32, dtype=torch.float16, device=h.device) \
+            if (hint is not None and cbounds[0] is not None and Ci % 16 == 0) else None
 
         def launch():
             check(hip.lib().sp_gateconv_lstm_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(wsplit.buf), ptr(wsplit.scale),
                                                    ptr(xg), ptr(c_prev), ptr(spcol), ptr(wc), P, KP, ptr(gates), ptr(c), ptr(h),
-                                                   _hint_ptr(hint), hip.stream()), "sp_gateconv_lstm_f16x2")
+                                                   None if hplanes is not None else _hint_ptr(hint), ptr(hplanes),
+                                                   ptr(hint) if hplanes is not None else None,
+                                                   float(cbounds[0]) if hplanes is not None else 0.0, hip.stream()),
+                  "sp_gateconv_lstm_f16x2")
         if hip.TIMER is None:
             launch()
         else:
             hip.TIMER.bracket(("h2_fwd", N * P, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * N * P * Co * KH * KW * Ci, launch)
         if hint is not None:
             h._sp_amax = hint
-        h._sp_cache = {}
+        h._sp_cache = {"f16x2": SplitOperand(hplanes, hint, "f16x2")} if hplanes is not None else {}
         ctx.set_materialize_grads(False)
-        ctx.cbounds = _cell_bounds(c_prev, c)
+        ctx.cbounds = cbounds
         keep = ctx.needs_input_grad[1] and _w3_pays(N * P, Co, KH * KW * Ci, Ci, free_splits=True) \
             and xs.scheme == _wgrad_scheme(Ci, Co)
         ctx.xs_scheme = xs.scheme if keep else None

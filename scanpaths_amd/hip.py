@@ -50,7 +50,7 @@ SIGNATURES = {
     "sp_conv_wgrad_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_igemm_f16x1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
-    "sp_gateconv_lstm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "sp_gateconv_lstm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
     "sp_conv_igemm_bf16x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_bf16x3_workspace": (_L, [C.POINTER(WgradDesc)]),
     "sp_conv_wgrad_bf16x3": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),
@@ -75,6 +75,8 @@ SIGNATURES = {
     "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
     "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sp_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "sp_maxpool3s2_fwd_idx": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P]),
+    "sp_maxpool3s2_bwd_idx": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sp_nchw_to_nhwc_pad": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_pad_lastdim": (_I, [_P, _L, _I, _I, _P, _P]),
     "sp_add": (_I, [_P, _P, _P, _L, _P]),

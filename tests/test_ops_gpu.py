@@ -194,14 +194,14 @@ def test_maxpool_ceil_with_ties(hw):
     _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-6, "dx")
 
 
-@pytest.mark.parametrize("fused", [False, True, "epilogue"])
+@pytest.mark.parametrize("fused", [False, True, "epilogue", "epilogue_planes"])
 def test_lstm_cell_and_gate_conv(fused):
     """fused=False: rank-1 gate terms accumulated by the batched GEMM of gate_conv; fused=True: plain h-conv + lstm_cell_rank1
     (rank-1 terms inside the pointwise kernel; 135 pixels = 2 full 64-pixel tiles + a tail: the path of map sizes whose pixel
     count is no multiple of 256); "epilogue": the whole cell as the epilogue of the h-gate conv (sp_gateconv_lstm_f16x2, the
     path of the 40x64 benchmark map; 3 samples x 256 pixels, 96 channels = 3 channel tiles of the gathered weight rows)"""
     from scanpaths_amd import functional as F
-    B, Hm, Wm, C, S = (3, 16, 16, 96, 2) if fused == "epilogue" else (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
+    B, Hm, Wm, C, S = (3, 16, 16, 96, 2) if str(fused).startswith("epilogue") else (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
     KP = 20
     h, c = _rand(B, C, Hm, Wm, seed=24), _rand(B, C, Hm, Wm, seed=25)
     xg = _rand(B, 4 * C, Hm, Wm, seed=26)
@@ -239,6 +239,14 @@ def test_lstm_cell_and_gate_conv(fused):
     if fused == "epilogue":
         hn, cn = F.gateconv_lstm(hg_, whg, xgg, cg_, spcol, wc, {})
         assert float(hn._sp_amax[1]) == float(hn.abs().max())          # fused max|h| hint (float bits in slot 1)
+    elif fused == "epilogue_planes":
+        # with a bound of max|c_prev| on the state tensor (|c_t| <= t + 1 in the model) the epilogue also writes h's split operand
+        cg_._sp_cbound = float(c.abs().max()) + 0.5
+        hn, cn = F.gateconv_lstm(hg_, whg, xgg, cg_, spcol, wc, {})
+        op = hn._sp_cache["f16x2"]
+        bound = float(op.scale[1])
+        assert bound == cg_._sp_cbound + 1.0 and float(hn.abs().max()) <= bound
+        assert float((_decode_split(op, hn.shape) - hn.detach()).abs().max()) <= 2.0 ** -21 * bound
     elif fused:
         hn, cn = F.lstm_cell_rank1(xgg, F.conv2d(hg_, whg, None, pad=1), cg_, spcol, wc)
     else:
