@@ -63,6 +63,7 @@ struct H2Args {
     uint16_t* l_hplanes;    // nullable: h as the 2xfp16 split operand of its consumers, scale from l_hbound >= max|h|
     float* l_hscale;        // [2] {scale, bound}
     float l_hbound;
+    int l_direct_hc;
     int lC, lP, lKP;
     // BatchNorm batch statistics of the output, fused into the epilogue (forward, 16x16x32 build): per M-tile and output column
     // the sum and the sum of squares (fp64) and min / max (fp32) of the tile's valid rows, in the [G = M-tiles][2][Nout] layout
@@ -684,6 +685,10 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 cv[i][r] = cn;
                 hv[i][r] = hn;
                 hmx = fmaxf(hmx, fabsf(hn));
+                if (p.l_direct_hc) {                        // A/B switch (sp_set_tuning("lstm_epi", 1)): 4-byte stores from the MFMA layout
+                    p.l_c[m * C + ch] = cn;
+                    p.l_h[m * C + ch] = hn;
+                }
             }
         __syncthreads();
 #pragma unroll
@@ -695,6 +700,14 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
         // h and c leave the same way ([256 rows][32 channels] each: 128-byte runs), and h also as the split operand of its consumers
         // (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <= t + 1, so the operand scale needs no max|h| pass
+        if (p.l_direct_hc) {
+            if (p.l_hamax) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) hmx = fmaxf(hmx, __shfl_xor(hmx, off));
+                if (lane == 0 && hmx > 0.f) atomicMax(p.l_hamax, __float_as_uint(hmx));
+            }
+            return;
+        }
         __syncthreads();
         float* hs = xs;
         float* cs2 = xs + HBM * 32;
@@ -1914,6 +1927,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (hout_planes && (!hout_scale || !(hout_bound > 0.f) || ((uintptr_t)hout_planes & 15))) return SP_EINVAL;
     a.l_gates = gates; a.l_c = c_out; a.l_h = h_out; a.l_hamax = h_amax;
     a.l_hplanes = (uint16_t*)hout_planes; a.l_hscale = hout_scale; a.l_hbound = hout_bound;
+    a.l_direct_hc = (!hout_planes && sp_tuning_get(SP_TUNE_LSTM_EPI, 0) == 1) ? 1 : 0;
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);

@@ -226,7 +226,8 @@ def _w3_pays(M, Co, K, Ci, nbatch=1, free_splits=False):
     return flops * (1 / 1.0e14 - 1 / (3.2e14 if f16 else 1.6e14)) > split_bytes / 4e12 and flops > 2e9
 
 
-def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0, alpha=1.0):
+def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0, alpha=1.0,
+              ws_slot=0):
     if not isinstance(Xs, SplitOperand):
         Xs, dYs = SplitOperand(Xs, None, "bf16x3"), SplitOperand(dYs, None, "bf16x3")
     assert Xs.scheme == dYs.scheme, (Xs.scheme, dYs.scheme)
@@ -234,7 +235,7 @@ def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, st
     L = hip.lib()
     f16 = Xs.scheme == "f16x2"
     ws = hip.workspace((L.sp_conv_wgrad_f16x2_workspace if f16 else L.sp_conv_wgrad_bf16x3_workspace)(C.byref(d)), dW.device,
-                       slot=0)
+                       slot=ws_slot)
 
     def launch():
         if f16:
@@ -433,6 +434,8 @@ class _Conv2d(Function):
     def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None, bn_stats=False, grad_store=None, grad_accum=None):
         # grad_store / grad_accum: GradMerge of a block input -- leave the input gradient there / accumulate into what is there
         ctx.grad_store, ctx.grad_accum = grad_store, grad_accum
+        defer = wcache.get("defer") if isinstance(wcache, dict) else None       # DeferredWgrad of a weight applied T times
+        ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
         # wcache: dict shared by all applications of the SAME weight inside one forward/backward (the h-gate conv runs T times):
         # its split forms ("w": forward operand, "wT": data-gradient operand) are produced once instead of per step
         x = x.contiguous()
@@ -489,14 +492,58 @@ class _Conv2d(Function):
             check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
             dy = dyr
         dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                accum=ctx.grad_accum)
+                                accum=ctx.grad_accum, defer_final=ctx.defer_final)
         if ctx.grad_store is not None and dx is not None:
             ctx.grad_store.first = dx
         db = _colsum_any(dy, wp.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None):
+# MEASURED (round 2, same box, bs 32, 320x512, T = 16): 317.6 / 319.5 ms per step with the side stream, 317.5 / 316.5 without -- the
+# weight-gradient GEMM (3.9 -> 6.9 ms per launch) and the main stream's kernels (data gradient 3.0 -> 3.9 ms) merely share the CUs:
+# a GEMM workgroup owns its CU's whole LDS and register file, so an HBM-bound kernel of the other stream cannot run BESIDE it, only
+# INSTEAD of it.  Off by default (SP_SIDE_WGRAD=1 enables it); results are bit-identical either way.
+SIDE_WGRAD = os.environ.get("SP_SIDE_WGRAD", "0") == "1"
+
+
+class DeferredWgrad:
+    """Weight gradient of a conv that is applied T times with the same weight (the h-gate conv): nobody needs the T contributions
+    before the end of backward, so each one runs on a SIDE stream, accumulating into one buffer (epilogue beta = 1), while the main
+    stream goes on with the recurrence (data gradient, cell backward, heads, fan-ins -- the HBM- and latency-bound part of a decode
+    step, during which the matrix pipes would otherwise idle).  The application that runs LAST in backward (the first one of the
+    forward pass claims that role) waits for the side stream and hands the sum to autograd; the others return no gradient."""
+    __slots__ = ("acc", "claimed")
+
+    def __init__(self):
+        self.acc, self.claimed = None, False
+
+    def claim(self) -> bool:
+        first, self.claimed = not self.claimed, True
+        return first
+
+
+def _deferred_wgrad(defer, final, Xs, dYs, wp, geom):
+    dev = wp.device
+    side, main = hip.side_stream(dev), torch.cuda.current_stream()
+    side.wait_stream(main)                       # the split operands were produced on the main stream
+    with torch.cuda.stream(side):
+        beta = 1
+        if defer.acc is None:
+            defer.acc, beta = torch.empty_like(wp), 0
+        _wgrad_b3(Xs, dYs, defer.acc, beta=beta, ws_slot=3, **geom)
+    for op in (Xs, dYs):                         # keep the operands' memory from being reused before the side kernel has read it
+        op.buf.record_stream(side)
+        if op.scale is not None:
+            op.scale.record_stream(side)
+    if not final:
+        return None
+    main.wait_stream(side)
+    acc, defer.acc, defer.claimed = defer.acc, None, False
+    acc.record_stream(main)                      # allocated on the side stream, consumed on the main one
+    return acc.permute(0, 3, 1, 2)
+
+
+def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None, defer_final=False):
     """data and weight gradient of y = conv(x, wp) (NHWC, physical weight [Co,KH,KW,Ci]); xs: the forward's split x or None;
     accum: GradMerge whose ``first`` (another consumer's gradient of x) the data gradient is added to in place"""
     N, H, W_, Ci = x.shape
@@ -505,14 +552,28 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
     dx = dw = None
     dys = None
     dy_cached = getattr(dy, "_sp_cache", None)       # the producer of dy (a BatchNorm / cell backward) already wrote its split form
+    defer = wcache.get("defer") if (SIDE_WGRAD and isinstance(wcache, dict)) else None
+    if need_dw and defer is not None:
+        wsch = _wgrad_scheme(Ci, Co)
+        if xs is not None and xs.scheme == wsch and \
+                _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=dy_cached is not None and wsch in dy_cached):
+            # launched BEFORE the data gradient: the side stream then only waits for the operands, not for that GEMM
+            dys = dy_cached[wsch] if (dy_cached is not None and wsch in dy_cached) else split_op(dy, wsch)
+            dw = _deferred_wgrad(defer, defer_final, xs, dys, wp,
+                                 dict(N_img=N, Hi=H, Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride,
+                                      pad=pad, dil=dil))
+            need_dw = False
+        elif defer_final and defer.acc is not None:          # (this application fell back to the plain path: still hand over the sum)
+            need_dw = "plus_deferred"
     if need_dx:
         beta = 0
         if accum is not None and accum.first is not None and accum.first.shape == x.shape and accum.first.is_contiguous():
             dx, beta, accum.merged = accum.first, 1, True
         else:
             dx = torch.empty_like(x)
-        if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel(), free_a=dy_cached is not None):
-            dys = split_op(dy)
+        if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel(), free_a=dy_cached is not None or dys is not None):
+            if dys is None or dys.scheme != _scheme_for(Co):
+                dys = split_op(dy)
             wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
             if wT is None:
                 wT = split_op_wT(wp, dys.scheme)
@@ -537,6 +598,10 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
             _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
         dw = dwp.permute(0, 3, 1, 2)
+        if need_dw == "plus_deferred":
+            torch.cuda.current_stream().wait_stream(hip.side_stream(wp.device))
+            dw = dw + defer.acc.permute(0, 3, 1, 2)
+            defer.acc, defer.claimed = None, False
     return dx, dw
 
 
@@ -1073,6 +1138,7 @@ def lstm_cell_rank1(xg, hg, c_prev, spcol, wc):
 
 
 FUSE_GATE_LSTM = os.environ.get("SP_FUSE_LSTM", "1") != "0"
+LSTM_H_PLANES = os.environ.get("SP_LSTM_H_PLANES", "1") != "0"
 
 
 def gateconv_lstm_fusable(h, w_h, spcol) -> bool:
@@ -1114,7 +1180,7 @@ class _GateConvLstm(Function):
         cbounds = _cell_bounds(c_prev, c)
         # |h| = |o * c| <= |c| <= t + 1: with that bound the epilogue writes h's split operand itself (no max|h| pass, no split pass)
         hplanes = torch.empty(2 * h.numel() + 32, dtype=torch.float16, device=h.device) \
-            if (hint is not None and cbounds[0] is not None and Ci % 16 == 0) else None
+            if (LSTM_H_PLANES and hint is not None and cbounds[0] is not None and Ci % 16 == 0) else None
 
         def launch():
             check(hip.lib().sp_gateconv_lstm_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(wsplit.buf), ptr(wsplit.scale),
@@ -1132,6 +1198,8 @@ class _GateConvLstm(Function):
         h._sp_cache = {"f16x2": SplitOperand(hplanes, hint, "f16x2")} if hplanes is not None else {}
         ctx.set_materialize_grads(False)
         ctx.cbounds = cbounds
+        defer = wcache.get("defer") if isinstance(wcache, dict) else None
+        ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
         keep = ctx.needs_input_grad[1] and _w3_pays(N * P, Co, KH * KW * Ci, Ci, free_splits=True) \
             and xs.scheme == _wgrad_scheme(Ci, Co)
         ctx.xs_scheme = xs.scheme if keep else None
@@ -1145,7 +1213,8 @@ class _GateConvLstm(Function):
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
                                                    ctx.needs_input_grad[5], ctx.cbounds)
         xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
-        dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                 defer_final=ctx.defer_final)
         return dhp, dw, dpre, dcp, dsp, dwc, None
 
 

@@ -156,7 +156,7 @@ def lib() -> C.CDLL:
         # their reset node only while a stream is being captured (graph replays re-use the slot)
         if not os.environ.get("SP_ALWAYS_RESET_AMAX"):
             check(_lib.sp_set_tuning(b"amax_reset", 1), "sp_set_tuning")
-        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant")):      # A/B timing / profiling only
+        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi")):      # A/B timing / profiling only
             if os.environ.get(env):
                 check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib
@@ -182,6 +182,19 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+_side = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """one extra HIP stream per device for work nobody waits for until the end of backward (deferred weight gradients)"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side[key] = s
+    return s
 
 
 _ws = {}

@@ -390,6 +390,8 @@ class ScanpathModel(nn.Module):
         outs = {"logits": [], "amap": [], "mu": [], "s2": []}
         zpad = torch.zeros(B, 3 * 512, KP - 9 * S, device=dev) if KP > 9 * S else None
         wh_cache = {}          # split forms of the h-gate weight, shared by the T applications (and their backward)
+        if torch.is_grad_enabled() and Wh.requires_grad:
+            wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight-gradient GEMMs run on a side stream, summed in place
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t in range(T):
             se = se_mem.view(S, B, Cc)
