@@ -436,6 +436,7 @@ class _Conv2d(Function):
         ctx.grad_store, ctx.grad_accum = grad_store, grad_accum
         defer = wcache.get("defer") if isinstance(wcache, dict) else None       # DeferredWgrad of a weight applied T times
         ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
+        ctx.dy_token = None
         # wcache: dict shared by all applications of the SAME weight inside one forward/backward (the h-gate conv runs T times):
         # its split forms ("w": forward operand, "wT": data-gradient operand) are produced once instead of per step
         x = x.contiguous()
@@ -466,6 +467,16 @@ class _Conv2d(Function):
             y._sp_from_split = xs.scheme == "f16x2"        # a BatchNorm behind this conv may emit the split gradient (bn_act)
             if stats is not None:
                 y._sp_bnstats = stats
+            # Both backward GEMMs of this conv would read ONLY the split form of the output gradient: a BatchNorm behind it (the
+            # single consumer of y, see bn_act skip_dx) may then leave the fp32 gradient unwritten.  The token lets this conv's
+            # backward fail loudly if such a gradient ever arrives without its split form.
+            wsch = _wgrad_scheme(Ci, Co)
+            if (y._sp_from_split and wsch == "f16x2" and bias is None and not relu
+                    and (not ctx.needs_input_grad[1] or (xs.scheme == wsch and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci,
+                                                                                          free_splits=True)))
+                    and (not ctx.needs_input_grad[0] or _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=y.numel(),
+                                                                  free_a=True))):
+                ctx.dy_token = y._sp_dy_token = {"skipped": False}
             # the weight-gradient GEMM consumes the same split operand: keep it (6 B/element) instead of re-splitting x in
             # backward (HBM pass of 10 B/element per conv); sized for 288 GB
             if not (ctx.needs_input_grad[1] and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=True)
@@ -486,6 +497,9 @@ class _Conv2d(Function):
         stride, pad, dil, relu, has_bias = ctx.cfg
         x, wp, y, xs_buf, xs_scale = ctx.saved_tensors
         xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
+        if ctx.dy_token is not None and ctx.dy_token["skipped"] and getattr(dy, "_sp_cache", None) is None:
+            raise RuntimeError("scanpaths_amd: a BatchNorm left this gradient's fp32 form unwritten (skip_dx) but its split form "
+                               "did not arrive with it; run with SP_BN_SKIP_DX=0")
         dy = dy.contiguous()
         if relu:
             dyr = torch.empty_like(dy)
@@ -805,8 +819,10 @@ class _BnActSplit(Function):
     measured one, and the ReLU mask as one bit per element instead of the fp32 output.  emit_fwd / emit_bwd: whether the split
     operands will be read (else only the bound is attached as the max|.| hint)."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre, res_store=None):
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre, res_store=None,
+                dy_token=None):
         ctx.res_store = res_store          # GradMerge: the residual's gradient is left there for conv1's data gradient to add to
+        ctx.dy_token = dy_token            # set: the producing conv's backward reads only the split gradient -> dx stays unwritten
         # pre: (partial, mm, G) -- first statistics stage already done by the producing conv's epilogue (conv2d bn_stats=True)
         x = x.contiguous()
         Cc = x.shape[-1]
@@ -852,7 +868,11 @@ class _BnActSplit(Function):
         planes = torch.empty(2 * x.numel() + 32, dtype=torch.float16, device=dev) if emit else None
         ws = hip.workspace(L.sp_bn_split_workspace(M, Cc), dev, slot=1)
         dhint, bhint = _amax_hint(dev), _amax_hint(dev)
-        check(L.sp_bn_bwd_split(ptr(dy), ptr(x), ptr(mask), ptr(mean), ptr(invstd), ptr(gamma), ptr(ext), M, Cc, ptr(dx),
+        skip = emit and ctx.dy_token is not None          # the fp32 dx is allocated (autograd wants a tensor) but never written
+        if skip:
+            ctx.dy_token["skipped"] = True
+        check(L.sp_bn_bwd_split(ptr(dy), ptr(x), ptr(mask), ptr(mean), ptr(invstd), ptr(gamma), ptr(ext), M, Cc,
+                                None if skip else ptr(dx),
                                 ptr(dres), ptr(planes), ptr(dhint), _hint_ptr(bhint), ptr(dgamma), ptr(dbeta), ptr(ws),
                                 hip.stream()), "sp_bn_bwd_split")
         dx._sp_amax = dhint
@@ -860,17 +880,23 @@ class _BnActSplit(Function):
             dx._sp_cache = {"f16x2": SplitOperand(planes, dhint, "f16x2")}
         if ctx.res_store is not None and dres is not None:
             ctx.res_store.first = dres
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+
+
+BN_SKIP_DX = os.environ.get("SP_BN_SKIP_DX", "1") != "0"
 
 
 def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True, emit_split=False,
-           res_store=None):
-    """emit_split: the output feeds a conv that runs on the 2xfp16 split path -- the BatchNorm pass writes that operand itself"""
+           res_store=None, skip_dx=False):
+    """emit_split: the output feeds a conv that runs on the 2xfp16 split path -- the BatchNorm pass writes that operand itself.
+    skip_dx: x is a conv output with NO other consumer; when that conv's backward reads only the split gradient (it says so with a
+    token on x) the backward pass here writes the split gradient alone and leaves the fp32 one unwritten."""
     if (training and BN_SPLIT and x.shape[-1] % 4 == 0 and _amax_hint_active()
             and (residual is None or getattr(residual, "_sp_amax", None) is not None)):
         emit_bwd = getattr(x, "_sp_from_split", False)       # the producing conv's backward GEMMs read the split gradient
+        token = getattr(x, "_sp_dy_token", None) if (skip_dx and BN_SKIP_DX and emit_bwd) else None
         return _BnActSplit.apply(x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_split, emit_bwd,
-                                 getattr(x, "_sp_bnstats", None), res_store)
+                                 getattr(x, "_sp_bnstats", None), res_store, token)
     return _BnAct.apply(x, gamma, beta, rmean, rvar, residual, training, momentum, eps, relu)
 
 

@@ -199,8 +199,9 @@ class ScanpathModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _bn(self, bn: _BN, x, residual=None, relu=True, emit_split=False, res_store=None):
+        # skip_dx: every BatchNorm of the encoder is the only consumer of the conv output it normalises
         y = F.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training=self.training, relu=relu,
-                     emit_split=emit_split, res_store=res_store)
+                     emit_split=emit_split, res_store=res_store, skip_dx=True)
         if self.training:
             self._bn_seen.append(bn.num_batches_tracked)       # one fused increment per forward (encode) instead of 53 launches
         return y
