@@ -448,6 +448,9 @@ class _Conv2d(Function):
         y = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
         xs = None
         shared = getattr(x, "_sp_cache", None) is not None
+        if getattr(x, "_sp_uninit", False) and not conv_runs_from_split(x.shape, w, stride, pad, dil, ctx.needs_input_grad[1]):
+            raise RuntimeError("scanpaths_amd: a BatchNorm left this input's fp32 form unwritten (skip_z) but this conv does not run "
+                               "from the split operand alone; run with SP_BN_SKIP_DX=0")
         if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel(), free_a=shared):
             xs = split_op(x)
             wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
@@ -625,6 +628,17 @@ def conv_takes_split(x_shape, w, stride=1, pad=0, dil=1) -> bool:
     Co, _, KH, KW = w.shape
     Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
     return _scheme_for(Ci) == "f16x2" and _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=N * H * W_ * Ci, free_a=True)
+
+
+def conv_runs_from_split(x_shape, w, stride=1, pad=0, dil=1, need_dw=True) -> bool:
+    """conv2d(x, w) reads x only through its split operand: forward on the split path, and (if the weight needs a gradient) the
+    weight-gradient GEMM from the split operand kept by the forward pass"""
+    N, H, W_, Ci = x_shape
+    Co, _, KH, KW = w.shape
+    Ho, Wo = _out_hw(H, W_, KH, KW, stride, pad, dil)
+    if not conv_takes_split(x_shape, w, stride, pad, dil):
+        return False
+    return (not need_dw) or (_wgrad_scheme(Ci, Co) == "f16x2" and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=True))
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None, bn_stats=False, grad_store=None, grad_accum=None):
@@ -820,7 +834,7 @@ class _BnActSplit(Function):
     operands will be read (else only the bound is attached as the max|.| hint)."""
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre, res_store=None,
-                dy_token=None):
+                dy_token=None, skip_z=False):
         ctx.res_store = res_store          # GradMerge: the residual's gradient is left there for conv1's data gradient to add to
         ctx.dy_token = dy_token            # set: the producing conv's backward reads only the split gradient -> dx stays unwritten
         # pre: (partial, mm, G) -- first statistics stage already done by the producing conv's epilogue (conv2d bn_stats=True)
@@ -840,14 +854,18 @@ class _BnActSplit(Function):
         y = torch.empty_like(x)
         res = residual.contiguous() if residual is not None else None
         zhint, bhint = _amax_hint(dev), _amax_hint(dev)
+        skip_z = bool(skip_z) and planes is not None          # the only consumer reads the split operand: fp32 output unwritten
         check(L.sp_bn_fwd_split(ptr(x), M, Cc, eps, momentum, ptr(gamma), ptr(beta), ptr(res),
                                 _hint_ptr(residual._sp_amax) if residual is not None else None, int(relu), ptr(mean), ptr(invstd),
-                                ptr(rmean), ptr(rvar), ptr(ext), ptr(y), ptr(planes), ptr(zhint), _hint_ptr(bhint), ptr(mask),
+                                ptr(rmean), ptr(rvar), ptr(ext), None if skip_z else ptr(y), ptr(planes), ptr(zhint),
+                                _hint_ptr(bhint), ptr(mask),
                                 ptr(ws), ptr(pre[0]) if pre else None, ptr(pre[1]) if pre else None, pre[2] if pre else 0,
                                 hip.stream()), "sp_bn_fwd_split")
         y._sp_amax = zhint
         if planes is not None:
             y._sp_cache = {"f16x2": SplitOperand(planes, zhint, "f16x2")}
+        if skip_z:
+            y._sp_uninit = True            # conv2d refuses such an input unless it runs (forward and backward) from the split operand
         ctx.cfg = (relu, residual is not None, bool(emit_bwd) and Cc % 16 == 0)
         ctx.save_for_backward(x, mask, mean, invstd, gamma.detach(), ext)
         return y
@@ -880,23 +898,26 @@ class _BnActSplit(Function):
             dx._sp_cache = {"f16x2": SplitOperand(planes, dhint, "f16x2")}
         if ctx.res_store is not None and dres is not None:
             ctx.res_store.first = dres
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
 
 
 BN_SKIP_DX = os.environ.get("SP_BN_SKIP_DX", "1") != "0"
+BN_SKIP_Z = os.environ.get("SP_BN_SKIP_Z", "1") != "0"
 
 
 def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True, emit_split=False,
-           res_store=None, skip_dx=False):
+           res_store=None, skip_dx=False, skip_z=False):
     """emit_split: the output feeds a conv that runs on the 2xfp16 split path -- the BatchNorm pass writes that operand itself.
     skip_dx: x is a conv output with NO other consumer; when that conv's backward reads only the split gradient (it says so with a
-    token on x) the backward pass here writes the split gradient alone and leaves the fp32 one unwritten."""
+    token on x) the backward pass here writes the split gradient alone and leaves the fp32 one unwritten.
+    skip_z: the output's ONLY consumer is a conv that runs forward and backward from the split operand (conv_runs_from_split): the
+    fp32 output is allocated but not written.  Neither tensor may be handed to code outside the encoder."""
     if (training and BN_SPLIT and x.shape[-1] % 4 == 0 and _amax_hint_active()
             and (residual is None or getattr(residual, "_sp_amax", None) is not None)):
         emit_bwd = getattr(x, "_sp_from_split", False)       # the producing conv's backward GEMMs read the split gradient
         token = getattr(x, "_sp_dy_token", None) if (skip_dx and BN_SKIP_DX and emit_bwd) else None
         return _BnActSplit.apply(x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_split, emit_bwd,
-                                 getattr(x, "_sp_bnstats", None), res_store, token)
+                                 getattr(x, "_sp_bnstats", None), res_store, token, skip_z and emit_split and BN_SKIP_DX and BN_SKIP_Z)
     return _BnAct.apply(x, gamma, beta, rmean, rvar, residual, training, momentum, eps, relu)
 
 

@@ -198,10 +198,10 @@ class ScanpathModel(nn.Module):
                 nn.init.zeros_(m.bias)
 
     # ------------------------------------------------------------------------------------------------
-    def _bn(self, bn: _BN, x, residual=None, relu=True, emit_split=False, res_store=None):
+    def _bn(self, bn: _BN, x, residual=None, relu=True, emit_split=False, res_store=None, skip_z=False):
         # skip_dx: every BatchNorm of the encoder is the only consumer of the conv output it normalises
         y = F.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training=self.training, relu=relu,
-                     emit_split=emit_split, res_store=res_store, skip_dx=True)
+                     emit_split=emit_split, res_store=res_store, skip_dx=True, skip_z=skip_z)
         if self.training:
             self._bn_seen.append(bn.num_batches_tracked)       # one fused increment per forward (encode) instead of 53 launches
         return y
@@ -230,9 +230,13 @@ class ScanpathModel(nn.Module):
             x, x_side = F.tap(x, gm) if gm is not None else (x, x)
             if kind == "bottleneck":
                 o = F.conv2d(x, blk.conv1.weight, None, stride=s, bn_stats=st, grad_accum=gm)
-                o = self._bn(blk.bn1, o, emit_split=F.conv_takes_split(o.shape, blk.conv2.weight, pad=dil, dil=dil))
+                # bn1 / bn2 feed exactly one conv: where that conv runs from the split operand alone the fp32 output stays unwritten
+                o = self._bn(blk.bn1, o, emit_split=F.conv_takes_split(o.shape, blk.conv2.weight, pad=dil, dil=dil),
+                             skip_z=F.conv_runs_from_split(o.shape, blk.conv2.weight, pad=dil, dil=dil,
+                                                           need_dw=blk.conv2.weight.requires_grad))
                 o = F.conv2d(o, blk.conv2.weight, None, pad=dil, dil=dil, bn_stats=st)
-                o = self._bn(blk.bn2, o, emit_split=F.conv_takes_split(o.shape, blk.conv3.weight))
+                o = self._bn(blk.bn2, o, emit_split=F.conv_takes_split(o.shape, blk.conv3.weight),
+                             skip_z=F.conv_runs_from_split(o.shape, blk.conv3.weight, need_dw=blk.conv3.weight.requires_grad))
                 o = F.conv2d(o, blk.conv3.weight, None, bn_stats=st)
                 last = blk.bn3
             else:
