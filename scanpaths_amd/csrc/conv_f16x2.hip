@@ -1452,11 +1452,11 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 
     int stage = 0;
     const bool late = VAR != 0 && wave >= 4;
-    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(1);
+    if ((VAR == 3 || VAR == 4) && late) __builtin_amdgcn_s_setprio(1);
     if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
-            if (VAR >= 2 && VAR != 4 && pre) issue_tile(prev_stage(stage));
+            if (VAR >= 2 && VAR != 4 && VAR != 5 && pre) issue_tile(prev_stage(stage));
             if (VAR == 0 && !M16) {         // round-1 order: reads of a 16-pixel group right before its MFMAs
                 read_group(stage, 0);
                 mma_group(0);
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             } else {
                 read_group(stage, 0);
                 read_group(stage, 1);
-                if (VAR == 4 && pre) issue_tile(prev_stage(stage));      // VAR 4: fragment reads ahead of the LDS-DMA issue block
+                if ((VAR == 4 || VAR == 5) && pre) issue_tile(prev_stage(stage));      // VAR 4 / 5 (5: without s_setprio): fragment reads ahead of the LDS-DMA issue block
                 mma_group(0);
                 mma_group(1);
             }
@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             fold(nkt - 1);
         }
     }
-    if (VAR >= 3 && late) __builtin_amdgcn_s_setprio(0);
+    if ((VAR == 3 || VAR == 4) && late) __builtin_amdgcn_s_setprio(0);
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
@@ -1985,6 +1985,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
         case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
         case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
         case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
+        case 10: rc = launch_hw<5, 3, true>(a, d->Co, s); break;     // = 8 without s_setprio on the late waves
         default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
     }
     if (rc != SP_OK) return rc;
