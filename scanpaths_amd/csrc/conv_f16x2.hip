@@ -33,7 +33,7 @@ constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
 constexpr int HW_DEFAULT_MAP = 0;                // sp_set_tuning("hw_map", 1): aligned-rounds workgroup order of hw_kernel
 constexpr int H2_DEFAULT_VARIANT = 17;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
-constexpr int HW_DEFAULT_VARIANT = 8;            // schedule variant of hw_kernel
+constexpr int HW_DEFAULT_VARIANT = 10;           // schedule variant of hw_kernel
 
 struct H2Args {
     const uint16_t* X;    // [pixels][Kc/16][2][16]
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     };
 
     int stage = 0;
-    const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5 || VAR == 6) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
+    const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5 || VAR == 6 || VAR == 7) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
     if ((VAR == 3 || VAR == 5 || VAR == 6) && late) __builtin_amdgcn_s_setprio(1);
     if constexpr (VAR == 6 && M16 && do_mma && do_load) {
         // VAR 6: ping-pong (as 3) with the LDS-DMA pieces spread through each wave's OWN matrix segment
@@ -561,9 +561,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
             // prefetch of tile kt+2 into the stage read in iteration kt-1: VAR >= 2 issues it FIRST (its partner wave is in its
             // matrix segment now), the lockstep / half-stagger variants behind the MFMAs in program order (see b3_kernel)
-            if (VAR >= 2 && VAR != 5 && pre) issue_tile(prev_stage(stage));
+            if (VAR >= 2 && VAR != 5 && VAR != 7 && pre) issue_tile(prev_stage(stage));
             read_frags(stage, kt);
-            if (VAR == 5 && pre) issue_tile(prev_stage(stage));          // VAR 5 (= 3 with the fragment reads ahead of the issue block)
+            if ((VAR == 5 || VAR == 7) && pre) issue_tile(prev_stage(stage));          // VAR 5 (= 3 with the fragment reads ahead of the issue block)
             mma_group(0);
             mma_group(1);
             if (VAR < 2 && pre) issue_tile(prev_stage(stage));
@@ -1851,12 +1851,13 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
     // bit 3 = channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
     const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
-    if ((variant == 17 || variant == 18) && !cbm_ok) variant = 7;
+    if ((variant == 17 || variant == 18 || variant == 19) && !cbm_ok) variant = 7;
     if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
     switch (variant) {
         case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
         case 17: return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);      // = 15, reads before the issue block
         case 18: return f ? launch_h2<0, 0, 6, 3, true, true>(a, st) : launch_h2<1, 0, 6, 3, true, true>(a, st);      // ping-pong + LDS-DMA pieces spread through the matrix segment
+        case 19: return f ? launch_h2<0, 0, 7, 3, true, true>(a, st) : launch_h2<1, 0, 7, 3, true, true>(a, st);      // = 17 without s_setprio on the late waves
         case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
         case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
         case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
