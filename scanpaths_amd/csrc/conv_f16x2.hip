@@ -890,9 +890,11 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 // These launches move 0.3-0.8 GB for 20-90 GFLOP: they are HBM-bound, and h2_kernel's 256x128 tile with a 144 KB ring (one
 // workgroup per CU, nothing to overlap its prologue latency and its 128 KB epilogue with) runs them at ~1.2 TB/s.  Here: 128x128 tile,
 // 4 waves (2x2, wave tile 64x64), two 32 KB stages -> 64 KB LDS, TWO workgroups per CU whose load / matrix / store phases overlap.
-// MEASURED (round 2, encoder at bs 32, 320x512): SLOWER than h2_kernel on the same launches (666 vs 540 us on the M = 327 680,
-// N = 512, K = 128 shape; encoder forward + backward 94.4 vs 91.8 ms) -- occupancy is not what holds these launches back.  Kept as
-// an opt-in experiment (sp_set_tuning("s2", 1)); the default path does not use it.
+// MEASURED (round 2, encoder at bs 32, 320x512): with 4-byte epilogue stores SLOWER than h2_kernel on the same launches (666 vs
+// 540 us on the M = 327 680, N = 512, K = 128 shape) -- what held these launches back was the store pattern of the epilogue, not
+// occupancy.  With float4 stores through the ring in both kernels: 328 vs 346 us on that shape, 111 vs 128 (K = 256, N = 64), equal
+// once the statistics epilogue is on, encoder forward + backward 79.68 vs 79.70 ms.  Kept as an opt-in experiment
+// (sp_set_tuning("s2", 1) / SP_S2=1); the default path does not use it.
 struct S2Args {
     const uint16_t* A;    // [rows][K/16][2][16]
     const uint16_t* W;    // [Nout][K/16][2][16]
@@ -1024,56 +1026,95 @@ __global__ __launch_bounds__(256, 2) void s2_kernel(S2Args p) {
 
     const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
     const bool stats = p.st_partial != nullptr;
-    if (stats) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // the stages are about to be reused for the statistics
-    }
-    double* sh_s = reinterpret_cast<double*>(smem);                  // [2 wm][128 col][2]
-    float* sh_m = reinterpret_cast<float*>(smem + 2 * S2_BN * 2 * sizeof(double));
+    const bool wide = (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // every wave is done with the stages: they become staging / statistics space
+    // float4 stores through a wave-private staging slice (see h2_kernel's epilogue), here in two halves of 32 rows (4 x 8.7 KB)
+    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    double cs[4], cq[4];
+    float cmn[4], cmx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + l16;
-        const bool n_ok = n < p.Nout;
-        const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
-        double cs = 0.0, cq = 0.0;
-        float cmn = INFINITY, cmx = -INFINITY;
+        cs[j] = 0.0;
+        cq[j] = 0.0;
+        cmn[j] = INFINITY;
+        cmx[j] = -INFINITY;
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
-                if (n_ok && m < p.M) {
-                    float* dst = p.C + m * p.ldc + n;
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l16;
+            const bool n_ok = n < p.Nout;
+            const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = half * 2 + ii;
+                    const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
                     float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
-                    if (p.beta) v += *dst;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    *dst = v;
-                    if (stats) {
-                        cs += (double)v;
-                        cq += (double)v * (double)v;
-                        cmn = fminf(cmn, v);
-                        cmx = fmaxf(cmx, v);
+                    if (wide) {
+                        stg[(ii * 16 + 4 * g4 + r) * 68 + j * 16 + l16] = v;
+                    } else if (n_ok && m < p.M) {
+                        float* dst = p.C + m * p.ldc + n;
+                        if (p.beta) v += *dst;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        *dst = v;
+                    }
+                    if (stats && n_ok && m < p.M) {
+                        cs[j] += (double)v;
+                        cq[j] += (double)v * (double)v;
+                        cmn[j] = fminf(cmn[j], v);
+                        cmx[j] = fmaxf(cmx[j], v);
                     }
                 }
-            }
-        if (stats) {
+        }
+        if (wide) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int cq4 = lane & 15, rsub = lane >> 4;
+            const int n = n0 + wn * 64 + 4 * cq4;
 #pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                cs += __shfl_xor(cs, off);
-                cq += __shfl_xor(cq, off);
-                cmn = fminf(cmn, __shfl_xor(cmn, off));
-                cmx = fmaxf(cmx, __shfl_xor(cmx, off));
+            for (int ps = 0; ps < 8; ++ps) {
+                const int row = ps * 4 + rsub;
+                const int64_t m = m0 + wm * 64 + half * 32 + row;
+                if (m < p.M && n < p.Nout) {
+                    float4 v = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
+                    float4* dst = reinterpret_cast<float4*>(p.C + m * p.ldc + n);
+                    if (p.beta) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *dst = v;
+                }
             }
-            if (g4 == 0) {
-                const int col = wn * 64 + j * 16 + l16;
-                sh_s[(wm * S2_BN + col) * 2 + 0] = cs;
-                sh_s[(wm * S2_BN + col) * 2 + 1] = cq;
-                sh_m[(wm * S2_BN + col) * 2 + 0] = cmn;
-                sh_m[(wm * S2_BN + col) * 2 + 1] = cmx;
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slice is rewritten by the second half
         }
     }
     if (stats) {
+        __syncthreads();
+        double* sh_s = reinterpret_cast<double*>(smem);                  // [2 wm][128 col][2]
+        float* sh_m = reinterpret_cast<float*>(smem + 2 * S2_BN * 2 * sizeof(double));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                cs[j] += __shfl_xor(cs[j], off);
+                cq[j] += __shfl_xor(cq[j], off);
+                cmn[j] = fminf(cmn[j], __shfl_xor(cmn[j], off));
+                cmx[j] = fmaxf(cmx[j], __shfl_xor(cmx[j], off));
+            }
+            if (g4 == 0) {
+                const int col = wn * 64 + j * 16 + l16;
+                sh_s[(wm * S2_BN + col) * 2 + 0] = cs[j];
+                sh_s[(wm * S2_BN + col) * 2 + 1] = cq[j];
+                sh_m[(wm * S2_BN + col) * 2 + 0] = cmn[j];
+                sh_m[(wm * S2_BN + col) * 2 + 1] = cmx[j];
+            }
+        }
         __syncthreads();
         if (t < S2_BN && n0 + t < p.Nout) {
             const double a = sh_s[t * 2 + 0] + sh_s[(S2_BN + t) * 2 + 0], b = sh_s[t * 2 + 1] + sh_s[(S2_BN + t) * 2 + 1];
@@ -1456,7 +1497,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
-            if (VAR >= 2 && VAR != 4 && VAR != 5 && pre) issue_tile(prev_stage(stage));
+            if (VAR >= 2 && VAR != 4 && VAR != 5 && VAR != 6 && pre) issue_tile(prev_stage(stage));
             if (VAR == 0 && !M16) {         // round-1 order: reads of a 16-pixel group right before its MFMAs
                 read_group(stage, 0);
                 mma_group(0);
@@ -1465,7 +1506,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             } else {
                 read_group(stage, 0);
                 read_group(stage, 1);
-                if ((VAR == 4 || VAR == 5) && pre) issue_tile(prev_stage(stage));      // VAR 4 / 5 (5: without s_setprio): fragment reads ahead of the LDS-DMA issue block
+                if ((VAR == 4 || VAR == 5 || VAR == 6) && pre) issue_tile(prev_stage(stage));      // VAR 4 / 5 / 6 (5, 6: without s_setprio): fragment reads ahead of the LDS-DMA issue block
                 mma_group(0);
                 mma_group(1);
             }
@@ -1477,14 +1518,15 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     } else {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
-            if (kt > 0) {
+            if (VAR == 6 && pre) issue_tile(prev_stage(stage));      // VAR 6: the late waves issue their loads at the START of the
+            if (kt > 0) {                                            // iteration (their issue block no longer sits right before the barrier)
                 mma_group(0);
                 mma_group(1);
                 fold(kt - 1);
             }
             read_group(stage, 0);
             read_group(stage, 1);
-            if (pre) issue_tile(prev_stage(stage));
+            if (VAR != 6 && pre) issue_tile(prev_stage(stage));
             wait_barrier(kt);
             stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
         }
@@ -1987,6 +2029,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
         case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
         case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
         case 10: rc = launch_hw<5, 3, true>(a, d->Co, s); break;     // = 8 without s_setprio on the late waves
+        case 11: rc = launch_hw<6, 3, true>(a, d->Co, s); break;     // = 10 with the late waves' loads issued at the start of their iteration
         default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
     }
     if (rc != SP_OK) return rc;

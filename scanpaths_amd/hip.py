@@ -156,7 +156,7 @@ def lib() -> C.CDLL:
         # their reset node only while a stream is being captured (graph replays re-use the slot)
         if not os.environ.get("SP_ALWAYS_RESET_AMAX"):
             check(_lib.sp_set_tuning(b"amax_reset", 1), "sp_set_tuning")
-        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi")):      # A/B timing / profiling only
+        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi"), ("SP_S2", b"s2")):      # A/B timing / profiling only
             if os.environ.get(env):
                 check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib
