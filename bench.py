@@ -163,8 +163,34 @@ def call_model(model, args, b, training):
     return model(b["images"], b["attention_maps"], b["tasks"])
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a torch.distributed launcher around it: THIS process never touches the GPU (no HIP
+    call, no exec of an initialised process); it starts N ranks -- one process per GPU, RCCL -- as a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` and relays
+    rank 0's JSON line and the exit code.  The reference's counterpart is nn.DataParallel(model, gpu_ids) (AiR/train.py:169-170)."""
+    import socket
+    ndev = torch.cuda.device_count()              # counting devices does not initialise the GPU on this image
+    if ndev < args.gpus and os.environ.get("SP_DIST_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {args.gpus} asked for but only {ndev} HIP device(s) are visible; refusing to report a "
+              f"{args.gpus}-GPU number from fewer devices (RCCL needs one device per rank)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL's hipIpcGetMemHandle otherwise fails)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} rank(s)")
     if args.precision == "f16x1":
         os.environ["SP_SPLIT_SCHEME"] = "f16x1"          # read by scanpaths_amd.functional at import
     rank = int(os.environ.get("RANK", "0"))
@@ -206,7 +232,8 @@ def main():
             from scanpaths_amd.ddp import broadcast_module_state_
             broadcast_module_state_(model)      # BatchNorm buffers; FlatAdam broadcasts the flat parameter buffer itself
         opt = FlatAdam(model.parameters(), lr=1e-4, weight_decay=5e-5 if args.task == "air" else 5e-4, clip=12.5,
-                       conditional_params=model.has_conditional_params)
+                       conditional_params=model.has_conditional_params,
+                       reference_zero_grad=model.has_conditional_params)     # COCO heads: the reference's torch-1.6 zero-fill semantics
 
         def step():
             opt.zero_grad()

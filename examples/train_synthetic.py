@@ -53,7 +53,9 @@ def main():
     model = baseline(convLSTM_length=T, min_length=args.min_length, map_width=args.map_width, map_height=args.map_height)
     fill_module(model, seed=0)
     model = model.to(dev)
-    optimizer = FlatAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, clip=args.clip)
+    optimizer = FlatAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, clip=args.clip,
+                         conditional_params=getattr(model, "has_conditional_params", False),
+                         reference_zero_grad=getattr(model, "has_conditional_params", False))   # torch-1.6 zero_grad semantics for COCO heads
     sampling = Sampling(convLSTM_length=T, min_length=args.min_length, map_width=args.map_width, map_height=args.map_height,
                         width=args.width, height=args.height)
     g = np.random.Generator(np.random.PCG64(0))

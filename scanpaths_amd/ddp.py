@@ -79,7 +79,15 @@ class GradBucketer:
             self.next_b -= 1
 
     def mark_ready(self, i: int):
-        self.pending[self.bucket_of[i]] -= 1
+        b = self.bucket_of[i]
+        if b > self.next_b or self.pending[b] <= 0:
+            # a second backward before step() (gradient accumulation, two losses): this bucket's all-reduce is already in flight
+            # on the RCCL stream while autograd accumulates into the same memory -- the new contribution would never be reduced
+            # and the replicas would drift silently
+            raise RuntimeError("GradBucketer: a parameter's gradient was produced twice before FlatAdam.step() (gradient accumulation "
+                               "or two backward passes per step); the overlapped bucketed all-reduce supports ONE backward per step -- "
+                               "construct FlatAdam(bucket_mb=0) for a single un-overlapped all-reduce in step()")
+        self.pending[b] -= 1
         self._launch_ready()
 
     def finish(self):

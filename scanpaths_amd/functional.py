@@ -77,6 +77,17 @@ if SPLIT_SCHEME not in ("f16x2", "bf16x3"):
     raise ValueError(f"SP_SPLIT_SCHEME must be f16x2, bf16x3 or f16x1, got {SPLIT_SCHEME!r}")
 
 
+# how often each fused pass ran (tests assert that the benchmark's kernel path, not a fallback, is the one under test)
+FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
+                 "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
+                 "conv_bn_stats": 0, "grad_merge": 0}
+
+
+def reset_fusion_counts():
+    for k in FUSION_COUNTS:
+        FUSION_COUNTS[k] = 0
+
+
 class SplitOperand:
     """a GEMM operand in split form: buf (16-bit planes, interleaved per 16 k) + device scale (f16x2 only)"""
     __slots__ = ("buf", "scale", "scheme")
@@ -117,8 +128,12 @@ def _amax_hint(device) -> Optional[torch.Tensor]:
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     pool = _HINT_POOL.get(key)
-    if pool is None or pool[1] >= pool[0].shape[0]:          # one zero-fill per 2048 hints instead of one per hint
-        pool = [torch.zeros((2048, 2), dtype=torch.float32, device=device), 0]
+    # A pool created while a stream is being captured is zero-filled by a graph node: EVERY replay re-zeroes all of it.  Such a pool
+    # may therefore only serve captures (whose launchers reset each slot in stream order, sp_set_tuning("amax_reset")); eager
+    # code that drew its single-use slots from it would see them wiped -- or filled -- by a later replay.
+    capturing = torch.cuda.is_current_stream_capturing()
+    if pool is None or pool[1] >= pool[0].shape[0] or (pool[2] and not capturing):
+        pool = [torch.zeros((2048, 2), dtype=torch.float32, device=device), 0, capturing]      # one zero-fill per 2048 hints
         _HINT_POOL[key] = pool
     hint = pool[0][pool[1]]
     pool[1] += 1
@@ -165,14 +180,20 @@ def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     return SplitOperand(out, scale, scheme)
 
 
+# Parity tests run the benchmark's kernel path at a small batch: the cost models below then price every GEMM as if its pixel
+# dimension were COST_M_SCALE times larger (bs 2 with scale 16 takes exactly the decisions of bs 32).  1.0 in the product path.
+COST_M_SCALE = 1.0
+
+
 def _b3_pays(M, N, K, Kc, nbatch=1, a_elems=None, free_a=False):
     """cost model: split passes (10-12 B per operand element at ~4 TB/s) + split GEMM (~2.3x / ~4x the fp32 rate) < fp32 GEMM.
     a_elems: elements of the activation-side tensor (the loaders use 32-bit byte offsets into the split operand)"""
     if not USE_BF16X3 or nbatch != 1 or Kc % 16 or N < 64:
         return False
     f16 = _scheme_for(Kc) == "f16x2"
-    flops = 2.0 * M * N * K
-    split_bytes = (12.0 if f16 else 10.0) * ((0 if free_a else M * Kc) + N * K)     # free_a: the activation split already exists
+    Mc = M * COST_M_SCALE
+    flops = 2.0 * Mc * N * K
+    split_bytes = (12.0 if f16 else 10.0) * ((0 if free_a else Mc * Kc) + N * K)     # free_a: the activation split already exists
     bpe = 4.0 if f16 else 6.0
     if bpe * (a_elems if a_elems is not None else 4.0 * M * Kc) + 64 >= 2 ** 32 or bpe * N * K + 64 >= 2 ** 32:
         return False
@@ -219,8 +240,8 @@ def _w3_pays(M, Co, K, Ci, nbatch=1, free_splits=False):
     f16 = _wgrad_scheme(Ci, Co) == "f16x2"          # the 2xfp16 kernel takes any Ci % 16 == 0, the 3xbf16 one needs Ci % 128 == 0
     if not USE_BF16X3 or nbatch != 1 or Co % 16 or Co < 64 or (Ci % 128 and not f16):
         return False
-    flops = 2.0 * M * Co * K
-    split_bytes = 0.0 if free_splits else (12.0 if f16 else 10.0) * M * (Ci + Co)
+    flops = 2.0 * M * COST_M_SCALE * Co * K
+    split_bytes = 0.0 if free_splits else (12.0 if f16 else 10.0) * M * COST_M_SCALE * (Ci + Co)
     if 6.0 * M * max(Ci, Co) * 4 >= 2 ** 32:
         return False
     return flops * (1 / 1.0e14 - 1 / (3.2e14 if f16 else 1.6e14)) > split_bytes / 4e12 and flops > 2e9
@@ -313,6 +334,7 @@ class _FanOut(Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        ctx.set_materialize_grads(False)      # an alias nobody consumed contributes None, not a full-size zero tensor to sum
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -469,6 +491,7 @@ class _Conv2d(Function):
                       ldw=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu, stats=stats)
             y._sp_from_split = xs.scheme == "f16x2"        # a BatchNorm behind this conv may emit the split gradient (bn_act)
             if stats is not None:
+                FUSION_COUNTS["conv_bn_stats"] += 1
                 y._sp_bnstats = stats
             # Both backward GEMMs of this conv would read ONLY the split form of the output gradient: a BatchNorm behind it (the
             # single consumer of y, see bn_act skip_dx) may then leave the fp32 gradient unwritten.  The token lets this conv's
@@ -586,6 +609,7 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
         beta = 0
         if accum is not None and accum.first is not None and accum.first.shape == x.shape and accum.first.is_contiguous():
             dx, beta, accum.merged = accum.first, 1, True
+            FUSION_COUNTS["grad_merge"] += 1
         else:
             dx = torch.empty_like(x)
         if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel(), free_a=dy_cached is not None or dys is not None):
@@ -862,9 +886,12 @@ class _BnActSplit(Function):
                                 ptr(ws), ptr(pre[0]) if pre else None, ptr(pre[1]) if pre else None, pre[2] if pre else 0,
                                 hip.stream()), "sp_bn_fwd_split")
         y._sp_amax = zhint
+        FUSION_COUNTS["bn_fwd_split"] += 1
         if planes is not None:
+            FUSION_COUNTS["bn_fwd_split_operand"] += 1
             y._sp_cache = {"f16x2": SplitOperand(planes, zhint, "f16x2")}
         if skip_z:
+            FUSION_COUNTS["bn_skip_z"] += 1
             y._sp_uninit = True            # conv2d refuses such an input unless it runs (forward and backward) from the split operand
         ctx.cfg = (relu, residual is not None, bool(emit_bwd) and Cc % 16 == 0)
         ctx.save_for_backward(x, mask, mean, invstd, gamma.detach(), ext)
@@ -887,7 +914,11 @@ class _BnActSplit(Function):
         ws = hip.workspace(L.sp_bn_split_workspace(M, Cc), dev, slot=1)
         dhint, bhint = _amax_hint(dev), _amax_hint(dev)
         skip = emit and ctx.dy_token is not None          # the fp32 dx is allocated (autograd wants a tensor) but never written
+        FUSION_COUNTS["bn_bwd_split"] += 1
+        if emit:
+            FUSION_COUNTS["bn_bwd_split_operand"] += 1
         if skip:
+            FUSION_COUNTS["bn_skip_dx"] += 1
             ctx.dy_token["skipped"] = True
         check(L.sp_bn_bwd_split(ptr(dy), ptr(x), ptr(mask), ptr(mean), ptr(invstd), ptr(gamma), ptr(ext), M, Cc,
                                 None if skip else ptr(dx),
@@ -1126,7 +1157,6 @@ def _cell_bounds(c_prev, c):
 
 
 LSTM_BWD_SPLIT = os.environ.get("SP_LSTM_BWD_SPLIT", "1") != "0"
-FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0}      # how often a pass emitted its consumer's operand (tests)
 
 
 def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None)):
@@ -1240,6 +1270,8 @@ class _GateConvLstm(Function):
             launch()
         else:
             hip.TIMER.bracket(("h2_fwd", N * P, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * N * P * Co * KH * KW * Ci, launch)
+        FUSION_COUNTS["gateconv_lstm"] += 1
+        FUSION_COUNTS["gateconv_lstm_hplanes"] += int(hplanes is not None)
         if hint is not None:
             h._sp_amax = hint
         h._sp_cache = {"f16x2": SplitOperand(hplanes, hint, "f16x2")} if hplanes is not None else {}

@@ -324,8 +324,8 @@ class ScanpathModel(nn.Module):
         bias = torch.cat([self._sum_bias([g + "_x", g + "_h"] + [g + s for s in self.streams])
                           for g in ("input", "forget", "output")] + [self._sum_bias(["memory_x", "memory_h"])])
         # vf feeds the x-gate conv, its channel mean and the semantic pooling of every memory push: one gradient fan-in pass
-        # (sp_sum_n) instead of T + 2 read-read-write adds by autograd
-        n_vf = T + 3
+        # (sp_sum_n) instead of T + 1 read-read-write adds by autograd (T memory pushes: the one after the last step is not run)
+        n_vf = T + 2
         vfs = list(F.fanout(vf, n_vf)) if vf.requires_grad and n_vf <= 32 else [vf] * n_vf
         Xg = F.conv2d(vfs.pop(), Wx, bias, pad=1)
         Wh = self._cat_phys([L.input_h.weight, L.forget_h.weight, L.output_h.weight, L.memory_h.weight])
@@ -369,9 +369,9 @@ class ScanpathModel(nn.Module):
             summed by ONE sp_sum_n pass instead of T small read-read-write adds that autograd would launch one by one"""
             return list(F.fanout(t, n)) if (t is not None and t.requires_grad and 1 < n <= 32) else [t] * n
 
-        spw, spb = rep(self.spatial_embed.weight, T + 1), rep(self.spatial_embed.bias, T + 1)
-        sew, seb = rep(self.semantic_embed.weight, T + 1), rep(self.semantic_embed.bias, T + 1)
-        mvfs, u_spas, u_sems = rep(mvf, T + 1), rep(u_spa, T + 1), rep(u_sem, T + 1)
+        spw, spb = rep(self.spatial_embed.weight, T), rep(self.spatial_embed.bias, T)
+        sew, seb = rep(self.semantic_embed.weight, T), rep(self.semantic_embed.bias, T)
+        mvfs, u_spas, u_sems = rep(mvf, T), rep(u_spa, T), rep(u_sem, T)
         Wrs = [rep(w, T) for w in Wr]
         Wsals, W11s, cbsums, cbs, w2s, b2s = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T), rep(w2, T), rep(b2, T)
 

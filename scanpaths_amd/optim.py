@@ -42,7 +42,8 @@ class FlatAdam(torch.optim.Optimizer):
         momentum-stepped with a zero gradient (a COCO head whose category is absent from later batches)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 clip: float = 0.0, process_group=None, conditional_params: bool = False, bucket_mb: float = 32.0):
+                 clip: float = 0.0, process_group=None, conditional_params: bool = False, bucket_mb: float = 32.0,
+                 reference_zero_grad: bool = False, force_bucketer: bool = False):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip=clip))
         assert len(self.param_groups) == 1
@@ -63,6 +64,9 @@ class FlatAdam(torch.optim.Optimizer):
         self._steps = [0] * len(params)          # per-parameter Adam step (torch.optim.Adam keeps it per parameter)
         self._touched = [False] * len(params)    # did this backward produce a gradient for the parameter?
         self._sticky = False                     # zero_grad(set_to_none=False) semantics, see the class docstring
+        # reference_zero_grad: a bare zero_grad() zero-fills like the reference's pinned torch==1.6.0 (sp_baseline.yml:116) instead of
+        # following the installed torch's set_to_none=True default -- COCO_Search18 heads then keep decaying / momentum-stepping
+        self.reference_zero_grad = bool(reference_zero_grad)
         self.process_group = process_group
         self.conditional_params = bool(conditional_params)
         with torch.no_grad():
@@ -78,7 +82,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._bucketer = None
         if process_group is not False:
             from .ddp import GradBucketer, world_size
-            if world_size(process_group) > 1:
+            # force_bucketer: run the hook -> bucket -> async all-reduce machinery even in a world of one (the single-GPU RCCL test)
+            if world_size(process_group) > 1 or (force_bucketer and torch.distributed.is_initialized()):
                 torch.distributed.broadcast(self.flat_p, src=0, group=process_group)      # replicas start identical
                 if bucket_mb > 0:
                     self._bucketer = GradBucketer(self.flat_g, offs, total, int(bucket_mb * (1 << 20)), process_group)
@@ -97,9 +102,12 @@ class FlatAdam(torch.optim.Optimizer):
             return torch.empty(p.shape).stride()
         return torch.empty(p.shape).contiguous(memory_format=torch.channels_last).stride()
 
-    def zero_grad(self, set_to_none: bool = True):
+    def zero_grad(self, set_to_none: Optional[bool] = None):
         """one memset of the flat buffer; the .grad views always survive (set_to_none only selects WHICH parameters the next
-        step() updates, see the class docstring)"""
+        step() updates, see the class docstring).  Default: the installed torch's set_to_none=True, or the reference's zero-fill
+        when the optimizer was built with reference_zero_grad=True."""
+        if set_to_none is None:
+            set_to_none = not self.reference_zero_grad
         self._sticky = not set_to_none
         self.flat_g.zero_()
         self._touched = [False] * len(self._params)
@@ -134,7 +142,7 @@ class FlatAdam(torch.optim.Optimizer):
         if self.process_group is not False:   # RCCL sum over xGMI of the flat buffer (bucketed, overlapped); averaged in the Adam kernel
             from .ddp import allreduce_sum_, union_flags, world_size
             world = world_size(self.process_group)
-            if world > 1:
+            if world > 1 or self._bucketer is not None:
                 if self._bucketer is None:
                     allreduce_sum_(self.flat_g, self.process_group)
                 elif foreign:

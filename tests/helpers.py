@@ -34,3 +34,54 @@ def max_err(a, b):
     a = torch.as_tensor(a).detach().cpu().to(torch.float64)
     b = torch.as_tensor(b).detach().cpu().to(torch.float64)
     return (a - b).abs().max().item()
+
+
+# ---- validation-metric goldens (tests/golden/make_golden_eval.py) -------------------------------------------------------------
+FV_DTYPE = {"names": ("start_x", "start_y", "duration"), "formats": ("f8", "f8", "f8")}
+
+
+def toy_multimatch(fv1, fv2, screensize):
+    """A FIXED deterministic stand-in for multimatch_gaze.docomparison (third-party, absent here and not vendored by the
+    reference): 5 values in (0, 1] from simple float64 statistics of the two scanpaths, NaN when either has fewer than 3 fixations
+    (the package's rule, which is what makes the reference drop a pair, utils/evaluation.py:215-217).  The SAME function is the
+    `multimatch_gaze` module of the golden run and the `multimatch=` argument of the build's functions, so the goldens pin
+    everything around that column (pair enumeration, dropping, grouping, float32 collection, means / stds / best columns)."""
+    import numpy as np
+    if len(fv1) < 3 or len(fv2) < 3:
+        return [float("nan")] * 5
+    x1, y1, d1 = (np.asarray(fv1[k], dtype=np.float64) for k in ("start_x", "start_y", "duration"))
+    x2, y2, d2 = (np.asarray(fv2[k], dtype=np.float64) for k in ("start_x", "start_y", "duration"))
+    w, h = float(screensize[0]), float(screensize[1])
+    return [float(1.0 / (1.0 + abs(x1.mean() - x2.mean()) / w)), float(1.0 / (1.0 + abs(y1.mean() - y2.mean()) / h)),
+            float(min(len(x1), len(x2)) / max(len(x1), len(x2))), float(1.0 / (1.0 + abs(x1[0] - x2[0]) / w + abs(y1[0] - y2[0]) / h)),
+            float(1.0 / (1.0 + abs(d1.sum() - d2.sum())))]
+
+
+def unpack_scanpaths(fix, lens, counts=None):
+    """[sum_len, 3] + per-scanpath lengths (+ per-image counts) -> (list of) lists of the reference's structured arrays"""
+    import numpy as np
+    out, o = [], 0
+    for n in lens:
+        a = np.zeros(int(n), dtype=FV_DTYPE)
+        a["start_x"], a["start_y"], a["duration"] = fix[o:o + n, 0], fix[o:o + n, 1], fix[o:o + n, 2]
+        out.append(a)
+        o += int(n)
+    if counts is None:
+        return out
+    grouped, k = [], 0
+    for c in counts:
+        grouped.append(out[k:k + int(c)])
+        k += int(c)
+    return grouped
+
+
+EVAL_COLUMNS = [("MultiMatch", k) for k in ("vector", "direction", "length", "position", "duration")] + \
+               [("ScanMatch", "w/o duration"), ("ScanMatch", "with duration"), ("VAME", "SED"), ("VAME", "STDE"),
+                ("VAME", "SED_best"), ("VAME", "STDE_best")]
+EVAL_CATEGORIES = ("all", "right_answer", "wrong_answer")
+
+
+def metrics_table(d):
+    """the reference's nested metric dict -> [3 categories, 11 columns] float64"""
+    import numpy as np
+    return np.array([[float(d[c][g][k]) for g, k in EVAL_COLUMNS] for c in EVAL_CATEGORIES], dtype=np.float64)

@@ -176,3 +176,28 @@ def test_run_test_loop_order_and_single_copy():
     for a, r in zip(fv, ref):
         assert np.array_equal(a["start_x"], r["start_x"]) and np.array_equal(a["duration"], r["duration"])
     assert results[0]["X"] == list(fv[0]["start_x"])
+
+
+def test_validation_metrics_match_the_real_reference():
+    """the HIP-scored evaluation_performance_related / human_evaluation against outputs of the REAL reference
+    functions (/root/reference/AiR/utils/evaluation.py:188-359, :11-186; tests/golden/eval_metrics.npz from
+    tests/golden/make_golden_eval.py, deterministic multimatch stand-in on both sides).  ScanMatch (columns 5, 6) and SED (7, 9)
+    enter bit-exact, STDE <= 4 ulp; the reference collects rows in float32, so table entries are held to 1e-6 and the float64
+    per-image score rows to 1e-9."""
+    from helpers import metrics_table, toy_multimatch
+    from test_oracle_golden import _eval_golden
+    from scanpaths_amd.utils.evaluation import evaluation_performance_related, human_evaluation
+    g, (gt, pred, perf, alloc), loader, qids = _eval_golden()
+    cur, cur_std, scores = evaluation_performance_related(gt, pred, perf, alloc, multimatch=toy_multimatch)
+    assert np.abs(metrics_table(cur) - g["epr_mean"]).max() <= 1e-6
+    assert np.abs(metrics_table(cur_std) - g["epr_std"]).max() <= 1e-6
+    assert np.abs(np.array(scores, dtype=np.float64) - g["epr_scores"]).max() <= 1e-9
+    assert np.array_equal(np.array(scores)[:, 5:8], g["epr_scores"][:, 5:8])                # ScanMatch x2 and SED: bit-exact
+    assert np.array_equal(metrics_table(cur)[:, 9], g["epr_mean"][:, 9])                     # SED_best
+    hm, hs, hsc = human_evaluation(loader, multimatch=toy_multimatch)
+    assert np.abs(metrics_table(hm) - g["hum_mean"]).max() <= 1e-6
+    assert np.abs(metrics_table(hs) - g["hum_std"]).max() <= 1e-6
+    good = np.array([hsc[q][True] for q in qids])
+    poor = np.array([hsc[q][False] for q in qids])
+    assert np.abs(good - g["hum_good"]).max() <= 1e-9 and np.abs(poor - g["hum_poor"]).max() <= 1e-9
+    assert np.array_equal(good[:, 5:8], g["hum_good"][:, 5:8]) and np.array_equal(poor[:, 5:8], g["hum_poor"][:, 5:8])

@@ -185,3 +185,25 @@ def test_shard_batch_rejects_empty_shards_and_slices_lists():
         shard_batch({"x": torch.arange(9)}, 3, 4)          # ceil(9/4) = 3 per rank -> rank 3 would be empty
     out = shard_batch({"x": torch.arange(8), "l": list("abcdefgh")}, 1, 4)
     assert out["l"] == ["c", "d"] and out["x"].tolist() == [2, 3]
+
+
+def test_second_backward_before_step_raises_instead_of_drifting():
+    """GradBucketer supports one backward per step; a parameter reporting twice (gradient accumulation, two losses)
+    would accumulate into a bucket whose all-reduce is already in flight -- it must raise, not let the replicas drift."""
+    import pytest
+    from scanpaths_amd.ddp import GradBucketer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        flat = torch.zeros(64)
+        bk = GradBucketer(flat, [0, 16, 32, 48], 64, bucket_bytes=128)      # two buckets of two parameters
+        for i in (3, 2, 1, 0):
+            bk.mark_ready(i)
+        with pytest.raises(RuntimeError, match="twice"):
+            bk.mark_ready(3)
+        bk.finish()
+        for i in (3, 2, 1, 0):                                               # after finish() the next step starts clean
+            bk.mark_ready(i)
+        bk.finish()
+    finally:
+        dist.destroy_process_group()

@@ -127,3 +127,90 @@ def test_ranks_with_different_coco_categories_stay_identical():
     assert res[0][2] == res[1][2]
     heads = sorted({n.split(".")[1] for n in res[0][2] if n.startswith("object_sal_layer.")})
     assert len(heads) == 3, heads            # categories 1, 7, 12 and no other
+
+
+def _rccl_world1(use_dist, port, q):
+    """two train steps; use_dist: torch.distributed over RCCL ("nccl") with a world of ONE and the GradBucketer forced on, so the
+    post-accumulate-grad hook -> bucket -> async ncclAllReduce (RCCL's own stream) -> wait -> sp_sumsq / sp_clip_adam (ctypes
+    launches on torch's current stream) chain runs exactly as it does on N GPUs, with an identity reduction"""
+    import torch.distributed as dist
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.models.scanpath_model import ScanpathModel
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    if use_dist:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    m = ScanpathModel("AiR", convLSTM_length=3, arch="resnet50")
+    fill_module(m, seed=8, family="tame")
+    m = m.to(dev).train()
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-5, clip=12.5, bucket_mb=16, force_bucketer=use_dist)
+    nb = len(opt._bucketer.ranges) if opt._bucketer is not None else 0
+    out = []
+    for it in range(2):
+        b = {k: v.to(dev) for k, v in make_batch("AiR", 2, 240, 320, 3, seed=8 + it).items()}
+        opt.zero_grad()
+        pred = m(b["images"], b["attention_maps"], b["performances"])
+        loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+        loss.backward()
+        tn = opt.step()
+        out.append((float(loss), float(tn)))
+    torch.cuda.synchronize()
+    q.put((use_dist, nb, out, opt.flat_p.detach().cpu().numpy()))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_of_one_bucketed_step_is_bit_identical_to_the_plain_step():
+    """the `nccl` (= RCCL) branch on a HIP device.  A world of one makes every all-reduce the identity, so two
+    training steps through hooks + buckets + RCCL streams must reproduce the non-distributed steps BIT for bit; a missing stream
+    dependency between RCCL's stream and the ctypes-launched kernels (clip+Adam reading a bucket still being reduced, backward
+    writing a bucket already launched) would show up as a difference.  Surface: nn.DataParallel, AiR/train.py:169-170, 190-202."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    res = {}
+    for use_dist in (False, True):
+        p = ctx.Process(target=_rccl_world1, args=(use_dist, _free_port(), q))
+        p.start()
+        r = q.get(timeout=600)
+        p.join(120)
+        assert p.exitcode == 0
+        res[r[0]] = r
+    assert res[True][1] >= 4, res[True][1]                 # 81 M parameters in 16 MB buckets: the bucketer really was active
+    assert res[True][2] == res[False][2], (res[True][2], res[False][2])
+    assert (res[True][3] == res[False][3]).all()
+
+
+def _run_bench(extra, env_extra=None, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True, env=env,
+                          timeout=timeout)
+
+
+def test_bench_gpus_n_launches_n_ranks_or_fails_loudly():
+    """`python bench.py --gpus N` without a launcher around it (the form the driver uses): (i) with fewer devices than ranks it must
+    FAIL, never print an `n_gpus: 1` line; (ii) with the gloo transport (two ranks sharing this box's GPU; RCCL refuses that) the
+    parent starts two ranks through torch.distributed.run and relays rank 0's line with n_gpus = 2 and the aggregate rate."""
+    import json
+    small = ["--task", "osie", "--arch", "resnet18", "--T", "2", "--batch", "2", "--height", "240", "--width", "320", "--steps", "2",
+             "--warmup", "1", "--no-cpu-baseline"]
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2"] + small)
+        assert r.returncode != 0 and '"n_gpus"' not in r.stdout, (r.returncode, r.stdout[-500:])
+        assert "only 1 HIP device" in r.stderr, r.stderr[-500:]
+    r1 = _run_bench(["--gpus", "1"] + small)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = _run_bench(["--gpus", "2"] + small, {"SP_DIST_BACKEND": "gloo"})
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["global_batch"] == 4 and two["scaling"] == "weak"
+    assert abs(two["value"] - 2 * two["value_per_gpu"]) < 1e-2 * two["value"]

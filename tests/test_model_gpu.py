@@ -10,7 +10,7 @@ Two weight families (scanpaths_amd/procedural.py):
                  steps.  Bar, EVERY step, EVERY GEMM back-end:  err(hip32, ref64) <= max(1e-4 * scale, 5 * err(ref32, ref64))
                  (north_star: 1e-4 fp32 on logits) and the argmax fixation index exact at every (b, t) whose fp64 top-2 margin
                  exceeds twice that bar (the reference's own fp32 run cannot resolve less).  test_tame_* below; the per-step
-                 numbers are written to gpurun_out/parity/r02_parity_errors.json (committed copy: profiles/).
+                 numbers are written to gpurun_out/parity/r03_parity_errors.json (committed copy: profiles/).
   * "default" -- round-1 goldens; eval-mode BN does not normalise, the decoder gates saturate and the recurrence is chaotic
                  (the reference's fp32 run leaves its fp64 run by 1 % after ~3 steps).  Bar per step
                  max(1e-4 * scale, NOISE_X * running max of err(ref32, ref64)), compared while the reference's own drift is
@@ -53,12 +53,12 @@ def backend(request):
 
 
 def _record(rows):
-    """append per-step parity numbers to gpurun_out/parity/r02_parity_errors.json (merged back by gpurun; committed under profiles/)"""
+    """append per-step parity numbers to gpurun_out/parity/r03_parity_errors.json (merged back by gpurun; committed under profiles/)"""
     import json
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "parity")
     try:
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "r02_parity_errors.json")
+        path = os.path.join(d, "r03_parity_errors.json")
         old = json.load(open(path)) if os.path.exists(path) else []
         keyf = lambda r: (r["case"], r["backend"], r["key"], r["step"])
         have = {keyf(r): r for r in old}
@@ -400,6 +400,122 @@ def test_air_320x512_matches_oracle():
         err = max_err(v, ref[k])
         print(f"320x512:{k}: hip-oracle64 {err:.2e}  oracle32-oracle64 {floor:.2e}  scale {scale:.2f}")
         assert err <= max(1e-4 * scale, 10 * floor), k
+
+
+BENCH_PATH_COUNTERS = ("gateconv_lstm", "gateconv_lstm_hplanes", "lstm_bwd_split", "bn_fwd_split", "bn_fwd_split_operand", "bn_skip_z",
+                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge")
+
+
+def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
+    """the EXACT kernel path of the bench line -- 40x64 map (P % 256 == 0), ResNet-50, 16 decode steps, the cell
+    as the epilogue of the h-gate conv (sp_gateconv_lstm_f16x2) on 15 of them, BatchNorm passes that emit split operands / leave
+    fp32 tensors unwritten (skip_z, skip_dx), the cell backward writing the split dpre -- held to the fp64 oracle on the tame
+    weight family at 2 images: every output of every step (train AND eval mode), argmax where decisive, the loss and every
+    parameter gradient.  The cost models price each GEMM as if the batch were 32 (F.COST_M_SCALE = 16), and the fusion counters
+    of this run must equal those of a real bs-32 step, so no fallback can stand in for a kernel of the bench path.
+    Reference semantics: AiR/models/baseline_attention.py:37-56, 265-383 (train), 385-493 (eval); AiR/train.py:190-201."""
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.spec import is_buffer
+    from scanpaths_amd.synth import make_batch
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3 or F.THROUGHPUT_MODE:
+        pytest.skip("2xfp16 back-end not active")
+    Hm, Wm, T, NB, seed = 40, 64, 16, 2, 21
+    meta = dict(task="AiR", arch="resnet50", T=T, weight_seed=seed, weight_family="tame")
+
+    # ---- what a real bs-32 training step of the bench configuration runs (counters only) ---------------------------------------
+    F.reset_fusion_counts()
+    m32 = _build(meta, Hm, Wm).train()
+    b32 = {k: v.to(DEV) for k, v in make_batch("AiR", 32, 320, 512, T, seed=seed).items()}
+    pred = m32(b32["images"], b32["attention_maps"], b32["performances"])
+    supervised_loss(pred, b32["scanpaths"], b32["durations"], b32["action_masks"], b32["duration_masks"], 1.0)[0].backward()
+    torch.cuda.synchronize()
+    bench_counts = {k: F.FUSION_COUNTS[k] for k in BENCH_PATH_COUNTERS}
+    del m32, b32, pred
+    torch.cuda.empty_cache()
+    assert bench_counts["gateconv_lstm"] == T - 1 and bench_counts["gateconv_lstm_hplanes"] == T - 1, bench_counts
+    assert bench_counts["lstm_bwd_split"] == T and bench_counts["bn_skip_z"] > 0 and bench_counts["bn_skip_dx"] > 0, bench_counts
+
+    # ---- the oracle on the host: fp64 and fp32, train (loss + gradients) and eval ------------------------------------------------
+    b = make_batch("AiR", NB, 320, 512, T, seed=seed)
+    g, grads, losses = {}, {}, {}
+    for dt, tag in ((torch.float64, "ref64/"), (torch.float32, "ref32/")):
+        sd = oracle_state("AiR", "resnet50", seed, Hm, Wm, dtype=dt, family="tame")
+        bd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in b.items()}
+        with torch.no_grad():
+            ev = O.forward(sd, "AiR", bd["images"], bd["attention_maps"], training=False, T=T)
+        for k, v in ev.items():
+            g[tag + "eval/" + k] = v.double().numpy()
+        for k, v in sd.items():
+            if v.is_floating_point() and not is_buffer(k):
+                v.requires_grad_(True)
+        tr = O.forward(sd, "AiR", bd["images"], bd["attention_maps"], bd["performances"], training=True, T=T)
+        loss, _, _ = O.supervised_loss(tr, bd)
+        loss.backward()
+        for k, v in tr.items():
+            g[tag + "train/" + k] = v.detach().double().numpy()
+        grads[tag] = {k: v.grad.double() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+        losses[tag] = float(loss.detach())
+        del sd, tr, ev, loss
+
+    # ---- the HIP path at 2 images with the bs-32 cost-model decisions --------------------------------------------------------------
+    monkeypatch.setattr(F, "COST_M_SCALE", 32.0 / NB)
+    report, rows = [], []
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    model = _build(meta, Hm, Wm).train()
+    F.reset_fusion_counts()
+    pred = model(bd["images"], bd["attention_maps"], bd["performances"])
+    loss, _, _ = supervised_loss(pred, bd["scanpaths"], bd["durations"], bd["action_masks"], bd["duration_masks"], 1.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    got_counts = {k: F.FUSION_COUNTS[k] for k in BENCH_PATH_COUNTERS}
+    assert got_counts == bench_counts, (got_counts, bench_counts)          # the SAME kernels as the bs-32 step, layer for layer
+    nargmax = ntot = 0
+    for k, v in pred.items():
+        bars = _check("bench_path_320x512_train_T16", "train/" + k, v, g, report, T, None, noise_x=TAME_X, rows=rows)
+        assert len(bars) == T, (k, len(bars))
+        if k == "all_actions_prob":
+            n, tot = _check_argmax(v, g["ref64/train/" + k], bars)
+            nargmax, ntot = nargmax + n, ntot + tot
+    l64, l32 = losses["ref64/"], losses["ref32/"]
+    assert abs(float(loss) - l64) <= max(1e-4, 10 * abs(l32 - l64)), (float(loss), l64, l32)
+    g64, g32 = grads["ref64/"], grads["ref32/"]
+    top = max(float(v.norm()) for v in g64.values())
+    worst, worst_name = 0.0, ""
+    for k, p in model.named_parameters():
+        if k not in g64:
+            continue
+        got = p.grad.detach().cpu().double() if p.grad is not None else torch.zeros_like(g64[k])
+        e, floor = float((got - g64[k]).norm()), float((g32[k] - g64[k]).norm())
+        assert e <= max(1e-4 * top, 10 * floor), (k, e, floor, float(g64[k].norm()))
+        if floor > 1e-12 * top and e / floor > worst:
+            worst, worst_name = e / floor, k
+    rows.append({"case": "bench_path_320x512_train_T16", "backend": "f16x2", "key": "loss", "step": -1, "err": abs(float(loss) - l64),
+                 "ref32_noise": abs(l32 - l64), "scale": abs(l64), "bar": max(1e-4, 10 * abs(l32 - l64)),
+                 "worst_grad_err_over_oracle32": worst, "worst_grad_param": worst_name, "fusion_counts": got_counts})
+    del pred, loss
+    # eval mode (probabilities; both heads)
+    model.eval()
+    F.reset_fusion_counts()
+    with torch.no_grad():
+        pe = model(bd["images"], bd["attention_maps"])
+    assert F.FUSION_COUNTS["gateconv_lstm"] == T - 1
+    for k, v in pe.items():
+        bars = _check("bench_path_320x512_eval_T16", "eval/" + k, v, g, report, T, None, noise_x=TAME_X, rows=rows)
+        assert len(bars) == T, (k, len(bars))
+        if k.endswith("all_actions_prob"):
+            n, tot = _check_argmax(v, g["ref64/eval/" + k], bars)
+            nargmax, ntot = nargmax + n, ntot + tot
+    _record(rows)
+    worst_row = max((r for r in rows if r["key"] != "loss"), key=lambda r: r["err"] / r["bar"])
+    print(f"bench path 320x512 T=16 (tame, {NB} images, bs-32 kernel decisions): {len(rows) - 1} (output, step) pairs; worst err/bar "
+          f"{worst_row['err'] / worst_row['bar']:.2f} ({worst_row['key']} t={worst_row['step']}: err {worst_row['err']:.2e}, oracle32 noise "
+          f"{worst_row['ref32_noise']:.2e}, scale {worst_row['scale']:.2e}); loss oracle64 {l64:.6f}; "
+          f"worst grad err / oracle32 err {worst:.2f} ({worst_name}); argmax exact on {nargmax}/{ntot} decisive; counters {got_counts}")
+    bad = [r for r in rows if r.get("failed")]
+    assert not bad, bad[:3]
+    assert nargmax >= 0.3 * ntot, (nargmax, ntot)
 
 
 def test_state_dict_roundtrip_and_no_cpu_path():

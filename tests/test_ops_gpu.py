@@ -759,7 +759,7 @@ def test_hgate_conv_at_benchmark_size_vs_fp64(path, monkeypatch):
     try:
         d = os.path.join(root, "gpurun_out", "parity")
         os.makedirs(d, exist_ok=True)
-        fn = os.path.join(d, "r02_hgate_fullsize_errors.json")
+        fn = os.path.join(d, "r03_hgate_fullsize_errors.json")
         old = json.load(open(fn)) if os.path.exists(fn) else {}
         old[path] = {k: {"rms_rel": v[0], "max_rel": v[1]} for k, v in res.items()}
         json.dump(old, open(fn, "w"), indent=1)
@@ -767,3 +767,78 @@ def test_hgate_conv_at_benchmark_size_vs_fp64(path, monkeypatch):
         pass
     for k, bar in (("fwd", 1e-6), ("dgrad", 1e-6), ("wgrad", 2e-6)):
         assert res[k][0] <= bar and res[k][1] <= 8 * bar, (path, k, res[k])
+
+
+def test_fused_gateconv_lstm_at_benchmark_size_vs_fp64():
+    """The kernel 15 of the 16 forward h-gate launches of the bench line run -- the ConvLSTM cell as the epilogue of the h-gate conv
+    (sp_gateconv_lstm_f16x2; M = 81 920 pixels, C = 512, N = 2048 gate columns, K = 4608) -- AT ITS SIZE against a row-subsampled
+    fp64 evaluation of AiR/models/baseline_attention.py:37-56 in the hoisted form of scanpath_model.py: gates, c' = f c + i g,
+    h' = o c', and h's split operand written by the same epilogue."""
+    import json
+    import os
+    from scanpaths_amd import functional as F
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3 or F.THROUGHPUT_MODE:
+        pytest.skip("2xfp16 back-end not active")
+    B, Hm, Wm, C, KP, S = 32, 40, 64, 512, 20, 2
+    P = Hm * Wm
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(15)
+    h = (torch.randn(B, Hm, Wm, C, generator=g) * torch.rand(B, Hm, Wm, C, generator=g)).float()        # h = o * c shaped
+    c = (torch.randn(B, Hm, Wm, C, generator=g) * 1.5).float()
+    xg = torch.randn(B, Hm, Wm, 4 * C, generator=g).float()
+    w = (torch.randn(4 * C, 3, 3, C, generator=g) / math.sqrt(9 * C)).float()                            # physical [Co][KH][KW][Ci]
+    spcol = torch.rand(B, P, KP, generator=g).float()
+    spcol[..., 9 * S:] = 0
+    wc = (torch.randn(B, 3 * C, KP, generator=g) * 0.1).float()
+    hg, cg = h.to(dev), c.to(dev)
+    cg._sp_cbound = float(c.abs().max()) + 0.5                                                           # -> the epilogue writes h's planes
+    wg = w.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+    assert F.gateconv_lstm_fusable(hg, wg, spcol.to(dev))
+    F.reset_fusion_counts()
+    hn, cn = F.gateconv_lstm(hg, wg, xg.to(dev), cg, spcol.to(dev), wc.to(dev), {})
+    torch.cuda.synchronize()
+    assert F.FUSION_COUNTS["gateconv_lstm"] == 1 and F.FUSION_COUNTS["gateconv_lstm_hplanes"] == 1
+    gates = hn.grad_fn.saved_tensors[0]
+    assert gates.shape == (B, Hm, Wm, 4 * C)
+    op = hn._sp_cache["f16x2"]
+    bound = float(op.scale[1])
+    assert float(hn.abs().max()) <= bound
+    assert float((_decode_split(op, hn.shape) - hn.detach()).abs().max()) <= 2.0 ** -21 * bound
+    h_c, c_c, g_c = hn.detach().cpu(), cn.detach().cpu(), gates.cpu()
+
+    rs = np.random.Generator(np.random.PCG64(19))
+    pix = [(int(rs.integers(B)), int(rs.integers(Hm)), int(rs.integers(Wm))) for _ in range(120)]
+    pix += [(0, 0, 0), (B - 1, Hm - 1, Wm - 1), (5, 0, Wm - 1), (9, Hm - 1, 0), (17, 3, 63), (17, 4, 0)]   # padding corners, tile seams
+    hd, wd = h.double(), w.double()
+    ref_g, ref_c, ref_h = [], [], []
+    for (b, y, x) in pix:
+        win = torch.zeros(3, 3, C, dtype=torch.float64)
+        for ky in range(3):
+            for kx in range(3):
+                iy, ix = y + ky - 1, x + kx - 1
+                if 0 <= iy < Hm and 0 <= ix < Wm:
+                    win[ky, kx] = hd[b, iy, ix]
+        pre = xg[b, y, x].double() + torch.einsum("yxc,oyxc->o", win, wd)
+        pre[:3 * C] += wc[b].double() @ spcol[b, y * Wm + x].double()
+        i, f, o, gg = pre[:C].sigmoid(), pre[C:2 * C].sigmoid(), pre[2 * C:3 * C].sigmoid(), pre[3 * C:].tanh()
+        cc = f * c[b, y, x].double() + i * gg
+        ref_g.append(torch.cat([i, f, o, gg]))
+        ref_c.append(cc)
+        ref_h.append(o * cc)
+    res = {}
+    for name, got, ref in (("gates", torch.stack([g_c[p] for p in pix]), torch.stack(ref_g)),
+                           ("c", torch.stack([c_c[p] for p in pix]), torch.stack(ref_c)),
+                           ("h", torch.stack([h_c[p] for p in pix]), torch.stack(ref_h))):
+        d = got.double() - ref
+        res[name] = (d.pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item(), d.abs().max().item() / ref.pow(2).mean().sqrt().item())
+    print("fused gate conv + cell M=81920 C=512: " + "  ".join(f"{k}: rms {v[0]:.2e} max {v[1]:.2e}" for k, v in res.items()))
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        d = os.path.join(root, "gpurun_out", "parity")
+        os.makedirs(d, exist_ok=True)
+        json.dump({k: {"rms_rel": v[0], "max_rel": v[1]} for k, v in res.items()},
+                  open(os.path.join(d, "r03_fused_cell_fullsize_errors.json"), "w"), indent=1)
+    except OSError:
+        pass
+    for k in res:
+        assert res[k][0] <= 1e-6 and res[k][1] <= 8e-6, (k, res[k])
