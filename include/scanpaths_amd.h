@@ -419,11 +419,16 @@ int sp_beam_search(const float* probs, int B, int T, int A, int min_length, int 
 /* Training targets of one batch from ragged fixation lists (AiR/dataset/dataset.py:111-147 with blur_sigma = None;
  * collate_func :168-211 stacks them): sample b owns fixations start[b] .. start[b]+count[b]-1 of X / Y (pixels of the
  * origin_w x origin_h image) / T_start / T_end (ms).  target [B][T][1 + map_h*map_w] soft one-hot (index 0 = terminate),
- * duration [B][T] seconds, action_mask, duration_mask [B][T].  f64_div: evaluate the cell index in float64 (numpy 1.x) instead
- * of float32 (numpy >= 2). */
+ * duration [B][T] seconds, action_mask, duration_mask [B][T].  f64_div: evaluate the cell index and the ms -> s division in
+ * float64 (numpy 1.x value-based casting: the reference's pinned numpy==1.19.2) instead of float32 (numpy >= 2). */
 int sp_collate_targets(const float* X, const float* Y, const float* T_start, const float* T_end, const int64_t* start,
                        const int* count, const double* origin_w, const double* origin_h, int B, int T, int map_h, int map_w,
                        int f64_div, float* target, float* duration, float* action_mask, float* duration_mask, void* stream);
+/* blur_sigma targets (AiR/dataset/dataset.py:144-147, OSIE/dataset/dataset.py:98-101, COCO_Search18/dataset/dataset.py:122-125):
+ * in place on target [rows = B*T][1 + map_h*map_w] after sp_collate_targets -- every row whose target is a map cell becomes
+ * scipy.ndimage.gaussian_filter(one-hot map, sigma) (mode reflect, truncate 4) divided by its sum; terminate rows are untouched.
+ * float32 results agree with scipy to ~1 ulp (the normaliser is summed in a different order). */
+int sp_blur_targets(float* target, int rows, int map_h, int map_w, double sigma, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * clip_grad_norm_ + Adam (L2 folded into the gradient) over one flat fp32 buffer.  AiR/train.py:116-117,200-202.

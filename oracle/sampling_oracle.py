@@ -15,9 +15,12 @@ import math
 import numpy as np
 
 
-def collate_targets(fixations, max_length, action_map, f64_div=False):
+def collate_targets(fixations, max_length, action_map, f64_div=False, blur_sigma=None):
     """fixations: list of dicts with X, Y, T_start, T_end (lists), height, width.  Returns target_scanpath [B,T,1+h*w],
-    duration, action_mask, duration_mask [B,T] float32 -- AiR/dataset/dataset.py:111-147."""
+    duration, action_mask, duration_mask [B,T] float32 -- AiR/dataset/dataset.py:111-147.  blur_sigma: :144-146 with scipy's own
+    gaussian_filter, as the reference calls it.  f64_div: numpy 1.x semantics (PARITY: tests/golden/collate_f64.npz holds the real
+    reference's outputs under float64 division, see tests/golden/make_golden_dataset.py)."""
+    import scipy.ndimage as filters
     H, W = action_map
     outs = [[], [], [], []]
     for fixation in fixations:
@@ -42,7 +45,7 @@ def collate_targets(fixations, max_length, action_map, f64_div=False):
             else:            # numpy >= 2 (NEP 50): the python float is weak -> float32 division
                 pos_x_discrete[index] = (pos_x[index] / np.float32(downscale_x)).astype(np.int32)
                 pos_y_discrete[index] = (pos_y[index] / np.float32(downscale_y)).astype(np.int32)
-            duration[index] = duration_raw[index] / np.float32(1000.0)
+            duration[index] = np.float64(duration_raw[index]) / 1000.0 if f64_div else duration_raw[index] / np.float32(1000.0)
             action_mask[index] = 1
             duration_mask[index] = 1
         if action_mask.sum() <= max_length - 1:                                       # :135-136
@@ -52,6 +55,9 @@ def collate_targets(fixations, max_length, action_map, f64_div=False):
                 target_scanpath[index, 0] = 1
             else:
                 scanpath[index, pos_y_discrete[index], pos_x_discrete[index]] = 1
+                if blur_sigma:                                                        # :144-146
+                    scanpath[index] = filters.gaussian_filter(scanpath[index], blur_sigma)
+                    scanpath[index] /= scanpath[index].sum()
                 target_scanpath[index, 1:] = scanpath[index].reshape(-1)
         for o, v in zip(outs, (target_scanpath, duration, action_mask, duration_mask)):
             o.append(v)

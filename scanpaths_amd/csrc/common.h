@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 // process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default
-enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_AMAX_RESET = 4, SP_TUNE_S2 = 5, SP_TUNE_LSTM_EPI = 6, SP_TUNE_COUNT = 7 };
+enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_AMAX_RESET = 4, SP_TUNE_S2 = 5, SP_TUNE_LSTM_EPI = 6, SP_TUNE_H2_CHUNK = 7, SP_TUNE_COUNT = 8 };
 extern int sp_tuning_values[SP_TUNE_COUNT];
 static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }
 

@@ -70,6 +70,7 @@ struct H2Args {
     // of bn_pool.hip's first reduction stage -- the BatchNorm behind this conv starts at its second stage
     double* st_partial;
     float* st_mm;
+    int chunk_kt;           // K-tiles per chunk of the two-level accumulation (power of two; HCHUNK_KT)
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
@@ -225,8 +226,12 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const uint32_t koffB = (uint32_t)(ld_tap * p.ncblk + ld_cblk) * 128u;
             const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
             const uint32_t zrelB = p.w_bytes - koffB;
+            // DBG 10 (timing proxy of a 128x64 wave tile in a 256x256 block: half the weight-side LDS traffic per MFMA): weight pieces
+            // and weight fragments only every second K-tile (wrong results)
+            if (DBG != 10 || (ld_tap & 1) == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
+                for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
+            }
             ++ld_tap;
             if (++ld_kx == p.KW) {
                 ld_kx = 0;
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
-    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2 && DBG != 9, do_lds = DBG != 3 && DBG != 9;      // DBG 9: loads only
+    constexpr bool do_load = DBG != 1 && DBG != 3 && DBG != 11, do_mma = DBG != 2 && DBG != 9, do_lds = DBG != 3 && DBG != 9;      // DBG 9: loads only
     constexpr bool do_bar = DBG != 3;
     int issued = 0;
     if (do_load)
@@ -404,7 +409,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 #pragma unroll
                     for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
                         af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[0][pl] + (2 * kk + i) * 16 * 128);
-                        bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[0][pl] + (2 * kk + i) * 16 * 128);
+                        if (DBG != 10 || (kt_ & 1) == 0)
+                            bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[0][pl] + (2 * kk + i) * 16 * 128);
                     }
         } else {
 #pragma unroll
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     };
     auto fold = [&](int kt_) {           // two-level accumulation: fold the chunk accumulator into the total every 256 k
         if constexpr (M16) {
-            if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
+            if (((kt_ + 1) & (p.chunk_kt - 1)) == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -482,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     auto wait_barrier = [&](int kt_) {
         // tile kt+1 must have landed: everything but the one younger tile (if it was issued)
         if (DBG == 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // the younger tile has 2 or 6 pieces: never wait for fewer than needed
+        else if (DBG == 10) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // 4 or 6 pieces
         else if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1844,6 +1851,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (((uintptr_t)Xs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
     H2Args a{};
+    a.chunk_kt = sp_tuning_get(SP_TUNE_H2_CHUNK, HCHUNK_KT);
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
     a.sx = x_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * d->Ho * d->Wo;
@@ -1888,6 +1896,8 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (dbg == 7) return f ? launch_h2<0, 2, 3, 3, true>(a, st) : launch_h2<1, 2, 3, 3, true>(a, st);      // no MFMAs
     if (dbg == 8) return f ? launch_h2<0, 3, 3, 3, true>(a, st) : launch_h2<1, 3, 3, 3, true>(a, st);      // MFMAs only
     if (dbg == 9) return f ? launch_h2<0, 9, 3, 3, true>(a, st) : launch_h2<1, 9, 3, 3, true>(a, st);      // LDS-DMA loads only
+    if (dbg == 10) return f ? launch_h2<0, 10, 5, 3, true, true>(a, st) : launch_h2<1, 10, 5, 3, true, true>(a, st);  // half the weight-side LDS traffic
+    if (dbg == 12) return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);    // default schedule (A/B reference in one process)
     if (nprod == 1)      // throughput mode: load-bound, the ping-pong schedule
         return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
     int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
@@ -1952,6 +1962,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (P != d->Ho * d->Wo || P % HBM || KP < 1 || KP > 32) return SP_EINVAL;
     if (((uintptr_t)Hs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     H2Args a{};
+    a.chunk_kt = sp_tuning_get(SP_TUNE_H2_CHUNK, HCHUNK_KT);
     a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
     a.sx = h_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * P;

@@ -247,7 +247,8 @@ __global__ void collate_kernel(const float* X, const float* Y, const float* Ts, 
             px = (int)(X[s] / (float)dsx);
             py = (int)(Y[s] / (float)dsy);
         }
-        d = (Te[s] - Ts[s]) / 1000.0f;
+        // numpy 1.x (the reference's pinned 1.19.2): float32 scalar / python float is evaluated in float64, then stored as float32
+        d = f64_div ? (float)((double)(Te[s] - Ts[s]) / 1000.0) : (Te[s] - Ts[s]) / 1000.0f;
         am = 1.f;
         dm = 1.f;
     } else if (t == n) {
@@ -270,6 +271,87 @@ extern "C" int sp_beam_search(const float* probs, int B, int T, int A, int min_l
     if (!probs || !actions || !scores) return SP_ENULL;
     if (B < 1 || T < 1 || T > 64 || A < 2 || A > 32767 || K < 1 || K > BEAM_MAX) return SP_EINVAL;
     hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, T, A, min_length, K, actions, scores);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+// blur_sigma targets (AiR/dataset/dataset.py:144-147): every non-terminate step's one-hot map is replaced by
+//   scipy.ndimage.gaussian_filter(map, sigma) / sum   (mode 'reflect', truncate 4.0: radius = int(4 sigma + 0.5)).
+// The filter of a delta is separable: pass 1 along y (double sum, rounded to float32 as scipy stores the intermediate), pass 2
+// along x (double sum of w[j] * float32 intermediate, rounded to float32), then the division by the float32 total.  One block
+// per (sample, step); the hot cell is found by scanning the row.  scipy sums the normaliser pairwise in float32, here it is a
+// double sum rounded once: agreement to ~1 ulp of float32, not bitwise (tests hold 2e-7 relative).
+constexpr int BLUR_MAXR = 64;
+__global__ __launch_bounds__(256) void blur_targets_kernel(float* target, int A, int map_h, int map_w, double sigma) {
+    __shared__ double w[2 * BLUR_MAXR + 1];
+    __shared__ float col[1024], rowv[1024];
+    __shared__ int hot;
+    __shared__ double red[256];
+    float* row = target + (int64_t)blockIdx.x * A;
+    const int t = threadIdx.x;
+    if (t == 0) hot = -1;
+    __syncthreads();
+    for (int i = 1 + t; i < A; i += 256)
+        if (row[i] == 1.f) hot = i - 1;
+    __syncthreads();
+    if (hot < 0) return;                                  // terminate target or a fixation outside the map: nothing to blur
+    const int y0 = hot / map_w, x0 = hot % map_w;
+    const int r = (int)(4.0 * sigma + 0.5);
+    if (t == 0) {
+        double sum = 0.0;
+        for (int j = 0; j <= 2 * r; ++j) {
+            const double x = (double)(j - r);
+            w[j] = exp(-0.5 / (sigma * sigma) * x * x);
+            sum += w[j];
+        }
+        for (int j = 0; j <= 2 * r; ++j) w[j] /= sum;
+    }
+    __syncthreads();
+    auto reflect = [](int i, int n) {                     // scipy 'reflect': (d c b a | a b c d | d c b a)
+        const int p2 = 2 * n;
+        i = ((i % p2) + p2) % p2;
+        return i < n ? i : p2 - 1 - i;
+    };
+    for (int y = t; y < map_h; y += 256) {
+        double s = 0.0;
+        for (int j = 0; j <= 2 * r; ++j)
+            if (reflect(y + j - r, map_h) == y0) s += w[j];
+        col[y] = (float)s;
+    }
+    for (int x = t; x < map_w; x += 256) {
+        double s = 0.0;
+        for (int j = 0; j <= 2 * r; ++j)
+            if (reflect(x + j - r, map_w) == x0) s += w[j];
+        rowv[x] = (float)s;                               // only used as the set of matching weights below
+    }
+    __syncthreads();
+    // pass 2: out[y][x] = float( sum_{j matching} w[j] * (double)col[y] ); with a single matching j this is float(w[j] * col[y])
+    double part = 0.0;
+    for (int i = t; i < map_h * map_w; i += 256) {
+        const int y = i / map_w, x = i % map_w;
+        double s = 0.0;
+        for (int j = 0; j <= 2 * r; ++j)
+            if (reflect(x + j - r, map_w) == x0) s += w[j] * (double)col[y];
+        const float v = (float)s;
+        row[1 + i] = v;
+        part += (double)v;
+    }
+    red[t] = part;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    const float total = (float)red[0];
+    for (int i = t; i < map_h * map_w; i += 256) row[1 + i] = row[1 + i] / total;
+}
+
+// in-place on target [rows][1 + map_h*map_w] (rows = B*T), after sp_collate_targets
+extern "C" int sp_blur_targets(float* target, int rows, int map_h, int map_w, double sigma, void* stream) {
+    if (!target) return SP_ENULL;
+    if (rows <= 0 || map_h < 1 || map_w < 1 || map_h > 1024 || map_w > 1024 || !(sigma > 0.0) || (int)(4.0 * sigma + 0.5) > BLUR_MAXR)
+        return SP_EINVAL;
+    hipLaunchKernelGGL(blur_targets_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, target, 1 + map_h * map_w, map_h, map_w, sigma);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -122,6 +122,7 @@ SIGNATURES = {
     "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sp_beam_search": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sp_collate_targets": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "sp_blur_targets": (_I, [_P, _I, _I, _I, C.c_double, _P]),
     "sp_scanpath_loss_workspace": (_L, [_I, _I]),
     "sp_scanpath_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "sp_log_action": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
@@ -156,7 +157,8 @@ def lib() -> C.CDLL:
         # their reset node only while a stream is being captured (graph replays re-use the slot)
         if not os.environ.get("SP_ALWAYS_RESET_AMAX"):
             check(_lib.sp_set_tuning(b"amax_reset", 1), "sp_set_tuning")
-        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi"), ("SP_S2", b"s2")):      # A/B timing / profiling only
+        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi"), ("SP_S2", b"s2"),
+                          ("SP_H2_CHUNK", b"h2_chunk")):      # A/B timing / profiling only
             if os.environ.get(env):
                 check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib

@@ -183,3 +183,58 @@ def test_init_weights_match_reference_distributions():
                 assert abs(rstd - std) <= tol_std, ("reference", k, rstd, std)
                 assert abs(float(v.mean())) <= tol_mean and abs(rmean) <= tol_mean, k
             assert float(v.abs().max()) <= 7.0 * std and rmax <= 7.0 * std, k
+
+
+def _json_field(g, k):
+    import json
+    return json.loads(bytes(g[k]).decode())
+
+
+def test_dataset_host_side_matches_reference_datasets():
+    """SURVEY §8 f4 remainder, host-side parts, against outputs of the REAL reference datasets (tests/golden/dataset_variants.npz,
+    collate_f64.npz from tests/golden/make_golden_dataset.py): the oracle's numpy-1.x (float64 division) and blur_sigma variants;
+    AiR_evaluation's per-question grouping / fixation vectors / performances (AiR/dataset/dataset.py:236-241, 258-343); the COCO
+    detector-box attention map (COCO_Search18/dataset/dataset.py:150-160) and the OSIE / COCO record adapters."""
+    import numpy as np
+    import torch
+    from helpers import GOLDEN
+    from oracle import sampling_oracle as SO
+    from scanpaths_amd import dataset as DS
+    g = np.load(os.path.join(GOLDEN, "dataset_variants.npz"))
+    g64 = np.load(os.path.join(GOLDEN, "collate_f64.npz"))
+    recs = _json_field(g64, "records")
+    keys = ("scanpaths", "durations", "action_masks", "duration_masks")
+    for k, w in zip(keys, SO.collate_targets(recs, 16, (30, 40), f64_div=True)):
+        assert np.array_equal(w, g64[k]), k
+    for k, w in zip(keys, SO.collate_targets(recs, 16, (30, 40), f64_div=True, blur_sigma=1)):
+        assert np.array_equal(w, g["blur_" + k]), k
+    # evaluation grouping
+    ev = _json_field(g, "eval_records")
+    groups = DS.group_by_question(ev, resize=(240, 320))
+    assert [s["question_id"] for s in groups] == _json_field(g, "eval_qids")
+    assert [s["img_name"] for s in groups] == _json_field(g, "eval_imgs")
+    assert [len(s["fix_vectors"]) for s in groups] == list(g["eval_count"])
+    fvs = [f for s in groups for f in s["fix_vectors"]]
+    assert [len(f) for f in fvs] == list(g["eval_len"])
+    got = np.concatenate([np.stack([f["start_x"], f["start_y"], f["duration"]], 1) for f in fvs], 0)
+    assert np.array_equal(got, g["eval_fix"])                                    # float32 divisions stored as f8: bit-exact
+    assert [int(p) for s in groups for p in s["performances"]] == list(g["eval_perf"])
+    batch = DS.collate_evaluation([dict(s, image=torch.zeros(3, 4, 4), attention_map=np.zeros((1, 30, 40), np.float32)) for s in groups],
+                                  device=torch.device("cpu"))
+    assert set(batch) == {"images", "fix_vectors", "attention_maps", "img_names", "performances", "question_ids"}
+    # COCO: detector boxes -> attention map (identity resize in the golden run), record adapter incl. the clamp
+    crecs, dets = _json_field(g, "coco_records"), _json_field(g, "coco_detector")
+    idx = DS.index_detections(dets, 0.6)
+    maps = np.stack([DS.detector_box_map(idx.get(r["name"].split(".")[0], []), r["task"], (30, 40))[None] for r in crecs])
+    # (skimage's resize -- and its identity stand-in of the golden run -- returns float64: the reference normalises in float64)
+    norm = DS.normalise_attention(torch.from_numpy(maps.astype(np.float64)), eps=1e-7).numpy()
+    assert np.array_equal(norm, g["coco_attention_maps"])
+    assert float(norm[3].max()) == 0.0 and float(norm[0].max()) > 0.99          # below-threshold detections are ignored
+    assert [DS.COCO_OBJECT_NAMES.index(r["task"]) for r in crecs] == list(g["coco_tasks"])
+    ad = DS._with_durations(crecs, (320, 512), clamp_to=(40 * (512 / 40), 30 * (320 / 30)))
+    for k, w in zip(keys, SO.collate_targets(ad, 16, (30, 40), f64_div=True)):
+        assert np.array_equal(w, g["coco_" + k]), k
+    orecs = _json_field(g, "osie_records")
+    for sigma, tag in ((None, "osie_"), (2, "osie_blur_")):
+        for k, w in zip(keys, SO.collate_targets(DS._with_durations(orecs, (600, 800)), 16, (30, 40), f64_div=True, blur_sigma=sigma)):
+            assert np.array_equal(w, g[tag + k]), (tag, k)

@@ -201,3 +201,45 @@ def test_validation_metrics_match_the_real_reference():
     poor = np.array([hsc[q][False] for q in qids])
     assert np.abs(good - g["hum_good"]).max() <= 1e-9 and np.abs(poor - g["hum_poor"]).max() <= 1e-9
     assert np.array_equal(good[:, 5:8], g["hum_good"][:, 5:8]) and np.array_equal(poor[:, 5:8], g["hum_poor"][:, 5:8])
+
+
+def test_dataset_variants_match_reference_datasets():
+    """SURVEY §8 f4 remainder on the device, against outputs of the REAL reference datasets (tests/golden/make_golden_dataset.py):
+    numpy-1.x division semantics (the default; AiR/dataset/dataset.py:125-134), blur_sigma targets (:144-146; scipy agreement to
+    float32 rounding, the normaliser is summed in another order), OSIE (OSIE/dataset/dataset.py:59-115, incl. blur_sigma = 2) and
+    COCO-Search18 targets (COCO_Search18/dataset/dataset.py:88-128, out-of-frame fixations clamped)."""
+    from scanpaths_amd import dataset as DS
+    g = np.load(os.path.join(GOLDEN, "dataset_variants.npz"))
+    g64 = np.load(os.path.join(GOLDEN, "collate_f64.npz"))
+    jf = lambda arr: json.loads(bytes(arr).decode())
+    keys = ("scanpaths", "durations", "action_masks", "duration_masks")
+    recs = jf(g64["records"])
+    out = DS.collate_targets(recs, 16, (30, 40))                         # default = the reference's pinned numpy semantics
+    for k in keys:
+        assert np.array_equal(out[k].cpu().numpy(), g64[k]), k
+
+    def close(a, b, what):
+        a = a.cpu().numpy()
+        assert np.array_equal(a == 0, b == 0), what                       # same support (the filter's radius and reflection)
+        assert np.abs(a - b).max() <= 2e-7 * np.abs(b).max(), (what, np.abs(a - b).max())
+        assert np.abs(a.sum(-1) - 1).max() <= 1e-6, what                   # every target row still sums to one
+
+    out = DS.collate_targets(recs, 16, (30, 40), blur_sigma=1)
+    close(out["scanpaths"], g["blur_scanpaths"], "AiR blur")
+    orecs, crecs = jf(g["osie_records"]), jf(g["coco_records"])
+    out = DS.collate_targets_osie(orecs, 16, (30, 40))
+    for k in keys:
+        assert np.array_equal(out[k].cpu().numpy(), g["osie_" + k]), k
+    close(DS.collate_targets_osie(orecs, 16, (30, 40), blur_sigma=2)["scanpaths"], g["osie_blur_scanpaths"], "OSIE blur")
+    out = DS.collate_targets_coco(crecs, 16, (30, 40))
+    for k in keys:
+        assert np.array_equal(out[k].cpu().numpy(), g["coco_" + k]), k
+    # the benchmark's map size: blur against the oracle (scipy, as the reference calls it)
+    from oracle import sampling_oracle as SO
+    rng = np.random.Generator(np.random.PCG64(4))
+    recs2 = [{"X": list(rng.uniform(0, 511.9, 9)), "Y": list(rng.uniform(0, 319.9, 9)), "T_start": list(np.arange(9) * 100.0),
+              "T_end": list(np.arange(9) * 100.0 + 60.0), "height": 320, "width": 512} for _ in range(4)]
+    recs2[0]["X"][0], recs2[0]["Y"][0] = 0.0, 0.0                          # corner cells: both axes reflect
+    recs2[1]["X"][0], recs2[1]["Y"][0] = 511.9, 319.9
+    want = SO.collate_targets(recs2, 16, (40, 64), f64_div=True, blur_sigma=1.5)[0]
+    close(DS.collate_targets(recs2, 16, (40, 64), blur_sigma=1.5)["scanpaths"], want, "40x64 blur")
