@@ -31,11 +31,16 @@ extern "C" {
 #define SP_ABI_VERSION 1
 int sp_abi_version(void);
 
-/* Kernel-schedule selectors for A/B timing (tools/bench_h2_variants.py) -- the ONE piece of process-wide state in the library.
- * A selector picks between schedules of the same kernel that compute bit-identical results (same MFMA order per accumulator);
- * it never changes numerics.  Names: "h2_variant", "hw_variant" (csrc/conv_f16x2.hip).  value < 0 restores the built-in default.
- * Returns SP_EINVAL for an unknown name.  Not thread-safe against concurrent launches (set it before launching). */
+/* The ONE piece of process-wide state in the product library: sp_set_tuning("amax_reset", 1) tells the launchers that the caller
+ * hands in ZEROED, single-use max|.| slots, so the one-thread reset kernel in front of a producer is only added while the stream is
+ * being captured into a HIP graph (a replay re-uses the slot).  Default 0: always reset.  Set it once before launching; every other
+ * name returns SP_EINVAL.
+ * Kernel-schedule variants and wrong-result timing modes ("h2_variant", "hw_variant", "h2_dbg", "hw_dbg", "b3_dbg", "s2", ...) are
+ * compiled ONLY into libscanpaths_amd_timing.so (make -C scanpaths_amd/csrc timing; -DSP_TIMING_VARIANTS), which tools/ load for
+ * A/B timing; the product library reads no environment variable and cannot be switched into a mode that changes results. */
 int sp_set_tuning(const char* name, int value);
+/* 1 in the timing build, 0 in the product library. */
+int sp_timing_build(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.

@@ -13,10 +13,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
-// process-wide schedule selectors (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default
-enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_AMAX_RESET = 4, SP_TUNE_S2 = 5, SP_TUNE_LSTM_EPI = 6, SP_TUNE_H2_CHUNK = 7, SP_TUNE_COUNT = 8 };
+// Process-wide switches (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default.  The PRODUCT library
+// (libscanpaths_amd.so) knows exactly one: "amax_reset".  Every other selector -- kernel schedule variants, wrong-result timing
+// modes (no loads / no MFMAs / ...), experimental kernels -- exists only in the TIMING build (-DSP_TIMING_VARIANTS ->
+// libscanpaths_amd_timing.so, `make timing`, loaded by tools/ through SP_LIBRARY=timing); the product build compiles the default
+// schedule plus one fallback per kernel and reads no environment variable.
+enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_AMAX_RESET = 4, SP_TUNE_S2 = 5,
+       SP_TUNE_LSTM_EPI = 6, SP_TUNE_H2_CHUNK = 7, SP_TUNE_H2_DBG = 8, SP_TUNE_HW_DBG = 9, SP_TUNE_B3_DBG = 10, SP_TUNE_COUNT = 11 };
 extern int sp_tuning_values[SP_TUNE_COUNT];
+#ifdef SP_TIMING_VARIANTS
 static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }
+#else
+static inline int sp_tuning_get(int key, int dflt) {      // product build: only amax_reset is settable
+    return (key == SP_TUNE_AMAX_RESET && sp_tuning_values[key] >= 0) ? sp_tuning_values[key] : dflt;
+}
+#endif
 
 // A producer's fused-amax slot is zeroed IN STREAM ORDER by the producer's own launcher, so every launch -- eager or a HIP-graph
 // replay on new inputs -- starts from 0 instead of max(old, new).  A one-thread KERNEL, not hipMemsetAsync: 4-byte memset nodes

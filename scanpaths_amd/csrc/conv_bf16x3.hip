@@ -697,12 +697,15 @@ extern "C" int sp_conv_igemm_bf16x3(const sp_conv_desc* d, const void* Xs, const
     const int64_t xb = 6LL * d->N_img * d->Hi * d->Wi * d->Kc, wb = 6LL * d->Nout * d->KH * d->KW * d->Kc;
     if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
-    static const int dbg = getenv("SP_B3_DBG") ? atoi(getenv("SP_B3_DBG")) : 0;
-    a.dbg = dbg;
+    a.dbg = 0;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
+#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes: timing build only (sp_set_tuning("b3_dbg", n))
+    const int dbg = sp_tuning_get(SP_TUNE_B3_DBG, 0);
+    a.dbg = dbg;
     if (dbg == 1) return d->mode == 0 ? launch_b3<0, 1>(a, (hipStream_t)stream) : launch_b3<1, 1>(a, (hipStream_t)stream);
     if (dbg == 2) return d->mode == 0 ? launch_b3<0, 2>(a, (hipStream_t)stream) : launch_b3<1, 2>(a, (hipStream_t)stream);
     if (dbg == 3) return d->mode == 0 ? launch_b3<0, 3>(a, (hipStream_t)stream) : launch_b3<1, 3>(a, (hipStream_t)stream);
+#endif
     return d->mode == 0 ? launch_b3<0, 0>(a, (hipStream_t)stream) : launch_b3<1, 0>(a, (hipStream_t)stream);
 }
 

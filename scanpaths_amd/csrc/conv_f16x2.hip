@@ -890,6 +890,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     }
 }
 
+#ifdef SP_TIMING_VARIANTS      // experimental kernel (lost its A/B, see below): timing build only
 // ================================================================================================================
 // Short-K pointwise GEMM (1x1 convolutions of the ResNet bottlenecks with K <= 512, forward and stride-1 data gradient):
 //   C[m][n] = sum_k A[row(m)][k] * W[n][k],   row(m) = the input pixel of output pixel m (stride), same split operands and arithmetic
@@ -1134,6 +1135,8 @@ __global__ __launch_bounds__(256, 2) void s2_kernel(S2Args p) {
         }
     }
 }
+
+#endif  // SP_TIMING_VARIANTS
 
 // ================================================================================================================
 // Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pix(m,tap)][ci]   (K = pixels), the structure of w3_kernel:
@@ -1782,6 +1785,7 @@ int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
     return SP_OK;
 }
 
+#ifdef SP_TIMING_VARIANTS
 int launch_s2(const S2Args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1799,6 +1803,7 @@ int launch_s2(const S2Args& a, hipStream_t s) {
 bool s2_applies(const sp_conv_desc* d) {
     return sp_tuning_get(SP_TUNE_S2, 0) == 1 && d->KH * d->KW == 1 && d->pad == 0 && d->Kc <= 512 && (d->mode == 0 || d->stride == 1);
 }
+#endif  // SP_TIMING_VARIANTS
 
 int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
     SP_RESET_AMAX_ALWAYS(amax, s);   // scratch word of the caller's scale buffer (not a pooled slot); a kernel node, not a memset node: see common.h
@@ -1867,9 +1872,12 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
     if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
-    static const int dbg = getenv("SP_H2_DBG") ? atoi(getenv("SP_H2_DBG")) : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool f = d->mode == 0;
+    // channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
+    const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
+#ifdef SP_TIMING_VARIANTS
+    const int dbg = sp_tuning_get(SP_TUNE_H2_DBG, 0);
     if (nprod == 3 && dbg == 0 && s2_applies(d)) {
         if (st_partial && (!f || !st_mm || d->beta || d->relu || bias)) return SP_EINVAL;
         S2Args q{};
@@ -1882,12 +1890,13 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
         q.st_partial = st_partial; q.st_mm = st_mm;
         return launch_s2(q, st);
     }
-    if (st_partial) {        // fused BatchNorm statistics: forward, fp32-faithful, the 16x16x32 build only
+#endif
+    if (st_partial) {        // fused BatchNorm statistics: forward, fp32-faithful
         if (!f || !st_mm || nprod != 3 || d->beta || d->relu || bias) return SP_EINVAL;
         a.st_partial = st_partial; a.st_mm = st_mm;
-        return (d->KH * d->KW > 1 && d->KH * d->KW <= 32) ? launch_h2<0, 0, 5, 3, true, true>(a, st)
-                                                          : launch_h2<0, 0, 3, 3, true, false>(a, st);
+        return cbm_ok ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<0, 0, 3, 3, true, false>(a, st);
     }
+#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes and schedule variants (A/B tools only; sp_set_tuning("h2_dbg" / "h2_variant", n))
     if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
     if (dbg == 2) return f ? launch_h2<0, 2, 0>(a, st) : launch_h2<1, 2, 0>(a, st);
     if (dbg == 3) return f ? launch_h2<0, 3, 0>(a, st) : launch_h2<1, 3, 0>(a, st);
@@ -1897,33 +1906,36 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (dbg == 8) return f ? launch_h2<0, 3, 3, 3, true>(a, st) : launch_h2<1, 3, 3, 3, true>(a, st);      // MFMAs only
     if (dbg == 9) return f ? launch_h2<0, 9, 3, 3, true>(a, st) : launch_h2<1, 9, 3, 3, true>(a, st);      // LDS-DMA loads only
     if (dbg == 10) return f ? launch_h2<0, 10, 5, 3, true, true>(a, st) : launch_h2<1, 10, 5, 3, true, true>(a, st);  // half the weight-side LDS traffic
-    if (dbg == 12) return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);    // default schedule (A/B reference in one process)
+    if (nprod == 3) {
+        int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
+        if ((variant == 17 || variant == 18 || variant == 19) && !cbm_ok) variant = 7;
+        if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
+        switch (variant) {
+            case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
+            case 18: return f ? launch_h2<0, 0, 6, 3, true, true>(a, st) : launch_h2<1, 0, 6, 3, true, true>(a, st);      // ping-pong + LDS-DMA pieces spread through the matrix segment
+            case 19: return f ? launch_h2<0, 0, 7, 3, true, true>(a, st) : launch_h2<1, 0, 7, 3, true, true>(a, st);      // = 17 without s_setprio on the late waves
+            case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
+            case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
+            case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
+            case 14: return f ? launch_h2<0, 0, 2, 3, true, true>(a, st) : launch_h2<1, 0, 2, 3, true, true>(a, st);
+            case 15: return f ? launch_h2<0, 0, 3, 3, true, true>(a, st) : launch_h2<1, 0, 3, 3, true, true>(a, st);
+            case 0: return f ? launch_h2<0, 0, 0>(a, st) : launch_h2<1, 0, 0>(a, st);
+            case 1: return f ? launch_h2<0, 0, 1>(a, st) : launch_h2<1, 0, 1>(a, st);
+            case 2: return f ? launch_h2<0, 0, 2>(a, st) : launch_h2<1, 0, 2>(a, st);
+            case 3: return f ? launch_h2<0, 0, 3>(a, st) : launch_h2<1, 0, 3>(a, st);
+            case 4: return f ? launch_h2<0, 0, 0, 3, true>(a, st) : launch_h2<1, 0, 0, 3, true>(a, st);      // 16x16x32, lockstep
+            case 5: return f ? launch_h2<0, 0, 1, 3, true>(a, st) : launch_h2<1, 0, 1, 3, true>(a, st);      // 16x16x32, half stagger
+            case 6: return f ? launch_h2<0, 0, 2, 3, true>(a, st) : launch_h2<1, 0, 2, 3, true>(a, st);      // 16x16x32, ping-pong
+            default: break;                                                                                  // 17 / 7: the product schedules below
+        }
+    }
+#endif
     if (nprod == 1)      // throughput mode: load-bound, the ping-pong schedule
         return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
-    int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
-    // bit 3 = channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
-    const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
-    if ((variant == 17 || variant == 18 || variant == 19) && !cbm_ok) variant = 7;
-    if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
-    switch (variant) {
-        case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
-        case 17: return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);      // = 15, reads before the issue block
-        case 18: return f ? launch_h2<0, 0, 6, 3, true, true>(a, st) : launch_h2<1, 0, 6, 3, true, true>(a, st);      // ping-pong + LDS-DMA pieces spread through the matrix segment
-        case 19: return f ? launch_h2<0, 0, 7, 3, true, true>(a, st) : launch_h2<1, 0, 7, 3, true, true>(a, st);      // = 17 without s_setprio on the late waves
-        case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
-        case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
-        case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
-        case 14: return f ? launch_h2<0, 0, 2, 3, true, true>(a, st) : launch_h2<1, 0, 2, 3, true, true>(a, st);
-        case 15: return f ? launch_h2<0, 0, 3, 3, true, true>(a, st) : launch_h2<1, 0, 3, 3, true, true>(a, st);
-        case 0: return f ? launch_h2<0, 0, 0>(a, st) : launch_h2<1, 0, 0>(a, st);
-        case 1: return f ? launch_h2<0, 0, 1>(a, st) : launch_h2<1, 0, 1>(a, st);
-        case 2: return f ? launch_h2<0, 0, 2>(a, st) : launch_h2<1, 0, 2>(a, st);
-        case 3: return f ? launch_h2<0, 0, 3>(a, st) : launch_h2<1, 0, 3>(a, st);
-        case 4: return f ? launch_h2<0, 0, 0, 3, true>(a, st) : launch_h2<1, 0, 0, 3, true>(a, st);      // 16x16x32, lockstep
-        case 5: return f ? launch_h2<0, 0, 1, 3, true>(a, st) : launch_h2<1, 0, 1, 3, true>(a, st);      // 16x16x32, half stagger
-        case 6: return f ? launch_h2<0, 0, 2, 3, true>(a, st) : launch_h2<1, 0, 2, 3, true>(a, st);      // 16x16x32, ping-pong
-        default: return f ? launch_h2<0, 0, 3, 3, true>(a, st) : launch_h2<1, 0, 3, 3, true>(a, st);
-    }
+    // product schedules: 16x16x32 MFMAs, ping-pong halves with s_setprio; channel-block-major K order with the fragment reads ahead
+    // of the LDS-DMA issue block where that order is defined, tap-major otherwise
+    if (cbm_ok) return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);
+    return f ? launch_h2<0, 0, 3, 3, true>(a, st) : launch_h2<1, 0, 3, 3, true>(a, st);
 }
 
 extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
@@ -1935,7 +1947,10 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
 // st_mm [tiles][2][Nout] floats (min, max), tiles = sp_conv_stats_tiles(M) -- the layout sp_bn_fwd_split accepts as pre_partial
 extern "C" int64_t sp_conv_stats_tiles(const sp_conv_desc* d) {
     if (!d) return 0;
-    return sp_cdiv((int64_t)d->N_img * d->Ho * d->Wo, s2_applies(d) ? S2_BM : HBM);
+#ifdef SP_TIMING_VARIANTS
+    if (s2_applies(d)) return sp_cdiv((int64_t)d->N_img * d->Ho * d->Wo, S2_BM);
+#endif
+    return sp_cdiv((int64_t)d->N_img * d->Ho * d->Wo, HBM);
 }
 extern "C" int sp_conv_igemm_f16x2_stats(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
                                          const float* w_scale, float* out, double* st_partial, float* st_mm, void* stream) {
@@ -1981,7 +1996,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (hout_planes && (!hout_scale || !(hout_bound > 0.f) || ((uintptr_t)hout_planes & 15))) return SP_EINVAL;
     a.l_gates = gates; a.l_c = c_out; a.l_h = h_out; a.l_hamax = h_amax;
     a.l_hplanes = (uint16_t*)hout_planes; a.l_hscale = hout_scale; a.l_hbound = hout_bound;
-    a.l_direct_hc = (!hout_planes && sp_tuning_get(SP_TUNE_LSTM_EPI, 0) == 1) ? 1 : 0;
+    a.l_direct_hc = (!hout_planes && sp_tuning_get(SP_TUNE_LSTM_EPI, 0) == 1) ? 1 : 0;      // (timing build A/B switch; 0 in the product)
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);
@@ -2021,7 +2036,9 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    static const int dbg = getenv("SP_HW_DBG") ? atoi(getenv("SP_HW_DBG")) : 0;
+    rc = -1000;
+#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes and schedule variants (A/B tools only; sp_set_tuning("hw_dbg" / "hw_variant", n))
+    const int dbg = sp_tuning_get(SP_TUNE_HW_DBG, 0);
     if (dbg == 1) rc = launch_hw<2, 3, true, 1>(a, d->Co, s);
     else if (dbg == 2) rc = launch_hw<2, 3, true, 2>(a, d->Co, s);
     else if (dbg == 3) rc = launch_hw<2, 3, true, 3>(a, d->Co, s);
@@ -2031,17 +2048,21 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     else if (dbg == 7) rc = launch_hw<2, 3, true, 7>(a, d->Co, s);
     else if (dbg == 8) rc = launch_hw<2, 3, true, 8>(a, d->Co, s);
     else if (dbg == 9) rc = launch_hw<2, 3, true, 9>(a, d->Co, s);
-    else if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);
-    else switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
+    else if (nprod == 3) switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
         case 0: rc = launch_hw<0>(a, d->Co, s); break;
         case 2: rc = launch_hw<2>(a, d->Co, s); break;
         case 3: rc = launch_hw<3>(a, d->Co, s); break;
         case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
         case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
         case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
-        case 10: rc = launch_hw<5, 3, true>(a, d->Co, s); break;     // = 8 without s_setprio on the late waves
         case 11: rc = launch_hw<6, 3, true>(a, d->Co, s); break;     // = 10 with the late waves' loads issued at the start of their iteration
-        default: rc = launch_hw<3, 3, true>(a, d->Co, s); break;     // 16x16x32, ping-pong + setprio
+        case 7: rc = launch_hw<3, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong + setprio
+        default: break;                                              // 10: the product schedule below
+    }
+#endif
+    if (rc == -1000) {
+        if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);           // throughput mode
+        else rc = launch_hw<5, 3, true>(a, d->Co, s);                // product schedule: 16x16x32, ping-pong, reads before the load issue, no setprio
     }
     if (rc != SP_OK) return rc;
     if (a.splits > 1) {

@@ -193,20 +193,33 @@ extern "C" int sp_scale_by(const float* x, const float* scale, int64_t n, float*
 
 extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
 
-int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 extern "C" int sp_set_tuning(const char* name, int value) {
     if (!name) return SP_ENULL;
-    const char* names[SP_TUNE_COUNT] = {"h2_variant", "hw_variant", "hw_map", "hw_splits", "amax_reset", "s2", "lstm_epi", "h2_chunk"};
+    const char* names[SP_TUNE_COUNT] = {"h2_variant", "hw_variant", "hw_map", "hw_splits", "amax_reset", "s2", "lstm_epi", "h2_chunk",
+                                        "h2_dbg", "hw_dbg", "b3_dbg"};
     for (int i = 0; i < SP_TUNE_COUNT; ++i) {
         const char *a = names[i], *b = name;
         while (*a && *a == *b) { ++a; ++b; }
         if (!*a && !*b) {
+#ifndef SP_TIMING_VARIANTS
+            if (i != SP_TUNE_AMAX_RESET) return SP_EINVAL;      // schedule / timing selectors exist in the timing build only
+#endif
             sp_tuning_values[i] = value;
             return SP_OK;
         }
     }
     return SP_EINVAL;
+}
+
+// 1 in libscanpaths_amd_timing.so (wrong-result timing modes and schedule variants compiled in), 0 in the product library
+extern "C" int sp_timing_build(void) {
+#ifdef SP_TIMING_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int64_t sp_scanpath_loss_workspace(int B, int T) { return 2 * (int64_t)B * T * (int64_t)sizeof(float); }

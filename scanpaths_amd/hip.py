@@ -12,7 +12,10 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscanpaths_amd.so")
+# SP_LIBRARY=timing (tools/ only): the A/B build with schedule variants and wrong-result timing modes compiled in
+# (make -C scanpaths_amd/csrc timing).  The product path always loads libscanpaths_amd.so.
+TIMING_LIB = os.environ.get("SP_LIBRARY", "") == "timing"
+LIB_PATH = os.path.join(_HERE, "libscanpaths_amd_timing.so" if TIMING_LIB else "libscanpaths_amd.so")
 
 
 class ConvDesc(C.Structure):
@@ -40,6 +43,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "sp_abi_version": (_I, []),
     "sp_set_tuning": (_I, [C.c_char_p, _I]),
+    "sp_timing_build": (_I, []),
     "sp_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_split3_bf16": (_I, [_P, _L, _P, _P]),
     "sp_split3_bf16_wT": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -157,10 +161,14 @@ def lib() -> C.CDLL:
         # their reset node only while a stream is being captured (graph replays re-use the slot)
         if not os.environ.get("SP_ALWAYS_RESET_AMAX"):
             check(_lib.sp_set_tuning(b"amax_reset", 1), "sp_set_tuning")
-        for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi"), ("SP_S2", b"s2"),
-                          ("SP_H2_CHUNK", b"h2_chunk")):      # A/B timing / profiling only
-            if os.environ.get(env):
-                check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
+        if _lib.sp_timing_build() != int(TIMING_LIB):
+            raise RuntimeError(f"{LIB_PATH}: timing / product build mix-up")
+        if TIMING_LIB:      # A/B timing / profiling knobs, honoured by the timing build only
+            for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi"),
+                              ("SP_S2", b"s2"), ("SP_H2_CHUNK", b"h2_chunk"), ("SP_H2_DBG", b"h2_dbg"), ("SP_HW_DBG", b"hw_dbg"),
+                              ("SP_B3_DBG", b"b3_dbg"), ("SP_HW_MAP", b"hw_map"), ("SP_HW_SPLITS", b"hw_splits")):
+                if os.environ.get(env):
+                    check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib
 
 

@@ -64,7 +64,7 @@ def run(name, **sw):
             e, fl, n = float((got - g64[k]).norm()), float((g32[k] - g64[k]).norm()), float(g64[k].norm())
             rows.append((k, e, fl, n))
         big = [r for r in rows if r[3] > 1e-3 * top]
-        worst = sorted(big, key=lambda r: -r[1] / max(r[2], 1e-30))[:8]
+        worst = sorted(big, key=lambda r: -r[1] / max(r[2], 1e-30))[:int(os.environ.get('NROWS', '8'))]
         print(f"== {name}: loss err {abs(float(loss) - losses['64']):.2e} (oracle32 {abs(losses['32'] - losses['64']):.2e}); "
               f"counts {dict((k, v) for k, v in F.FUSION_COUNTS.items() if v)}")
         for k, e, fl, n in worst:
@@ -76,15 +76,19 @@ def run(name, **sw):
             setattr(F, k, v)
 
 
+CONFIGS = {
+    "default_bs2_costmodel": ("default (cost model at bs 2)", {}),
+    "bench_path": ("bench path (COST_M_SCALE 16)", dict(COST_M_SCALE=16.0)),
+    "no_lstm_bwd_split": ("bench path, LSTM_BWD_SPLIT off", dict(COST_M_SCALE=16.0, LSTM_BWD_SPLIT=False)),
+    "no_bn_split": ("bench path, BN_SPLIT off", dict(COST_M_SCALE=16.0, BN_SPLIT=False)),
+    "no_fuse": ("bench path, FUSE_GATE_LSTM off", dict(COST_M_SCALE=16.0, FUSE_GATE_LSTM=False)),
+    "no_hplanes": ("bench path, LSTM_H_PLANES off", dict(COST_M_SCALE=16.0, LSTM_H_PLANES=False)),
+    "no_amax_hint": ("bench path, FUSED_AMAX off", dict(COST_M_SCALE=16.0, FUSED_AMAX=False)),
+    "bf16x3": ("bf16x3 back-end", dict(COST_M_SCALE=16.0, SPLIT_SCHEME="bf16x3")),
+    "fp32": ("fp32 MFMA back-end", dict(USE_BF16X3=False)),
+}
 out = {}
-out["default_bs2_costmodel"] = run("default (cost model at bs 2)")
-out["bench_path"] = run("bench path (COST_M_SCALE 16)", COST_M_SCALE=16.0)
-out["no_lstm_bwd_split"] = run("bench path, LSTM_BWD_SPLIT off", COST_M_SCALE=16.0, LSTM_BWD_SPLIT=False)
-out["no_bn_split"] = run("bench path, BN_SPLIT off", COST_M_SCALE=16.0, BN_SPLIT=False)
-out["no_fuse"] = run("bench path, FUSE_GATE_LSTM off", COST_M_SCALE=16.0, FUSE_GATE_LSTM=False)
-out["no_hplanes"] = run("bench path, LSTM_H_PLANES off", COST_M_SCALE=16.0, LSTM_H_PLANES=False)
-out["no_amax_hint"] = run("bench path, FUSED_AMAX off", COST_M_SCALE=16.0, FUSED_AMAX=False)
-out["bf16x3"] = run("bf16x3 back-end", COST_M_SCALE=16.0, SPLIT_SCHEME="bf16x3")
-out["fp32"] = run("fp32 MFMA back-end", USE_BF16X3=False)
+for key in (os.environ.get("CONFIGS", ",".join(CONFIGS)).split(",")):
+    out[key] = run(*[CONFIGS[key][0]], **CONFIGS[key][1])
 os.makedirs(os.path.join(ROOT, "gpurun_out", "diag"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "diag", f"grad_error_table_T{T}.json"), "w"))

@@ -238,3 +238,19 @@ def test_dataset_host_side_matches_reference_datasets():
     for sigma, tag in ((None, "osie_"), (2, "osie_blur_")):
         for k, w in zip(keys, SO.collate_targets(DS._with_durations(orecs, (600, 800)), 16, (30, 40), f64_div=True, blur_sigma=sigma)):
             assert np.array_equal(w, g[tag + k]), (tag, k)
+
+
+def test_kernel_sources_read_no_environment():
+    """the product library takes no behaviour from the environment: no getenv in scanpaths_amd/csrc; the schedule /
+    timing selectors are compiled only under SP_TIMING_VARIANTS"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fn in glob.glob(os.path.join(root, "scanpaths_amd", "csrc", "*.h*")):
+        assert "getenv" not in open(fn).read(), fn
+    import ctypes
+    from scanpaths_amd import hip
+    if os.path.exists(hip.LIB_PATH):
+        lib = ctypes.CDLL(hip.LIB_PATH)
+        lib.sp_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        assert lib.sp_timing_build() == 0
+        assert lib.sp_set_tuning(b"h2_dbg", 1) == -1 and lib.sp_set_tuning(b"amax_reset", 1) == 0

@@ -166,3 +166,98 @@ def test_full_size_eval_is_independent_of_batch_mates_and_normalised():
         assert p.shape == (32, T, 1 + 40 * 64)
         assert float((p.sum(-1) - 1).abs().max()) < 1e-5 and float(p.min()) >= 0
         assert float(big[head + "_log_normal_sigma2"].min()) > 0
+
+
+def test_config5_bs128_eval_forward_graph_replay_and_beam4():
+    """BASELINE.json config 5 as worded: AiR inference at bs 128, 320x512, 16 decode steps, HIP-graph capture, beam-4 decoding.
+    (i)   the eval forward at bs 128 (tame weights): probabilities are distributions, sigma2 > 0, all finite; samples 0..1 agree with
+          a bs-2 run of the same images to 2e-4 of scale (no cross-sample coupling in eval mode; different tile decomposition and
+          per-tensor operand scales only) and their argmax fixation indices agree wherever the top-2 margin is decisive;
+    (ii)  the WHOLE 16-step forward is captured as ONE HIP graph (all 15 recurrent decode steps inside it) and replayed on new
+          inputs through the static buffers: bit-identical to eager on the same inputs.  The decode body is not captured step by
+          step: the memory lists grow by one entry per step (baseline_attention.py:277-296, 317-336), so the 16 step bodies are 16
+          different kernel sequences, and at this batch the device is the bottleneck anyway (eager and replay times are recorded in
+          gpurun_out/parity/r03_infer128.json; they agree to a few percent);
+    (iii) beam-4 decoding of the model's own distributions (Sampling.beam_search): scores sorted, every sequence scores what it
+          claims, beam 0 never below the greedy path, fixation vectors come out of generate_scanpath.
+    Reference loop: AiR/models/baseline_attention.py:385-493, AiR/test.py:130-193."""
+    import json
+    import time
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.models.sampling import Sampling
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    B, T, Hm, Wm = 128, 16, 40, 64
+    m = baseline(convLSTM_length=T, map_width=Wm, map_height=Hm)
+    fill_module(m, 6, family="tame")
+    m = m.to(DEV).eval()
+    b = make_batch("AiR", B, 320, 512, T, seed=6)
+    img, att = b["images"].to(DEV), b["attention_maps"].to(DEV)
+    with torch.no_grad():
+        big = m(img, att)
+        small = m(img[:2].contiguous(), att[:2].contiguous())
+    for k, v in big.items():
+        assert torch.isfinite(v).all(), k
+        scale = float(small[k].abs().max())
+        assert float((v[:2] - small[k]).abs().max()) <= 2e-4 * max(scale, 1e-30), (k, float((v[:2] - small[k]).abs().max()), scale)
+    for head in ("good", "poor"):
+        p = big[head + "_all_actions_prob"]
+        assert p.shape == (B, T, 1 + Hm * Wm)
+        assert float((p.sum(-1) - 1).abs().max()) < 1e-5 and float(p.min()) >= 0
+        assert float(big[head + "_log_normal_sigma2"].min()) > 0
+        top2 = small[head + "_all_actions_prob"].topk(2, -1).values
+        dec = (top2[..., 0] - top2[..., 1]) > 4e-4 * float(small[head + "_all_actions_prob"].max())
+        assert torch.equal(p[:2].argmax(-1)[dec], small[head + "_all_actions_prob"].argmax(-1)[dec])
+    # ---- one HIP graph for the whole forward, replayed on other inputs --------------------------------------------------------------
+    s_img, s_att = img.clone(), att.clone()
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(s_img, s_att)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gout = m(s_img, s_att)
+    b2 = make_batch("AiR", B, 320, 512, T, seed=7)
+    s_img.copy_(b2["images"].to(DEV))
+    s_att.copy_(b2["attention_maps"].to(DEV))
+    g.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref2 = m(s_img, s_att)
+    for k in ref2:
+        assert torch.equal(gout[k], ref2[k]), k
+    assert not torch.equal(ref2["good_all_actions_prob"], big["good_all_actions_prob"])
+    times = {}
+    for name, fn in (("eager", lambda: m(s_img, s_att)), ("graph_replay", g.replay)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(2):
+                fn()
+        torch.cuda.synchronize()
+        times[name + "_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+    try:
+        d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "parity")
+        os.makedirs(d, exist_ok=True)
+        json.dump(dict(times, batch=B, T=T, images_per_s_graph=B / times["graph_replay_ms"] * 1e3), open(os.path.join(d, "r03_infer128.json"), "w"))
+    except OSError:
+        pass
+    print(f"config 5 eval forward bs {B}: eager {times['eager_ms']:.1f} ms, whole-forward graph replay {times['graph_replay_ms']:.1f} ms")
+    # ---- beam-4 on the model's own distributions -------------------------------------------------------------------------------------
+    s = Sampling(convLSTM_length=T, min_length=1, map_width=Wm, map_height=Hm, width=512, height=320)
+    probs = ref2["good_all_actions_prob"]
+    out = s.beam_search(probs, ref2["good_log_normal_mu"], ref2["good_log_normal_sigma2"], beam=4)
+    acts, sc = out["selected_actions"], out["scores"]
+    assert acts.shape == (B, 4, T) and (sc[:, :-1] >= sc[:, 1:]).all()
+    lp = torch.gather(probs.unsqueeze(1).expand(B, 4, T, probs.shape[-1]), 3, acts.clamp(min=0).unsqueeze(-1)).squeeze(-1).double().log()
+    live = ((acts == 0).float().cumsum(2) - (acts == 0).float()) == 0
+    assert torch.allclose((lp * live).sum(2), sc, rtol=0, atol=1e-9)
+    pm = probs.clone()
+    pm[:, 0, 0] = 0
+    gp, ga = pm.max(-1)
+    alive = ((ga == 0).float().cumsum(1) - (ga == 0).float()) == 0
+    assert (sc[:, 0] >= (gp.double().log() * alive).sum(1) - 1e-9).all()
+    fix, am, dm = s.generate_scanpath(s_img, None, out["durations"][:, 0], acts[:, 0])
+    assert len(fix) == B and am.shape == (B, T)

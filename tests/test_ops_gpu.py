@@ -601,8 +601,8 @@ def test_bn_act_emits_the_split_operand_and_the_bit_mask(relu, monkeypatch):
 
 @pytest.mark.parametrize("k", [3, 1])
 def test_conv_epilogue_writes_the_batchnorm_statistics(k, monkeypatch, request):
-    """conv2d(bn_stats=True) on the 2xfp16 path: per M-tile (256 rows; 128 for the short-K pointwise kernel, k = 1) and output
-    column the epilogue leaves sum / sum of squares (fp64) and min / max (fp32) of the conv output -- exactly the first stage of
+    """conv2d(bn_stats=True) on the 2xfp16 path (k = 3: channel-block-major schedule; k = 1: the tap-major fallback): per M-tile
+    (256 rows) and output column the epilogue leaves sum / sum of squares (fp64) and min / max (fp32) of the conv output -- exactly the first stage of
     bn_pool.hip's statistics; the BatchNorm behind it gives the same result with and without them (ragged last tile: 2 x 63 x 65 =
     8190 pixels)"""
     from scanpaths_amd import functional as F
@@ -610,14 +610,11 @@ def test_conv_epilogue_writes_the_batchnorm_statistics(k, monkeypatch, request):
         pytest.skip("2xfp16 back-end not active")
     dev = _dev()
     N, H, W, Ci, Co = 2, 63, 65, 128, 160
-    TM = 256 if k == 3 else 128
+    TM = 256
     x = _rand(N, H, W, Ci, seed=51).to(dev).requires_grad_(True)
     w = (_rand(Co, Ci, k, k, seed=52, scale=0.05)).to(dev).contiguous(memory_format=torch.channels_last)
     if k == 1:
-        from scanpaths_amd import hip
         monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1, **kw: True)        # small for the cost model
-        hip.check(hip.lib().sp_set_tuning(b"s2", 1), "sp_set_tuning")                        # the opt-in short-K pointwise kernel
-        request.addfinalizer(lambda: hip.lib().sp_set_tuning(b"s2", -1))
     assert F.conv_takes_split(x.shape, w, pad=k // 2)
     y = F.conv2d(x, w, None, pad=k // 2, bn_stats=True)
     st = getattr(y, "_sp_bnstats", None)
@@ -664,6 +661,18 @@ def test_semantic_pool(S, B, P, C):
     _close(out, ref, 3e-6, "pooled")
     _close(ad.grad, ar.grad, 3e-6, "d amaps")
     _close(vd.grad, vr.grad, 3e-6, "d vf")
+
+
+def test_product_library_has_no_timing_modes():
+    """the shipped library cannot be switched into a wrong-result timing mode or another kernel schedule -- those
+    selectors exist only in libscanpaths_amd_timing.so; the one process-wide switch left is "amax_reset"."""
+    from scanpaths_amd import hip
+    L = hip.lib()
+    assert L.sp_timing_build() == 0 and hip.LIB_PATH.endswith("libscanpaths_amd.so")
+    for name in (b"h2_dbg", b"hw_dbg", b"b3_dbg", b"h2_variant", b"hw_variant", b"s2", b"lstm_epi", b"hw_map", b"hw_splits", b"h2_chunk",
+                 b"nonsense"):
+        assert L.sp_set_tuning(name, 1) == -1, name
+    assert L.sp_set_tuning(b"amax_reset", 1) == 0
 
 
 def test_c_abi_error_codes():

@@ -5,6 +5,7 @@ between two HIP events on the launch stream); prints median and min per variant 
 bit-identical outputs.      python3 tools/bench_h2_variants.py [rounds] [reps]"""
 import json
 import os
+os.environ.setdefault("SP_LIBRARY", "timing")      # schedule variants / timing modes live in libscanpaths_amd_timing.so (make timing)
 import statistics
 import sys
 

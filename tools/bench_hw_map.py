@@ -4,6 +4,7 @@
     python3 tools/bench_hw_map.py [rounds] [reps]        env CONFIGS="0:0,1:0,0:16,1:16" (map:splits, splits 0 = heuristic)"""
 import json
 import os
+os.environ.setdefault("SP_LIBRARY", "timing")      # schedule variants / timing modes live in libscanpaths_amd_timing.so (make timing)
 import statistics
 import sys
 

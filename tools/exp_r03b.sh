@@ -1,4 +1,5 @@
 #!/bin/bash
+export SP_LIBRARY=timing      # knobs below exist in libscanpaths_amd_timing.so only (make -C scanpaths_amd/csrc timing)
 # round-3 experiment batch: gradient error table, accumulation-level accuracy, weight-side LDS traffic proxy
 O=gpurun_out/r03b
 mkdir -p $O
