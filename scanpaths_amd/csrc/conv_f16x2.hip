@@ -184,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
     }
     int ld_tap = 0;
+    int dbg_last_pieces = 6;      // DBG 10: LDS-DMA pieces of the most recently issued K-tile
 
     auto tap_update = [&]() {
 #pragma unroll
@@ -220,9 +221,16 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const uint32_t koffA = (uint32_t)ld_cblk * 128u;
             const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
             const uint32_t zrelA = p.x_bytes - koffA;
+            // DBG 11 (timing proxy of ONE halo'd activation block per channel block shared by the three horizontal taps of a filter row:
+            // a third of the activation LDS-DMA pieces; wrong results): activation pieces only for the first tap of each filter row
+            if (DBG != 11 || ld_kx == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                SP_GLDS16(baseA + (((a_mask[j] >> ld_tap) & 1u) ? a_base0[j] + delta : zrelA), st + (wave + 8 * j) * 1024);
+                for (int j = 0; j < 4; ++j)
+                    SP_GLDS16(baseA + (((a_mask[j] >> ld_tap) & 1u) ? a_base0[j] + delta : zrelA), st + (wave + 8 * j) * 1024);
+                dbg_last_pieces = 6;
+            } else {
+                dbg_last_pieces = 2;
+            }
             const uint32_t koffB = (uint32_t)(ld_tap * p.ncblk + ld_cblk) * 128u;
             const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
             const uint32_t zrelB = p.w_bytes - koffB;
@@ -231,6 +239,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             if (DBG != 10 || (ld_tap & 1) == 0) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
+                if (DBG == 10) dbg_last_pieces = 6;
+            } else {
+                dbg_last_pieces = 4;
             }
             ++ld_tap;
             if (++ld_kx == p.KW) {
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
 
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every thread issues 6 loads per tile)
-    constexpr bool do_load = DBG != 1 && DBG != 3 && DBG != 11, do_mma = DBG != 2 && DBG != 9, do_lds = DBG != 3 && DBG != 9;      // DBG 9: loads only
+    constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2 && DBG != 9, do_lds = DBG != 3 && DBG != 9;      // DBG 9: loads only
     constexpr bool do_bar = DBG != 3;
     int issued = 0;
     if (do_load)
@@ -488,7 +499,12 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     auto wait_barrier = [&](int kt_) {
         // tile kt+1 must have landed: everything but the one younger tile (if it was issued)
         if (DBG == 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // the younger tile has 2 or 6 pieces: never wait for fewer than needed
-        else if (DBG == 10) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // 4 or 6 pieces
+        else if (DBG == 10 || DBG == 11) {                                    // the younger tile has 2, 4 or 6 pieces
+            if (kt_ + 2 >= p.nkt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (dbg_last_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (dbg_last_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         else if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1906,6 +1922,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (dbg == 8) return f ? launch_h2<0, 3, 3, 3, true>(a, st) : launch_h2<1, 3, 3, 3, true>(a, st);      // MFMAs only
     if (dbg == 9) return f ? launch_h2<0, 9, 3, 3, true>(a, st) : launch_h2<1, 9, 3, 3, true>(a, st);      // LDS-DMA loads only
     if (dbg == 10) return f ? launch_h2<0, 10, 5, 3, true, true>(a, st) : launch_h2<1, 10, 5, 3, true, true>(a, st);  // half the weight-side LDS traffic
+    if (dbg == 11) return f ? launch_h2<0, 11, 5, 3, true, true>(a, st) : launch_h2<1, 11, 5, 3, true, true>(a, st);  // a third of the activation LDS-DMA pieces
     if (nprod == 3) {
         int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
         if ((variant == 17 || variant == 18 || variant == 19) && !cbm_ok) variant = 7;

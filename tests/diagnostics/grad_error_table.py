@@ -69,6 +69,17 @@ def run(name, **sw):
               f"counts {dict((k, v) for k, v in F.FUSION_COUNTS.items() if v)}")
         for k, e, fl, n in worst:
             print(f"   {k:45s} err/norm {e / n:.2e}  oracle32 err/norm {fl / n:.2e}  ratio {e / max(fl, 1e-30):6.1f}  norm {n:.3e}")
+        for name_ in [d for d in os.environ.get("DETAIL", "").split(",") if d]:
+            # is the error concentrated in a few output channels (the signature of single ReLU-mask flips) or spread out?
+            p_ = dict(m.named_parameters())[name_]
+            err = (p_.grad.detach().cpu().double() - g64[name_])
+            e32 = (g32[name_] - g64[name_])
+            ch = err.flatten(1).pow(2).sum(1) if err.dim() > 1 else err.pow(2)
+            ch32 = e32.flatten(1).pow(2).sum(1) if e32.dim() > 1 else e32.pow(2)
+            tk = torch.topk(ch, min(5, ch.numel()))
+            print(f"   DETAIL {name_}: share of squared error in the top-5 output channels {[round(float(v / ch.sum()), 4) for v in tk.values]} "
+                  f"(channels {tk.indices.tolist()}); oracle32: {[round(float(v / ch32.sum()), 4) for v in torch.topk(ch32, min(5, ch32.numel())).values]}; "
+                  f"err norm without the top-2 channels {float((ch.sum() - tk.values[:2].sum()).clamp(min=0).sqrt()):.3e} vs oracle32 {float(ch32.sum().sqrt()):.3e}")
         sys.stdout.flush()
         return {k: (e, fl, n) for k, e, fl, n in rows}
     finally:

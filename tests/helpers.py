@@ -85,3 +85,33 @@ def metrics_table(d):
     """the reference's nested metric dict -> [3 categories, 11 columns] float64"""
     import numpy as np
     return np.array([[float(d[c][g][k]) for g, k in EVAL_COLUMNS] for c in EVAL_CATEGORIES], dtype=np.float64)
+
+
+def oracle_bench_case(args):
+    """(runs in a spawned worker process) the oracle's train step (loss + gradients) and eval forward of one AiR case in ONE dtype.
+    args = (dtype name, seed, Hm, Wm, T, NB, H, W, threads) -> ({"train/<key>": array, "eval/<key>": array}, {param: grad}, loss)"""
+    import torch
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.spec import is_buffer
+    from scanpaths_amd.synth import make_batch
+    dtname, seed, Hm, Wm, T, NB, H, W, threads = args
+    torch.set_num_threads(threads)
+    dt = getattr(torch, dtname)
+    b = make_batch("AiR", NB, H, W, T, seed=seed)
+    sd = oracle_state("AiR", "resnet50", seed, Hm, Wm, dtype=dt, family="tame")
+    bd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in b.items()}
+    out = {}
+    with torch.no_grad():
+        ev = O.forward(sd, "AiR", bd["images"], bd["attention_maps"], training=False, T=T)
+    for k, v in ev.items():
+        out["eval/" + k] = v.double().numpy()
+    for k, v in sd.items():
+        if v.is_floating_point() and not is_buffer(k):
+            v.requires_grad_(True)
+    tr = O.forward(sd, "AiR", bd["images"], bd["attention_maps"], bd["performances"], training=True, T=T)
+    loss, _, _ = O.supervised_loss(tr, bd)
+    loss.backward()
+    for k, v in tr.items():
+        out["train/" + k] = v.detach().double().numpy()
+    grads = {k: v.grad.numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    return out, grads, float(loss.detach())
