@@ -31,6 +31,12 @@ constexpr int HB_BYTES = HBN * 128;              // 16384
 constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 49152
 constexpr int HNSTAGE = 3;                       // 2 K-tiles (64 k) in flight, 144 KB LDS
 constexpr int HCHUNK_KT = 8;                     // fold acc into tot every 8 K-tiles (256 k)
+// HALO build of h2_kernel (3x3 stride-1 "same" convs on 64-pixel-wide maps): per 32-channel block ONE activation block with a
+// one-pixel halo -- the tile's 4 image rows plus the row above and below, 66 pixel slots per row -- serves all 9 filter taps
+constexpr int HALO_W = 64, HALO_ROWSLOTS = HALO_W + 2, HALO_NSLOT = 6 * HALO_ROWSLOTS;      // 396 pixel slots of 128 B
+constexpr int HALO_PIECES = (HALO_NSLOT + 7) / 8;                                         // 50 LDS-DMA pieces of 1 KB
+constexpr int HALO_A_BYTES = HALO_PIECES * 1024;                                          // 51200 per block, two blocks in flight
+constexpr int HALO_LDS = 2 * HALO_A_BYTES + 3 * HB_BYTES;                                 // 151552
 constexpr int HW_DEFAULT_MAP = 0;                // sp_set_tuning("hw_map", 1): aligned-rounds workgroup order of hw_kernel
 constexpr int H2_DEFAULT_VARIANT = 17;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
 constexpr int HW_DEFAULT_VARIANT = 10;           // schedule variant of hw_kernel
@@ -107,10 +113,19 @@ struct H2Args {
 // hidden state, max|h| -- the [M][4C] h-gate tensor (42 MB per decode step at the benchmark size) is never written or re-read.
 // Needs P % 256 == 0 (a 256-pixel tile lies inside one sample: one filter slice per workgroup), C % 32 == 0, KP <= 32.
 __device__ __forceinline__ float h2_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }      // = decoder.hip sigmoidf_
+// Chunk swizzle of the halo activation block.  A ds_read_b128 is served in lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (per
+// 32-lane half): of the 16 consecutive pixel slots b .. b+15 a group reads slots {0-3,12-15} at chunk c (k-group g4 even) and slots
+// {4-11} at chunk c ^ 1 (g4 odd), or the other way round.  The ring's swizzle  c ^ ((row >> 1) & 7)  is conflict-free only for b = 0
+// mod 16; in the halo block b = (image row + tap row) * 66 + tap column is arbitrary (3600 of 4800 groups conflict over b = 0..599).
+// XOR-ing ((slot >> 1) & 3) into bits 2:1 ONLY keeps bit 0 = the k-group parity: slots of one parity then differ in bits 2:1 within
+// the outer four and within the middle four slot pairs (four consecutive values of slot >> 1 mod 4) and the two sets differ in bit 0
+// -- 16 distinct 16-byte bank slots for every b (0 of 4800 conflict; enumerated in tests/test_cpu_host.py).
+__device__ __forceinline__ int halo_swz(int slot) { return ((slot >> 1) & 3) << 1; }
 
-template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false>
+template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false, bool HALO = false>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     static_assert(!LSTM || (M16 && MODE == 0), "the LSTM epilogue is written for the forward 16x16x32 build");
+    static_assert(!HALO || (M16 && CBM && VAR == 5 && NPROD == 3 && DBG == 0), "the halo build extends the default schedule only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     bool a_ok[4];
     const int rowbytes = p.Kc * 4;
     uint32_t a_base0[4], a_mask[4];      // CBM: offset of the lane's pixel at tap (0,0) (wrapping arithmetic), valid-tap bits
-    if constexpr (CBM) {
+    if constexpr (CBM && !HALO) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a_base0[j] = (uint32_t)(a_boff[j] + a_py[j] * p.Wi + a_px[j]) * (uint32_t)rowbytes + (uint32_t)a_c8[j];
@@ -185,6 +200,39 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     }
     int ld_tap = 0;
     int dbg_last_pieces = 6;      // DBG 10: LDS-DMA pieces of the most recently issued K-tile
+    // HALO: the lane's source offsets of the activation block (per-lane constants over the whole K loop; only the channel block,
+    // a scalar, changes).  LDS piece q = wave + 8 j holds pixel slots 8 q .. 8 q + 7; slot s = (block row s / 66, column s % 66 - 1),
+    // block row 0 = the image row above the tile's first row.  Slots outside the image (halo columns, rows above / below the image,
+    // the tail of the last piece) read the zero block.  Chunk swizzle: halo_swz (see there).
+    uint32_t h_off[7];
+    uint32_t h_valid = 0;
+    const int h_npieces = HALO ? (HALO_PIECES - wave + 7) / 8 : 0;          // pieces this wave issues per block (7 or 6; scalar)
+    if constexpr (HALO) {
+        const int img = (int)(m0 / HoWo);
+        const int y0 = (int)(m0 - (int64_t)img * HoWo) / p.Wo;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int slot = (wave + 8 * j) * 8 + (lane >> 3), pos = lane & 7;
+            const int br = slot / HALO_ROWSLOTS, sx = slot - br * HALO_ROWSLOTS;
+            const int y = y0 - 1 + br, x = sx - 1;
+            const bool ok = slot < HALO_NSLOT && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi && m0 < p.M;
+            h_off[j] = ok ? (uint32_t)((img * p.Hi + y) * p.Wi + x) * (uint32_t)rowbytes + (uint32_t)((pos ^ halo_swz(slot)) * 16) : 0u;
+            h_valid |= ok ? (1u << j) : 0u;
+        }
+    }
+    int h_cb = 0;                 // HALO: next activation block (channel block) to issue
+    auto issue_block = [&]() {    // the whole block at once (prologue)
+        if constexpr (HALO) {
+            unsigned char* stA = smem + (h_cb & 1) * HALO_A_BYTES;
+            const uint32_t koffA = (uint32_t)h_cb * 128u;
+            const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
+            const uint32_t zrelA = p.x_bytes - koffA;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < h_npieces) SP_GLDS16(baseA + (((h_valid >> j) & 1u) ? h_off[j] : zrelA), stA + (wave + 8 * j) * 1024);
+            ++h_cb;
+        }
+    };
 
     auto tap_update = [&]() {
 #pragma unroll
@@ -215,6 +263,19 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 
     auto issue_tile = [&](int stage) {
         unsigned char* st = smem + stage * HSTAGE;
+        if constexpr (HALO) {      // weight tile of K-tile (ld_cblk, ld_tap) into the weight ring; activations come by issue_block
+            unsigned char* stB = smem + 2 * HALO_A_BYTES + stage * HB_BYTES;
+            const uint32_t koffB = (uint32_t)(ld_tap * p.ncblk + ld_cblk) * 128u;
+            const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
+            const uint32_t zrelB = p.w_bytes - koffB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), stB + (wave + 8 * j) * 1024);
+            if (++ld_tap == 9) {
+                ld_tap = 0;
+                ++ld_cblk;
+            }
+            return;
+        }
         if constexpr (CBM) {
             const int step = (ld_ky * p.Wi + ld_kx) * p.dil;                   // scalar: pixel offset of tap (ld_ky, ld_kx)
             const uint32_t delta = (uint32_t)(MODE == 0 ? step : -step) * (uint32_t)rowbytes;
@@ -362,6 +423,12 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
         }
 
+    // HALO: fragment row i*16 + l16 of wave row-group wm is pixel (image row wm of the tile, column i*16 + l16) -> block slot
+    // (wm + dy) * 66 + column + dx with (dy, dx) = (ky, kx) forward, (2 - ky, 2 - kx) data gradient; the slot (hence the swizzle)
+    // changes with the tap, 16-slot steps leave the swizzle alone (the four row tiles are reached by immediate offsets)
+    const int h_slot0 = wm * HALO_ROWSLOTS + l16;
+    const int h_chunk = (g4 >> 1) * 4 + (g4 & 1);
+    int rd_tap = 0, rd_cb = 0;           // HALO: coordinates of the K-tile whose fragments are read next
     f32x16 tot[2][2], acc[2][2];         // M32 accumulators (unused registers are dropped by the compiler in the M16 build)
     f32x4 tot4[4][4], acc4[4][4];        // M16 accumulators
 #pragma unroll
@@ -387,10 +454,15 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     constexpr bool do_load = DBG != 1 && DBG != 3, do_mma = DBG != 2 && DBG != 9, do_lds = DBG != 3 && DBG != 9;      // DBG 9: loads only
     constexpr bool do_bar = DBG != 3;
     int issued = 0;
+    if constexpr (HALO) issue_block();                        // activation block of channel block 0, ahead of the weight tiles
     if (do_load)
         for (; issued < HNSTAGE - 1 && issued < p.nkt; ++issued) issue_tile(issued);
-    if (issued >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (issued >= 2) {
+        if constexpr (HALO) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]: all 16 fragments of a K-tile (64 VGPRs)
@@ -411,6 +483,26 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                         af[kk][i][pl] = z;
                         bf[kk][i][pl] = z;
                     }
+        } else if constexpr (HALO) {
+            const int ky = rd_tap / 3, kx = rd_tap - 3 * ky;                                 // scalar
+            const int slot = h_slot0 + (MODE == 0 ? ky * HALO_ROWSLOTS + kx : (2 - ky) * HALO_ROWSLOTS + 2 - kx);
+            const int sw = halo_swz(slot);
+            const unsigned char* stA = smem + (rd_cb & 1) * HALO_A_BYTES + slot * 128;
+            const unsigned char* stB = smem + 2 * HALO_A_BYTES + stage_ * HB_BYTES - HA_BYTES;
+            const int oa0 = ((h_chunk) ^ sw) * 16, oa1 = ((h_chunk + 2) ^ sw) * 16;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[kk][i][0] = *reinterpret_cast<const f16x8*>(stA + oa0 + (2 * kk + i) * 16 * 128);
+                    af[kk][i][1] = *reinterpret_cast<const f16x8*>(stA + oa1 + (2 * kk + i) * 16 * 128);
+                    bf[kk][i][0] = *reinterpret_cast<const f16x8*>(stB + offB[0][0] + (2 * kk + i) * 16 * 128);
+                    bf[kk][i][1] = *reinterpret_cast<const f16x8*>(stB + offB[0][1] + (2 * kk + i) * 16 * 128);
+                }
+            if (++rd_tap == 9) {
+                rd_tap = 0;
+                ++rd_cb;
+            }
         } else if constexpr (M16) {
             // af[kk][i][pl] holds row tile 2*kk + i (16 rows each) of the ONE 32-k block; bf likewise for column tiles
 #pragma unroll
@@ -531,7 +623,65 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     int stage = 0;
     const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5 || VAR == 6 || VAR == 7) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
     if ((VAR == 3 || VAR == 5 || VAR == 6) && late) __builtin_amdgcn_s_setprio(1);
-    if constexpr (VAR == 6 && M16 && do_mma && do_load) {
+    if constexpr (HALO) {
+        // Default schedule (VAR 5: ping-pong halves, fragment reads ahead of the LDS-DMA issue block, s_setprio on the late half) with
+        // the activation operand staged as halo blocks: per K-tile every lane issues its 2 weight pieces (tile kt + 2); at the first tap
+        // of channel block cb it then issues the 6-7 pieces of activation block cb + 1 (into the block buffer that block cb - 1 left at
+        // the barrier before this channel block); the block is complete two barriers later, seven K-tiles before its first use.
+        // (One block piece per K-tile instead of the burst measured SLOWER: 3.62 / 3.50 ms against 3.56 / 3.43 without halo blocks.)
+        int cur_tap = 0, cur_cb = 0;
+        auto halo_issue = [&](int kt_) {                      // weight tile kt + 2; at the first tap of a channel block the next block
+            if (kt_ + HNSTAGE - 1 < p.nkt) issue_tile(prev_stage(stage));
+            if (cur_tap == 0 && cur_cb + 1 < p.ncblk) issue_block();
+        };
+        auto halo_wait = [&](int kt_) {
+            // weight tile kt + 1 (issued one K-tile ago) must have landed; loads complete in issue order, so exactly the loads issued
+            // after it may stay outstanding: this K-tile's 2 weight pieces, and the block issued behind the weight pieces of tap 0
+            // (during taps 0 and 1: it sits between weight tiles kt + 1 and kt + 2 of tap 1)
+            if (kt_ + 2 < p.nkt) {
+                if (cur_tap <= 1 && cur_cb + 1 < p.ncblk) {
+                    if (h_npieces == 7) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (++cur_tap == 9) {
+                cur_tap = 0;
+                ++cur_cb;
+            }
+        };
+        if (!late) {
+            for (int kt = 0; kt < p.nkt; ++kt) {
+                read_frags(stage, kt);
+                halo_issue(kt);
+                mma_group(0);
+                mma_group(1);
+                fold(kt);
+                halo_wait(kt);
+                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+            }
+        } else {
+            for (int kt = 0; kt < p.nkt; ++kt) {
+                if (kt > 0) {
+                    mma_group(0);                           // tile kt-1: its 16 fragments were read before the last barrier
+                    mma_group(1);
+                    fold(kt - 1);
+                }
+                read_frags(stage, kt);
+                halo_issue(kt);
+                halo_wait(kt);
+                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
+            }
+            mma_group(0);
+            mma_group(1);
+            fold(p.nkt - 1);
+        }
+    } else if constexpr (VAR == 6 && M16 && do_mma && do_load) {
         // VAR 6: ping-pong (as 3) with the LDS-DMA pieces spread through each wave's OWN matrix segment
         if (!late) {
             for (int kt = 0; kt < p.nkt; ++kt) {
@@ -1771,17 +1921,18 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
-template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false>
+template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false, bool HALO = false>
 int launch_h2(const H2Args& a, hipStream_t s) {
-    auto kern = h2_kernel<MODE, DBG, VAR, NPROD, M16, CBM, LSTM>;
+    auto kern = h2_kernel<MODE, DBG, VAR, NPROD, M16, CBM, LSTM, HALO>;
+    constexpr int lds = HALO ? HALO_LDS : HNSTAGE * HSTAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HSTAGE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int64_t grid = sp_cdiv(a.M, HBM) * a.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), HNSTAGE * HSTAGE, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, a);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -1861,6 +2012,13 @@ extern "C" int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* 
     hipLaunchKernelGGL(split2_wT_kernel, dim3(blocks), dim3(256), 0, s, w, Co, taps, Ci, amax, (uint16_t*)out, scale_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+
+// the halo build of h2_kernel applies: 3x3, stride 1, dilation 1, "same" padding on a 64-pixel-wide map whose images are whole
+// numbers of 256-pixel tiles (so a tile is 4 full image rows of one image)
+static bool halo_applies(const sp_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->Wo == HALO_W && d->Wi == HALO_W &&
+           d->Hi == d->Ho && (d->Ho * d->Wo) % HBM == 0 && d->Kc % 32 == 0;
 }
 
 static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws, const float* w_scale,
@@ -1951,6 +2109,8 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
         return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
     // product schedules: 16x16x32 MFMAs, ping-pong halves with s_setprio; channel-block-major K order with the fragment reads ahead
     // of the LDS-DMA issue block where that order is defined, tap-major otherwise
+    if (cbm_ok && halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1)      // one halo'd activation block per channel block for all 9 taps
+        return f ? launch_h2<0, 0, 5, 3, true, true, false, true>(a, st) : launch_h2<1, 0, 5, 3, true, true, false, true>(a, st);
     if (cbm_ok) return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);
     return f ? launch_h2<0, 0, 3, 3, true>(a, st) : launch_h2<1, 0, 3, 3, true>(a, st);
 }
@@ -2017,6 +2177,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);
+    if (halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1) return launch_h2<0, 0, 5, 3, true, true, true, true>(a, st);
     return launch_h2<0, 0, 5, 3, true, true, true>(a, st);
 }
 

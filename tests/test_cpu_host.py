@@ -254,3 +254,36 @@ def test_kernel_sources_read_no_environment():
         lib.sp_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
         assert lib.sp_timing_build() == 0
         assert lib.sp_set_tuning(b"h2_dbg", 1) == -1 and lib.sp_set_tuning(b"amax_reset", 1) == 0
+
+
+def test_halo_block_swizzle_is_bank_conflict_free_for_every_base():
+    """csrc/conv_f16x2.hip halo_swz: a ds_read_b128 is served in lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} per 32-lane half;
+    the fragment rows of the halo activation block start at an arbitrary pixel slot (image row, tap row and tap column shift it), so
+    the chunk swizzle must give 16 distinct 16-byte bank slots for EVERY base.  Enumerated here for bases 0..599: the halo swizzle
+    has no conflict, the ring's swizzle (made for bases that are multiples of 16) conflicts on 3/4 of the groups."""
+    def banks(slot, chunk, swz):
+        addr = slot * 128 + ((chunk ^ swz(slot)) * 16)
+        return {((addr // 4) + k) % 64 for k in range(4)}
+    g1 = [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27]
+    g2 = [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]
+    groups = [g1, g2, [x + 32 for x in g1], [x + 32 for x in g2]]
+
+    def conflicts(bases, swz):
+        bad = 0
+        for base in bases:
+            for pl in range(2):
+                for g in groups:
+                    used = set()
+                    for lane in g:
+                        l16, g4 = lane & 15, lane >> 4
+                        bs = banks(base + l16, (g4 >> 1) * 4 + pl * 2 + (g4 & 1), swz)
+                        if used & bs:
+                            bad += 1
+                            break
+                        used |= bs
+        return bad
+    halo = lambda s: ((s >> 1) & 3) << 1
+    ring = lambda s: (s >> 1) & 7
+    assert conflicts(range(600), halo) == 0
+    assert conflicts(range(0, 256, 16), ring) == 0            # the ring's fragment rows start at multiples of 16
+    assert conflicts(range(600), ring) > 3000

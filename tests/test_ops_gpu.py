@@ -43,6 +43,11 @@ CONV_CASES = [
     (2, 14, 18, 128, 288, 3, 1, 1, 1, True, False),      # Ci % 128 == 0: exercises the split-scheme wgrad (tr reads)
     (3, 9, 13, 256, 64, 3, 1, 2, 2, False, False),
     (2, 16, 20, 128, 256, 1, 2, 0, 1, False, False),
+    # 64-pixel-wide maps: the halo build of h2_kernel (one activation block with a one-pixel halo per channel block for all 9 taps);
+    # tiles at the top / bottom of an image, ragged output-channel tiles, several images
+    (3, 8, 64, 96, 160, 3, 1, 1, 1, True, True),
+    (2, 4, 64, 32, 64, 3, 1, 1, 1, False, False),
+    (1, 12, 64, 64, 288, 3, 1, 1, 1, False, False),
 ]
 
 
@@ -194,14 +199,16 @@ def test_maxpool_ceil_with_ties(hw):
     _close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-6, "dx")
 
 
-@pytest.mark.parametrize("fused", [False, True, "epilogue", "epilogue_planes"])
+@pytest.mark.parametrize("fused", [False, True, "epilogue", "epilogue_planes", "epilogue_w64"])
 def test_lstm_cell_and_gate_conv(fused):
     """fused=False: rank-1 gate terms accumulated by the batched GEMM of gate_conv; fused=True: plain h-conv + lstm_cell_rank1
     (rank-1 terms inside the pointwise kernel; 135 pixels = 2 full 64-pixel tiles + a tail: the path of map sizes whose pixel
     count is no multiple of 256); "epilogue": the whole cell as the epilogue of the h-gate conv (sp_gateconv_lstm_f16x2, the
     path of the 40x64 benchmark map; 3 samples x 256 pixels, 96 channels = 3 channel tiles of the gathered weight rows)"""
     from scanpaths_amd import functional as F
-    B, Hm, Wm, C, S = (3, 16, 16, 96, 2) if str(fused).startswith("epilogue") else (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
+    # "epilogue_w64": the same on a 64-pixel-wide map (8 x 64, two tiles per sample): the halo build of the kernel, the benchmark's
+    B, Hm, Wm, C, S = (2, 8, 64, 64, 2) if fused == "epilogue_w64" else (3, 16, 16, 96, 2) if str(fused).startswith("epilogue") \
+        else (2, 9, 15, 64, 2) if fused else (2, 6, 8, 32, 2)
     KP = 20
     h, c = _rand(B, C, Hm, Wm, seed=24), _rand(B, C, Hm, Wm, seed=25)
     xg = _rand(B, 4 * C, Hm, Wm, seed=26)
@@ -236,7 +243,7 @@ def test_lstm_cell_and_gate_conv(fused):
         parts.append(F.gemm(seg[s], wflat, None, "nk").view(B, 3 * C, 9))
     wc = torch.cat(parts + [torch.zeros(B, 3 * C, KP - 9 * S, device=dev)], 2)
     spcol = F.im2col3x3(spg, KP)
-    if fused == "epilogue":
+    if fused in ("epilogue", "epilogue_w64"):
         hn, cn = F.gateconv_lstm(hg_, whg, xgg, cg_, spcol, wc, {})
         assert float(hn._sp_amax[1]) == float(hn.abs().max())          # fused max|h| hint (float bits in slot 1)
     elif fused == "epilogue_planes":
