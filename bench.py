@@ -41,6 +41,8 @@ KERNEL_NAMES = {
     "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)", "b3_dgrad": "b3_kernel<dgrad>", "b3_wgrad": "w3_kernel",
     "igemm_fwd": "igemm_kernel<fwd> (fp32 MFMA)", "igemm_dgrad": "igemm_kernel<dgrad> (fp32 MFMA)", "wgrad": "wgrad_kernel (fp32 MFMA)"}
 PMC_PREFIX = {"h2_fwd": "h2_kernel<0,", "h2_dgrad": "h2_kernel<1,", "h2_wgrad": "hw_kernel"}      # kernel-name prefixes in profiles/*_pmc_hconv.json
+# the forward launches of the h-gate shape are (15 of 16) the ConvLSTM-fused variant: its own PMC entry (7th template argument true)
+PMC_FUSED_FWD = ", true, true, true"
 
 
 def parse():
@@ -308,10 +310,12 @@ def main():
         # the committed PMC passes were taken on the h-gate conv shape (tools/bench_hconv.py: M = 81920, N = 2048, K = 4608)
         if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_PREFIX and \
                 (dom_key[1], dom_key[2], dom_key[3]) == (81920, 2048, 4608):
-            for fn in ("r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
+            for fn in ("r03_pmc_hconv.json", "r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
-                    key = [k for k in pmc if k.startswith(PMC_PREFIX[kind])][0]
+                    keys = [k for k in pmc if k.startswith(PMC_PREFIX[kind])]
+                    fused = [k for k in keys if PMC_FUSED_FWD in k]
+                    key = fused[0] if (kind == "h2_fwd" and fused) else keys[0]
                     traffic, traffic_src = round(pmc[key]["hbm_side_bytes_per_launch"]), fn
                     break
                 except Exception:
@@ -331,7 +335,8 @@ def main():
             "traffic": traffic,
             "traffic_note": (f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{traffic_src}); "
                              "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.75 GB "
-                             "(weight gradient) / 1.05 GB (forward)") if traffic else "no committed PMC pass for this kernel/shape",
+                             "(weight gradient) / 1.05 GB (forward; the ConvLSTM-fused forward also reads the x-gates and writes gates, c, h "
+                             "and h's split operand: 2.9 GB)") if traffic else "no committed PMC pass for this kernel/shape",
             "kernel": f"{KERNEL_NAMES.get(kind, kind)}: implicit GEMM M={M} N={N} K={K} ({dom_key[4]} taps) -- the timed GEMM "
                       "kind+shape with the largest total time",
             "achieved_note": "ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMM the reference computes) / HIP-event launch time on the "
