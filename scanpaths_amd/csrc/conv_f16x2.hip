@@ -40,6 +40,7 @@ constexpr int HALO_LDS = 2 * HALO_A_BYTES + 3 * HB_BYTES;                       
 constexpr int HW_DEFAULT_MAP = 0;                // sp_set_tuning("hw_map", 1): aligned-rounds workgroup order of hw_kernel
 constexpr int H2_DEFAULT_VARIANT = 17;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
 constexpr int HW_DEFAULT_VARIANT = 10;           // schedule variant of hw_kernel
+constexpr int TWOBAR_DEFAULT = 0;                // second barrier per K-tile (strictly alternating matrix segments), h2_kernel / hw_kernel
 
 struct H2Args {
     const uint16_t* X;    // [pixels][Kc/16][2][16]
@@ -77,6 +78,7 @@ struct H2Args {
     double* st_partial;
     float* st_mm;
     int chunk_kt;           // K-tiles per chunk of the two-level accumulation (power of two; HCHUNK_KT)
+    int twobar;             // 1: a second barrier per K-tile between the two halves' matrix segments (see the K loop)
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
@@ -655,10 +657,17 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 ++cur_cb;
             }
         };
+        // p.twobar: a SECOND barrier per K-tile, between the late half's matrix segment (tile kt-1) and the early half's (tile kt).
+        // With one barrier the early half starts its 48 MFMAs as soon as its reads and load issues are done -- in the middle of the
+        // late half's matrix segment: the two streams interleave on the SIMD's one matrix pipe (each hand-over costs cycles against
+        // a 16-cycle MFMA: two waves issuing concurrently sustain ~21 cycles per MFMA), the late half's segment stretches to the end
+        // of the early half's and its own read / issue phase is then exposed before the barrier.  With the second barrier the
+        // phases alternate strictly: [late: MFMA(kt-1) | early: read(kt), issue] barrier [early: MFMA(kt) | late: read(kt), issue] barrier.
         if (!late) {
             for (int kt = 0; kt < p.nkt; ++kt) {
                 read_frags(stage, kt);
                 halo_issue(kt);
+                if (p.twobar) __builtin_amdgcn_s_barrier();
                 mma_group(0);
                 mma_group(1);
                 fold(kt);
@@ -672,6 +681,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     mma_group(1);
                     fold(kt - 1);
                 }
+                if (p.twobar) __builtin_amdgcn_s_barrier();
                 read_frags(stage, kt);
                 halo_issue(kt);
                 halo_wait(kt);
@@ -737,6 +747,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             if (VAR >= 2 && VAR != 5 && VAR != 7 && pre) issue_tile(prev_stage(stage));
             read_frags(stage, kt);
             if ((VAR == 5 || VAR == 7) && pre) issue_tile(prev_stage(stage));          // VAR 5 (= 3 with the fragment reads ahead of the issue block)
+            if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();                     // (see the halo loop)
             mma_group(0);
             mma_group(1);
             if (VAR < 2 && pre) issue_tile(prev_stage(stage));
@@ -767,6 +778,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 mma_group(1);
                 fold(kt - 1);
             }
+            if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();
             read_frags(stage, kt);
             if (pre) issue_tile(prev_stage(stage));
             wait_barrier(kt);
@@ -1325,6 +1337,7 @@ struct HWArgs {
     float alpha;
     int beta;
     uint32_t x_bytes, y_bytes;
+    int twobar;            // as H2Args
 };
 
 constexpr int HWA_ROW = 1024, HWB_ROW = 512;
@@ -1683,6 +1696,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                 read_group(stage, 0);
                 read_group(stage, 1);
                 if ((VAR == 4 || VAR == 5 || VAR == 6) && pre) issue_tile(prev_stage(stage));      // VAR 4 / 5 / 6 (5, 6: without s_setprio): fragment reads ahead of the LDS-DMA issue block
+                if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();      // second barrier: strictly alternating matrix segments (h2_kernel)
                 mma_group(0);
                 mma_group(1);
             }
@@ -1700,6 +1714,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                 mma_group(1);
                 fold(kt - 1);
             }
+            if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();
             read_group(stage, 0);
             read_group(stage, 1);
             if (VAR != 6 && pre) issue_tile(prev_stage(stage));
@@ -2031,6 +2046,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
     H2Args a{};
     a.chunk_kt = sp_tuning_get(SP_TUNE_H2_CHUNK, HCHUNK_KT);
+    a.twobar = sp_tuning_get(SP_TUNE_TWOBAR, TWOBAR_DEFAULT);
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
     a.sx = x_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * d->Ho * d->Wo;
@@ -2155,6 +2171,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (((uintptr_t)Hs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     H2Args a{};
     a.chunk_kt = sp_tuning_get(SP_TUNE_H2_CHUNK, HCHUNK_KT);
+    a.twobar = sp_tuning_get(SP_TUNE_TWOBAR, TWOBAR_DEFAULT);
     a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
     a.sx = h_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * P;
@@ -2193,6 +2210,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     if (d->Ci % 16 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
     if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
     HWArgs a;
+    a.twobar = sp_tuning_get(SP_TUNE_TWOBAR, TWOBAR_DEFAULT);
     a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;
     a.sx = x_scale; a.sy = y_scale;
     a.M = (int64_t)d->N_img * d->Ho * d->Wo;

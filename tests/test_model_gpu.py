@@ -470,7 +470,7 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     for k, v in pred.items():
         bars = _check("bench_path_320x512_train_T16", "train/" + k, v, g, report, T, None, noise_x=TAME_X, rows=rows)
         assert len(bars) == T, (k, len(bars))
-        if k == "all_actions_prob":
+        if k == "all_actions_prob" and not any(r.get("failed") for r in rows):
             n, tot = _check_argmax(v, g["ref64/train/" + k], bars)
             nargmax, ntot = nargmax + n, ntot + tot
     l64, l32 = losses["ref64/"], losses["ref32/"]
@@ -507,8 +507,10 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
                  "worst_grad_err_over_oracle32": worst, "worst_grad_param": worst_name, "fusion_counts": got_counts,
                  "relu_kink_affected_params": kinked})
     del pred, loss
-    # eval mode (probabilities; both heads)
-    model.eval()
+    # eval mode (probabilities; both heads) -- on a FRESH model: the train-mode forward above has updated the BatchNorm running
+    # statistics of `model`, the oracle's eval forward uses the initial ones
+    del model
+    model = _build(meta, Hm, Wm).eval()
     F.reset_fusion_counts()
     with torch.no_grad():
         pe = model(bd["images"], bd["attention_maps"])
@@ -522,10 +524,13 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
         bars = _check("bench_path_320x512_eval_T16", "eval/" + k, v, g, report, T, None, noise_x=TAME_X, rows=rows)
         assert len(bars) >= T // 2, (k, len(bars))
         eval_steps = min(eval_steps, len(bars))
-        if k.endswith("all_actions_prob"):
+        if k.endswith("all_actions_prob") and not any(r.get("failed") for r in rows):
             n, tot = _check_argmax(v, g["ref64/eval/" + k], bars)
             nargmax, ntot = nargmax + n, ntot + tot
     _record(rows)
+    for r in rows:
+        if r.get("failed"):
+            print("FAILED ROW", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in r.items() if k != "fusion_counts"})
     worst_row = max((r for r in rows if r["key"] != "loss"), key=lambda r: r["err"] / r["bar"])
     print(f"bench path 320x512 T=16 (tame, {NB} images, bs-32 kernel decisions): {len(rows) - 1} (output, step) pairs; worst err/bar "
           f"{worst_row['err'] / worst_row['bar']:.2f} ({worst_row['key']} t={worst_row['step']}: err {worst_row['err']:.2e}, oracle32 noise "
