@@ -9,5 +9,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- py
 f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summarize_prof.py "${f%_kernel_trace.csv}" $O/r03 > $O/summ_bench.log 2>&1
 find $O -name "*trace.csv" -delete
 python3 tools/bench_backbone.py > $O/backbone.json 2> $O/backbone.err
+python3 examples/train_synthetic.py > $O/example.log 2>&1; echo "example rc=$?" >> $O/example.log
+python3 bench.py --steps 3 --warmup 1 --cpu-batch 4 --cpu-threads 128 --cpu-steps 2 > $O/cpu_baseline_b4_t128.json 2> $O/cpu_b4_t128.err
+python3 bench.py --steps 3 --warmup 1 --cpu-batch 4 --cpu-threads 32 --cpu-steps 2 > $O/cpu_baseline_b4_t32.json 2> $O/cpu_b4_t32.err
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-tail -n 4 $O/pytest.log; cut -c1-300 $O/backbone.json; cut -c1-260 $O/bench.json
+tail -n 4 $O/pytest.log; tail -n 3 $O/example.log; cut -c1-300 $O/backbone.json; cut -c1-260 $O/bench.json
