@@ -259,99 +259,6 @@ __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __rest
     }
 }
 
-// The same slabs with far fewer re-reads of h (used when each axis has <= 3 border classes, i.e. always for the model's maps):
-// grid (11 window rows vy, C/64 channel chunks, B), 176 threads = 16 channel quads x 11 window columns vx.  Thread (c4, vx) walks the
-// sites: for a site row sy (one y-class) it loads h[b][5sy-4+vy][5sx-4+vx][its 4 channels] for the site columns four at a time (four
-// independent 16-byte loads in flight; the 16 quads of a pixel are 256 contiguous bytes), adds w * h into the row's x-class sums and
-// folds them into the accumulators of the row's y-class.  A block touches 8 image rows of a 64-channel chunk (131 KB) once per head
-// pair; the (sx, vx) pairs that share a pixel hit L2: h is read ~2x per launch instead of 18x.  Same summation order per slab entry
-// as drt_bwd_weight_kernel (sites ascending), bit-identical slabs.
-constexpr int DWX = 3;      // border classes per axis held in registers (first / interior / last); more: the one-block-per-entry kernel
-__global__ __launch_bounds__(176) void drt_bwd_weight_rows_kernel(const float* __restrict__ dD, const float* __restrict__ h, int B,
-                                                                  int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
-                                                                  float* __restrict__ slab) {
-    const int vy = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
-    const int c4 = chunk * 16 + (threadIdx.x & 15), vx = threadIdx.x >> 4;          // vx 0..10
-    const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;
-    if (c4 >= C4) return;
-    const f32x4* H4 = reinterpret_cast<const f32x4*>(h) + (int64_t)b * Hm * Wm * C4 + c4;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int i0 = 0; i0 < nsel; i0 += 2) {
-        const bool two = i0 + 1 < nsel;
-        const float* g0 = dD + ((int64_t)i0 * B + b) * S;
-        const float* g1 = dD + ((int64_t)(two ? i0 + 1 : i0) * B + b) * S;
-        f32x4 acc0[DWX][DWX], acc1[DWX][DWX];
-#pragma unroll
-        for (int yc = 0; yc < DWX; ++yc)
-#pragma unroll
-            for (int xc = 0; xc < DWX; ++xc) {
-                acc0[yc][xc] = zero;
-                acc1[yc][xc] = zero;
-            }
-        for (int sy = 0; sy < ay.n; ++sy) {
-            const int qy = 5 * sy - 4 + vy;
-            if ((unsigned)qy >= (unsigned)Hm) continue;
-            const int ycls = ay.cls[sy];
-            const f32x4* row = H4 + (int64_t)qy * Wm * C4;
-            f32x4 t0[DWX], t1[DWX];
-            bool hit[DWX];
-#pragma unroll
-            for (int xc = 0; xc < DWX; ++xc) {
-                t0[xc] = zero;
-                t1[xc] = zero;
-                hit[xc] = false;
-            }
-            for (int sx0 = 0; sx0 < ax.n; sx0 += 4) {
-                f32x4 a[4];
-                float w0[4], w1[4];
-                int xc4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int sx = sx0 + u, qx = 5 * sx - 4 + vx;
-                    const bool ok = sx < ax.n && (unsigned)qx < (unsigned)Wm;
-                    a[u] = ok ? row[(int64_t)qx * C4] : zero;
-                    w0[u] = ok ? g0[sy * ax.n + sx] : 0.f;
-                    w1[u] = ok ? g1[sy * ax.n + sx] : 0.f;
-                    xc4[u] = ok ? ax.cls[sx] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int xc = 0; xc < DWX; ++xc)
-                        if (xc == xc4[u]) {
-                            t0[xc] += w0[u] * a[u];
-                            t1[xc] += w1[u] * a[u];
-                            hit[xc] = true;
-                        }
-            }
-            // fold the row's x-class sums into the accumulators of its y-class.  (Keeping the per-site order of the one-block-per-
-            // entry kernel would need the sums to be added site by site; a row's sites of one class are summed first here, so
-            // entries that collect several rows agree with that kernel to rounding, not bitwise.)
-#pragma unroll
-            for (int yc = 0; yc < DWX; ++yc)
-                if (yc == ycls) {
-#pragma unroll
-                    for (int xc = 0; xc < DWX; ++xc)
-                        if (hit[xc]) {
-                            acc0[yc][xc] += t0[xc];
-                            acc1[yc][xc] += t1[xc];
-                        }
-                }
-        }
-        f32x4* O40 = reinterpret_cast<f32x4*>(slab) + (((int64_t)b * nsel + i0) * ncls * NV + vy * 11 + vx) * C4 + c4;
-        f32x4* O41 = O40 + (int64_t)ncls * NV * C4;
-#pragma unroll
-        for (int yc = 0; yc < DWX; ++yc)
-#pragma unroll
-            for (int xc = 0; xc < DWX; ++xc)
-                if (yc < ay.ncls && xc < ax.ncls) {
-                    const int64_t off = (int64_t)(yc * ax.ncls + xc) * NV * C4;
-                    O40[off] = acc0[yc][xc];
-                    if (two) O41[off] = acc1[yc][xc];
-                }
-    }
-}
-
 // dW11[k] = sum of the slabs whose source head is k, in (b, i) order.  one thread per float4 of dW11.
 __global__ __launch_bounds__(256) void drt_slab_reduce_kernel(const float* __restrict__ slab, const int* __restrict__ hmap,
                                                               int B, int nsel, int nheads, int64_t per_head4,
@@ -478,12 +385,8 @@ extern "C" int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, cons
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || nheads < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
     const int ncls = ay.ncls * ax.ncls;
-    if (ay.ncls <= DWX && ax.ncls <= DWX)
-        hipLaunchKernelGGL(drt_bwd_weight_rows_kernel, dim3(11, (C / 4 + 15) / 16, B), dim3(176), 0, (hipStream_t)stream, dDpre, h, B,
-                           C / 4, nsel, ncls, ay, ax, (float*)workspace);
-    else
-        hipLaunchKernelGGL(drt_bwd_weight_kernel, dim3(NV * ncls, B, (nsel + 1) / 2), dim3(128), 0, (hipStream_t)stream, dDpre, h, B, C / 4,
-                           nsel, ncls, ay, ax, (float*)workspace);
+    hipLaunchKernelGGL(drt_bwd_weight_kernel, dim3(NV * ncls, B, (nsel + 1) / 2), dim3(128), 0, (hipStream_t)stream, dDpre, h, B, C / 4,
+                       nsel, ncls, ay, ax, (float*)workspace);
     SP_LAUNCH_CHECK();
     const int64_t per_head4 = (int64_t)ncls * NV * (C / 4);
     hipLaunchKernelGGL(drt_slab_reduce_kernel, dim3(ew_grid(nheads * per_head4)), dim3(256), 0, (hipStream_t)stream,

@@ -696,3 +696,45 @@ def test_checkpoint_resume_is_bit_identical_and_adam_format_compatible(tmp_path)
     for p in m3.parameters():
         assert torch.allclose(o3.state[p]["exp_avg"], ref.state[ref.param_groups[0]["params"][i]]["exp_avg"])
         i += 1
+
+
+def test_coco_per_gpu_shard_of_config4_trains_reproducibly():
+    """BASELINE.json config 4's per-GPU shard (COCO_Search18 visual search: global bs 64 over 4 GPUs = bs 16 per rank, 320x512, 6 decode
+    steps, per-category heads selected by task id): two training steps from the same state are bit-identical (fixed-order reductions,
+    no float atomics in the per-sample head path either), finite, only the heads of the categories present are stepped (the
+    reference's int(tasks[index]) head selection, COCO_Search18/models/baseline_attention_multihead.py:285-288).  (The 4-rank
+    exchange itself is covered by tests/test_ddp_gloo.py's 4-rank bs-64 sharding test and tests/test_ddp_gpu.py.)"""
+    from scanpaths_amd.models.baseline_attention_multihead import baseline
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    T, B = 6, 16
+    b = {k: v.to(DEV) for k, v in make_batch("COCO_Search18", B, 320, 512, T, seed=14).items()}
+    b["tasks"] = torch.tensor([0, 3, 3, 7, 7, 7, 12, 12, 0, 17, 17, 3, 5, 5, 5, 9], device=DEV)
+    present = sorted(set(b["tasks"].tolist()))
+
+    def build():
+        m = baseline(convLSTM_length=T, map_width=64, map_height=40)
+        fill_module(m, 14, family="tame")
+        return m.to(DEV).train()
+
+    def run():
+        m = build()
+        opt = FlatAdam(m.parameters(), lr=1e-4, weight_decay=5e-4, clip=12.5, conditional_params=True, reference_zero_grad=True)
+        out = []
+        for _ in range(2):
+            opt.zero_grad()
+            pred = m(b["images"], b["attention_maps"], b["tasks"])
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+            loss.backward()
+            out.append((float(loss), float(opt.step())))
+        stepped = sorted({n.split(".")[1] for n, p in m.named_parameters()
+                          if n.startswith("object_sal_layer.") and float(opt.state[p]["step"]) > 0})
+        return out, opt.flat_p.detach().clone(), stepped, m
+
+    o1, p1, heads, m = run()
+    o2, p2, _, _ = run()
+    assert o1 == o2 and torch.equal(p1, p2)
+    assert all(math.isfinite(v) for pair in o1 for v in pair) and torch.isfinite(p1).all()
+    assert heads == sorted(m.int2object[t] for t in present), (heads, present)
