@@ -346,6 +346,9 @@ def main():
             "mfma_products_per_fma": nprod,
             "mfma_pipe_frac": round(dom["tflops"] * nprod / peak, 4) if nprod else None,
             "mfma_pipe_note": "issued MFMA FLOPs / peak = frac x products per algorithmic FMA (matrix-pipe occupancy of the scheme)",
+            "practical_ceiling_note": "profiles/r03_wave_tile_probe.log: an idealised loop of the kernels' structure (same MFMAs, fragment reads, "
+                                      "LDS-DMA pieces; no epilogue, no address arithmetic) runs 2.3-2.5 ms per launch on constant and 3.3-3.55 ms on random "
+                                      "fp16 operands (DVFS under switching power); the shipped kernels run at 3.2-3.8 ms, i.e. at the ceiling of their structure",
             "timed_gemms": by_kind,
             "all_big_gemms_ms_per_step": round(total_timed_ms, 2),
             "all_big_gemms_tflops": round(sum(d["flops_per_launch"] * d["launches"] for d in summ.values())

@@ -219,6 +219,109 @@ __global__ __launch_bounds__(256, 1) void probe4(float* out, int nkt) {
     if (s == 123.456f) out[threadIdx.x] = s;
 }
 
+// ---- C: hw_kernel's structure: K = pixels, tiles staged pixel-major ([32 pixels][256 co] / [32 pixels][128 ci] rows of 1024 / 512 B),
+// fragments by ds_read_b64_tr_b16 pairs (32 LDS instructions per wave and K-tile instead of 16), same MFMAs, ping-pong, 6 LDS-DMA pieces
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 tr_pair(const unsigned char* base, int off0, int off1) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + off0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + off1));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ int rot4p(int q) { return 2 * (q & 1) + 8 * (q >> 1); }
+__device__ __forceinline__ int swz16p(int r) { return rot4p(r & 3) + 4 * ((r >> 3) & 1); }
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void probe_hw(float* out, int nkt, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool constant = nkt < 0;
+    nkt = constant ? -nkt : nkt;
+    fill_lds(smem, 512, constant);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
+    int offA[4][2][2], offB[4][2][2];
+    for (int i = 0; i < 4; ++i) for (int pl = 0; pl < 2; ++pl) for (int s2 = 0; s2 < 2; ++s2) {
+        const int row = 8 * kg + q;
+        const int pa = (((wm << 2) | (pl << 1) | (pp >> 1)) ^ swz16p(row));
+        offA[i][pl][s2] = row * 1024 + pa * 16 + (pp & 1) * 8 + i * 256 + s2 * 4 * 1024;
+        const int pb = ((((i & 1) << 3) | (wn << 2) | (pl << 1) | (pp >> 1)) ^ swz16p(row));
+        offB[i][pl][s2] = HA + row * 512 + pb * 16 + (pp & 1) * 8 + (i >> 1) * 256 + s2 * 4 * 512;
+    }
+    f32x4 acc[4][4], tot[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    f16x8 af[4][2], bf[4][2];
+    auto rd = [&](int stage) {
+        const unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = tr_pair(st, offA[i][pl][0], offA[i][pl][1]);
+                bf[i][pl] = tr_pair(st, offB[i][pl][0], offB[i][pl][1]);
+            }
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    auto fold = [&](int kt) {
+        if ((kt & 7) == 7)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; }
+    };
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    uint32_t gpos = (uint32_t)blockIdx.x * 1572864u;
+    auto issue = [&](int stage_) {
+        if constexpr (MODE == 1) {
+            unsigned char* st = smem + stage_ * STAGE;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) GLDS16(src + ((gpos + j * 8192u + lane_off) & srcmask), st + (wave + 8 * j) * 1024);
+            gpos += 6 * 8192u;
+        }
+    };
+    auto wait_loads = [&](bool more) {
+        if constexpr (MODE == 1) { if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    };
+    const bool late = wave >= 4;
+    int stage = 0;
+    auto prev = [](int st_) { return st_ == 0 ? 2 : st_ - 1; };
+    if constexpr (MODE == 1) { issue(0); issue(1); wait_loads(true); __builtin_amdgcn_s_barrier(); }
+    if (!late) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            rd(stage);
+            if (kt + 2 < nkt) issue(prev(stage));
+            mm(); fold(kt);
+            wait_loads(kt + 2 < nkt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt > 0) { mm(); fold(kt - 1); }
+            rd(stage);
+            if (kt + 2 < nkt) issue(prev(stage));
+            wait_loads(kt + 2 < nkt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        mm(); fold(nkt - 1);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r] + acc[i][j][r];
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+
 int main() {
     float* d; hipMalloc(&d, 4096);
     unsigned char* src; const uint32_t maxbytes = 1024u << 20; hipMalloc(&src, (size_t)maxbytes + (1 << 20)); { std::vector<uint32_t> hbuf((size_t)(maxbytes >> 2) + (1 << 18)); uint32_t x = 12345u; for (auto& v : hbuf) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = (x & 0x8fff8fffu) | 0x30003000u; } hipMemcpy(src, hbuf.data(), hbuf.size() * 4, hipMemcpyHostToDevice); }
@@ -230,11 +333,14 @@ int main() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe_hw<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe_hw<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe4), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double mfma_cycles_per_simd = 20.0 * 144 * 96 * 16;      // 20 workgroups per CU, 96 MFMAs per K-tile per SIMD, 16 cycles each
-    const char* names[6] = {"8 waves 64x64 ping-pong, no loads          ", "8 waves, 6 LDS-DMA pieces / K-tile, linear  ", "8 waves, 2 LDS-DMA pieces / K-tile, linear  ",
-                            "8 waves, conv gather, pixel rows 2 KiB apart", "8 waves, conv gather, pixel rows 8 KiB apart", "4 waves 128x64 double-buffer, no loads      "};
+    const char* names[8] = {"8 waves 64x64 ping-pong, no loads          ", "8 waves, 6 LDS-DMA pieces / K-tile, linear  ", "8 waves, 2 LDS-DMA pieces / K-tile, linear  ",
+                            "8 waves, conv gather, pixel rows 2 KiB apart", "8 waves, conv gather, pixel rows 8 KiB apart", "4 waves 128x64 double-buffer, no loads      ",
+                            "hw structure (transposed reads), no loads   ", "hw structure, 6 LDS-DMA pieces / K-tile      "};
     uint32_t srcmask = (1024u << 20) - 1;
     auto launch = [&](int which) {
         const uint32_t wsrc = 900u << 20;           // weights: a 2.4 MiB slice re-read by every workgroup
@@ -244,11 +350,13 @@ int main() {
             case 2: hipLaunchKernelGGL(probe8<2>, dim3(grid), dim3(512), lds, 0, d, nkt, src, (64u << 20) - 1, 0u, wsrc); break;
             case 3: hipLaunchKernelGGL(probe8<4>, dim3(grid), dim3(512), lds, 0, d, nkt, src, srcmask, 2048u, wsrc); break;
             case 4: hipLaunchKernelGGL(probe8<4>, dim3(grid), dim3(512), lds, 0, d, nkt, src, srcmask, 8192u, wsrc); break;
-            default: hipLaunchKernelGGL(probe4, dim3(grid), dim3(256), lds, 0, d, nkt); break;
+            case 5: hipLaunchKernelGGL(probe4, dim3(grid), dim3(256), lds, 0, d, nkt); break;
+            case 6: hipLaunchKernelGGL(probe_hw<0>, dim3(2304), dim3(512), lds, 0, d, nkt < 0 ? -320 : 320, src, (64u << 20) - 1); break;
+            default: hipLaunchKernelGGL(probe_hw<1>, dim3(2304), dim3(512), lds, 0, d, nkt < 0 ? -320 : 320, src, (64u << 20) - 1); break;
         }
     };
     for (int rep = 0; rep < 4; ++rep)
-        for (int which = 0; which < 6; ++which) {
+        for (int which = 0; which < 8; ++which) {
             const bool constant = (rep & 1) == 0;
             src = constant ? srcc : srcr;
             nkt = constant ? -144 : 144;
