@@ -33,7 +33,7 @@ __device__ __forceinline__ void fill_lds(unsigned char* smem, int nthreads, bool
 // MODE 0: no global loads.  MODE 1: 6 LDS-DMA pieces per lane per K-tile (the ring of h2_kernel: tile kt+2 issued in K-tile kt, counted
 // vmcnt).  MODE 2: 2 pieces per K-tile (the halo build's steady state).  MODE 3: 6 pieces by global_load_dwordx4 into registers, written
 // to LDS by ds_write_b128 one K-tile later.  Sources: a 64 MiB buffer, every workgroup its own sliding window (L2 / MALL resident).
-template <int MODE>
+template <int MODE, bool EPI = false>
 __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsigned char* src, uint32_t srcmask, uint32_t stride4, uint32_t wsrc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bool constant = nkt < 0;
@@ -150,6 +150,26 @@ __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsi
             stage = stage == 2 ? 0 : stage + 1;
         }
         mm(); fold(nkt - 1);
+    }
+    if constexpr (EPI) {
+        // h2_kernel's epilogue: the wave's 64x64 tile through its private 17 KB slice of the idle ring, float4 stores, 256 B per row
+        float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 68);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(i * 16 + 4 * g4 + r) * 68 + j * 16 + l16] = tot[i][j][r] + acc[i][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int cq4 = lane & 15, rsub = lane >> 4;
+        const int64_t tile = blockIdx.x;                       // [tiles][256 rows][128 cols] fp32: 128 KB per workgroup
+        float* dst0 = out + tile * (256 * 128) + (wm * 64) * 128 + wn * 64 + 4 * cq4;
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int row = ps * 4 + rsub;
+            *reinterpret_cast<float4*>(dst0 + row * 128) = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
+        }
+        return;
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r] + acc[i][j][r];
@@ -322,6 +342,120 @@ __global__ __launch_bounds__(512, 2) void probe_hw(float* out, int nkt, const un
     if (s == 123.456f) out[threadIdx.x] = s;
 }
 
+// ---- D: persistent short-K kernel: one workgroup per CU walks its tiles; the 3-stage ring runs ACROSS tile boundaries (the first two
+// K-tiles of the next tile are in flight while the current tile finishes), every wave stores its 64x64 result through a private 2 KB
+// staging slice (8 rows per pass) so the epilogue of one half overlaps the other half's next K-tile.  NKT K-tiles per tile.
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void probe_persist(float* out, int ntiles, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_lds(smem, 512, false);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, g4 = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = HA + (wn * 64 + l16) * 128 + pos * 16;
+    }
+    f32x4 acc[4][4];
+    f16x8 af[4][2], bf[4][2];
+    auto zero = [&]() { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; };
+    zero();
+    auto rd = [&](int stage) {
+        const unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + i * 16 * 128);
+                bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + i * 16 * 128);
+            }
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    float* stg = reinterpret_cast<float*>(smem + 3 * STAGE) + wave * 512;          // 2 KB per wave behind the ring
+    auto epilogue = [&](int tile) {
+        const int cq4 = lane & 15, rsub = lane >> 4;
+        float* dst0 = out + (int64_t)tile * (256 * 128) + (wm * 64) * 128 + wn * 64 + 4 * cq4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int hpass = 0; hpass < 2; ++hpass) {      // rows i*16 + 4*g4 + r: pass = the 8 rows with g4 in {2*hpass, 2*hpass+1}
+                if ((g4 >> 1) == hpass) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stg[((g4 & 1) * 4 + r) * 64 + j * 16 + l16] = acc[i][j][r];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // 8 rows x 64 floats = 128 float4: two per lane
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = lane + 64 * u, row8 = e >> 4, c4 = e & 15;
+                    const int row = i * 16 + 8 * hpass + row8;
+                    *reinterpret_cast<float4*>(dst0 - 4 * cq4 + row * 128 + 4 * c4) = *reinterpret_cast<const float4*>(stg + row8 * 64 + 4 * c4);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        zero();
+    };
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * NKT;
+    int gi = 0;                                            // next global K-tile index to issue
+    auto issue = [&](int stage_) {
+        const int tl = (int)blockIdx.x + (gi / NKT) * (int)gridDim.x;
+        const uint32_t gpos = (uint32_t)tl * (uint32_t)(NKT * 49152) + (uint32_t)(gi % NKT) * 49152u;
+        unsigned char* st = smem + stage_ * STAGE;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) GLDS16(src + ((gpos + j * 8192u + lane_off) & srcmask), st + (wave + 8 * j) * 1024);
+        ++gi;
+    };
+    auto prev = [](int st_) { return st_ == 0 ? 2 : st_ - 1; };
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_setprio(1);
+    int stage = 0;
+    issue(0); if (total > 1) issue(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!late) {
+        for (int g = 0; g < total; ++g) {
+            rd(stage);
+            if (g + 2 < total) issue(prev(stage));
+            mm();
+            if (g % NKT == NKT - 1) epilogue((int)blockIdx.x + (g / NKT) * (int)gridDim.x);
+            if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    } else {
+        for (int g = 0; g < total; ++g) {
+            if (g > 0) {
+                mm();
+                if ((g - 1) % NKT == NKT - 1) epilogue((int)blockIdx.x + ((g - 1) / NKT) * (int)gridDim.x);
+            }
+            rd(stage);
+            if (g + 2 < total) issue(prev(stage));
+            if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        mm();
+        epilogue((int)blockIdx.x + ((total - 1) / NKT) * (int)gridDim.x);
+    }
+}
+
 int main() {
     float* d; hipMalloc(&d, 4096);
     unsigned char* src; const uint32_t maxbytes = 1024u << 20; hipMalloc(&src, (size_t)maxbytes + (1 << 20)); { std::vector<uint32_t> hbuf((size_t)(maxbytes >> 2) + (1 << 18)); uint32_t x = 12345u; for (auto& v : hbuf) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = (x & 0x8fff8fffu) | 0x30003000u; } hipMemcpy(src, hbuf.data(), hbuf.size() * 4, hipMemcpyHostToDevice); }
@@ -369,5 +503,46 @@ int main() {
             printf("[%s operands] %s: %.3f ms per launch (matrix pipe alone: %.3f ms at 2.4 GHz, %.3f at 2.0 GHz); %s\n", constant ? "constant" : "random  ", names[which], ms,
                    mfma_cycles_per_simd / 2.4e6, mfma_cycles_per_simd / 2.0e6, hipGetErrorString(hipGetLastError()));
         }
+    // ---- short-K lifecycle: 5120 workgroups x 4 K-tiles (the encoder's M = 327680, K = 128, N = 512 pointwise conv), operands streamed
+    //      from HBM (every workgroup its own 192 KB), with / without the 128 KB-per-workgroup epilogue (671 MB of output)
+    float* big; hipMalloc(&big, (size_t)5120 * 256 * 128 * 4);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const char* pn[4] = {"short K (4 K-tiles): loads + epilogue   ", "short K: loads, no epilogue             ", "short K: no loads, epilogue             ", "short K: neither                        "};
+    for (int rep = 0; rep < 2; ++rep)
+        for (int which = 0; which < 4; ++which) {
+            auto go = [&]() {
+                switch (which) {
+                    case 0: hipLaunchKernelGGL((probe8<1, true>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, (1024u << 20) - 1, 0u, 0u); break;
+                    case 1: hipLaunchKernelGGL((probe8<1, false>), dim3(grid), dim3(512), lds, 0, d, 4, srcr, (1024u << 20) - 1, 0u, 0u); break;
+                    case 2: hipLaunchKernelGGL((probe8<0, true>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, (1024u << 20) - 1, 0u, 0u); break;
+                    default: hipLaunchKernelGGL((probe8<0, false>), dim3(grid), dim3(512), lds, 0, d, 4, srcr, (1024u << 20) - 1, 0u, 0u); break;
+                }
+            };
+            go(); go();
+            hipEventRecord(e0);
+            for (int w = 0; w < 10; ++w) go();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+            printf("%s: %.1f us per launch = %.2f us per workgroup round (20 rounds); %s\n", pn[which], ms * 1e3, ms * 1e3 / 20, hipGetErrorString(hipGetLastError()));
+        }
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe_persist<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384);
+    // the operand footprint decides how much of the read stream the caches absorb (the real kernel re-reads each activation tile for
+    // 4 output-channel tiles: 220 MB from HBM out of 983 MB requested, PMC) -- sweep it for both structures
+    for (int fp = 0; fp < 3; ++fp) {
+        const uint32_t mask = ((fp == 0 ? 1024u : fp == 1 ? 256u : 64u) << 20) - 1;
+        for (int g = 0; g < 3; ++g) {
+            auto go = [&]() {
+                if (g == 0) hipLaunchKernelGGL((probe8<1, true>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, mask, 0u, 0u);
+                else hipLaunchKernelGGL(probe_persist<4>, dim3(g == 1 ? 256 : 512), dim3(512), lds + 16384, 0, big, 5120, srcr, mask);
+            };
+            go(); go();
+            hipEventRecord(e0);
+            for (int w = 0; w < 10; ++w) go();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+            printf("short K, operand footprint %u MB, %s: %.1f us per launch; %s\n", (mask + 1) >> 20, g == 0 ? "one tile per workgroup" : g == 1 ? "persistent 256" : "persistent 512", ms * 1e3, hipGetErrorString(hipGetLastError()));
+        }
+    }
     return 0;
 }
