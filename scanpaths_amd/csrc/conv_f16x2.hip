@@ -135,6 +135,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     const int l32 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
+    // the two operand scales (device words written by the split kernels): requested FIRST, used by the epilogue -- behind the K loop
+    // their latency would be exposed once per workgroup
+    const float sx_dev = p.sx[0], sw_dev = p.sw[0];
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int tn, tmi;
     supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
@@ -152,11 +155,11 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         a_c8[j] = (pos ^ ((row >> 1) & 7)) * 16;
         const int64_t m = m0 + row;
         a_rowok[j] = m < p.M;
-        const int64_t mm = a_rowok[j] ? m : 0;
-        const int b = (int)(mm / HoWo);
-        const int rem = (int)(mm - (int64_t)b * HoWo);
-        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
-        a_boff[j] = b * p.Hi * p.Wi;
+        const uint32_t mm = a_rowok[j] ? (uint32_t)m : 0u;        // M < 2^31 (launch_h2): 32-bit divisions, a fifth of the 64-bit sequence --
+        const uint32_t b = mm / (uint32_t)HoWo;                   // a short-K tile lives ~15 us, the prologue is a visible part of it
+        const uint32_t rem = mm - b * (uint32_t)HoWo;
+        const int yo = (int)(rem / (uint32_t)p.Wo), xo = (int)rem - yo * p.Wo;
+        a_boff[j] = (int)b * p.Hi * p.Wi;
         if (MODE == 0) {
             a_py[j] = yo * p.stride - p.pad;
             a_px[j] = xo * p.stride - p.pad;
@@ -210,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     uint32_t h_valid = 0;
     const int h_npieces = HALO ? (HALO_PIECES - wave + 7) / 8 : 0;          // pieces this wave issues per block (7 or 6; scalar)
     if constexpr (HALO) {
-        const int img = (int)(m0 / HoWo);
-        const int y0 = (int)(m0 - (int64_t)img * HoWo) / p.Wo;
+        const int img = (int)((uint32_t)m0 / (uint32_t)HoWo);
+        const int y0 = (int)(((uint32_t)m0 - (uint32_t)img * (uint32_t)HoWo) / (uint32_t)p.Wo);
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int slot = (wave + 8 * j) * 8 + (lane >> 3), pos = lane & 7;
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
-    const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
+    const float isx = 1.f / sx_dev, isw = 1.f / sw_dev;
     if constexpr (LSTM) {
         // every LDS read of the K loop was waited for before its last barrier (the late waves multiply from registers): the ring is free
         const int KP = p.lKP, C = p.lC;
@@ -1414,6 +1417,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         tmi = lid / p.tiles_n;
         split = blockIdx.y;
     }
+    const float sx_dev = p.sx[0], sy_dev = p.sy[0];              // requested first, used by the epilogue (see h2_kernel)
     const int co0 = tmi * 256, n0 = tn * 128;
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
     const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
@@ -1449,12 +1453,12 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         b_r[j] = r;
         b_c8[j] = ci * 4 + (js & 3) * 16;
         b_live[j] = col < p.Ntot;
-        const int64_t m = m_begin + r;                            // coordinates of this lane's pixel in K-tile 0
-        const int b = (int)(m / HoWo);
-        const int rem = (int)(m - (int64_t)b * HoWo);
-        b_b[j] = b;
-        b_y[j] = rem / p.Wo;
-        b_x[j] = rem - b_y[j] * p.Wo;
+        const uint32_t m = (uint32_t)(m_begin + r);               // coordinates of this lane's pixel in K-tile 0 (M < 2^31: 32-bit divisions)
+        const uint32_t b = m / (uint32_t)HoWo;
+        const uint32_t rem = m - b * (uint32_t)HoWo;
+        b_b[j] = (int)b;
+        b_y[j] = (int)(rem / (uint32_t)p.Wo);
+        b_x[j] = (int)rem - b_y[j] * p.Wo;
     }
     const int y_adv = 32 / p.Wo, x_adv = 32 - y_adv * p.Wo;      // advancing 32 output pixels = y_adv rows + x_adv columns
     const uint32_t xrow = (uint32_t)(4 * p.Ci);
@@ -1731,7 +1735,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
-    const float isx = 1.f / p.sx[0], isy = 1.f / p.sy[0];
+    const float isx = 1.f / sx_dev, isy = 1.f / sy_dev;
     if constexpr (M16) {
         const int l16 = lane & 15;
         // float4 stores through a wave-private LDS staging tile (see h2_kernel's epilogue): 256-byte runs instead of 64-byte ones
@@ -2061,7 +2065,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     const int64_t xb = 4LL * d->N_img * d->Hi * d->Wi * d->Kc, wb = 4LL * d->Nout * d->KH * d->KW * d->Kc;
     if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
-    if (a.M <= 0 || a.Nout <= 0) return SP_EINVAL;
+    if (a.M <= 0 || a.M >= (1LL << 31) || a.Nout <= 0) return SP_EINVAL;             // 32-bit pixel arithmetic in the kernels
     hipStream_t st = (hipStream_t)stream;
     const bool f = d->mode == 0;
     // channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)

@@ -33,7 +33,7 @@ __device__ __forceinline__ void fill_lds(unsigned char* smem, int nthreads, bool
 // MODE 0: no global loads.  MODE 1: 6 LDS-DMA pieces per lane per K-tile (the ring of h2_kernel: tile kt+2 issued in K-tile kt, counted
 // vmcnt).  MODE 2: 2 pieces per K-tile (the halo build's steady state).  MODE 3: 6 pieces by global_load_dwordx4 into registers, written
 // to LDS by ds_write_b128 one K-tile later.  Sources: a 64 MiB buffer, every workgroup its own sliding window (L2 / MALL resident).
-template <int MODE, bool EPI = false>
+template <int MODE, int EPI = 0>   // EPI 1: each workgroup writes a contiguous 128 KB block; 2: the real conv layout (512-float rows, 4 column tiles)
 __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsigned char* src, uint32_t srcmask, uint32_t stride4, uint32_t wsrc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bool constant = nkt < 0;
@@ -61,6 +61,28 @@ __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsi
 #pragma unroll
             for (int j = 0; j < 2; ++j) GLDS16(src + ((wsrc + (uint32_t)kt_issue * 16384u + j * 8192u + lane_off) & srcmask), st + HA + (wv + 8 * j) * 1024);
             ++kt_issue;
+        } else if constexpr (MODE == 5) {
+            // the pointwise conv's loader: rows of `stride4` bytes (= 4 K bytes: both planes of every channel), K-tile kt = 128 B of each row;
+            // the activation tile is shared by the 4 neighbouring workgroups (output-channel tiles), the weights come from a small region
+            unsigned char* st = smem + stage_ * STAGE;
+            // srcmask bit 0 clear: workgroups of one activation tile on one XCD (the real kernel's map); bit 1 clear: K-tile-major activations
+            // ([K-tile][row][128 B]: every K-tile of a tile is one contiguous 32 KB block)
+            const bool xmap = (srcmask & 1u) == 0, ktmajor = (srcmask & 2u) == 0;
+            const uint32_t lid = xmap ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+            const uint32_t arow0 = (lid >> 2) * 256u, brow0 = (lid & 3) * 128u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t row = arow0 + (uint32_t)((wv + 8 * j) * 8 + (threadIdx.x & 63) / 8);
+                const uint64_t off = ktmajor ? ((uint64_t)kt_issue * (gridDim.x / 4u) * 256u + row) * 128u + (threadIdx.x & 7) * 16u
+                                             : (uint64_t)row * stride4 + (uint32_t)kt_issue * 128u + (threadIdx.x & 7) * 16u;
+                GLDS16(src + (off & (srcmask | 15u)), st + (wv + 8 * j) * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t row = brow0 + (uint32_t)((wv + 8 * j) * 8 + (threadIdx.x & 63) / 8);
+                GLDS16(src + ((wsrc + row * stride4 + (uint32_t)kt_issue * 128u + (threadIdx.x & 7) * 16u) & srcmask), st + HA + (wv + 8 * j) * 1024);
+            }
+            ++kt_issue;
         } else if constexpr (MODE == 1 || MODE == 2) {
             unsigned char* st = smem + stage_ * STAGE;
 #pragma unroll
@@ -80,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsi
         }
     };
     auto wait_loads = [&](bool more) {
-        if constexpr (MODE == 1 || MODE == 4) { if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if constexpr (MODE == 1 || MODE == 4 || MODE == 5) { if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if constexpr (MODE == 2) { if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     };
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsi
     if (late) __builtin_amdgcn_s_setprio(1);
     int stage = 0;
     auto prev = [](int st_) { return st_ == 0 ? 2 : st_ - 1; };
-    if constexpr (MODE == 1 || MODE == 2 || MODE == 4) { issue(0); issue(1); wait_loads(true); __builtin_amdgcn_s_barrier(); }
+    if constexpr (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5) { issue(0); issue(1); wait_loads(true); __builtin_amdgcn_s_barrier(); }
     if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             rd(stage);
@@ -163,11 +185,12 @@ __global__ __launch_bounds__(512, 2) void probe8(float* out, int nkt, const unsi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int cq4 = lane & 15, rsub = lane >> 4;
         const int64_t tile = blockIdx.x;                       // [tiles][256 rows][128 cols] fp32: 128 KB per workgroup
-        float* dst0 = out + tile * (256 * 128) + (wm * 64) * 128 + wn * 64 + 4 * cq4;
+        constexpr int LDC = EPI == 2 ? 512 : 128;
+        float* dst0 = (EPI == 2 ? out + (tile >> 2) * (256 * 512) + (tile & 3) * 128 : out + tile * (256 * 128)) + (wm * 64) * LDC + wn * 64 + 4 * cq4;
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
             const int row = ps * 4 + rsub;
-            *reinterpret_cast<float4*>(dst0 + row * 128) = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
+            *reinterpret_cast<float4*>(dst0 + row * LDC) = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
         }
         return;
     }
@@ -526,14 +549,18 @@ int main() {
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
             printf("%s: %.1f us per launch = %.2f us per workgroup round (20 rounds); %s\n", pn[which], ms * 1e3, ms * 1e3 / 20, hipGetErrorString(hipGetLastError()));
         }
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe8<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(probe_persist<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds + 16384);
     // the operand footprint decides how much of the read stream the caches absorb (the real kernel re-reads each activation tile for
     // 4 output-channel tiles: 220 MB from HBM out of 983 MB requested, PMC) -- sweep it for both structures
     for (int fp = 0; fp < 3; ++fp) {
         const uint32_t mask = ((fp == 0 ? 1024u : fp == 1 ? 256u : 64u) << 20) - 1;
-        for (int g = 0; g < 3; ++g) {
+        for (int g = -2; g < 3; ++g) {
             auto go = [&]() {
-                if (g == 0) hipLaunchKernelGGL((probe8<1, true>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, mask, 0u, 0u);
+                if (g == -2) hipLaunchKernelGGL((probe8<5, 2>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, ((1024u << 20) - 1) & ~(uint32_t)fp, 512u, 512u << 20);
+                else if (g == -1) hipLaunchKernelGGL((probe8<1, 2>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, mask, 0u, 0u);
+                else if (g == 0) hipLaunchKernelGGL((probe8<1, true>), dim3(grid), dim3(512), lds, 0, big, 4, srcr, mask, 0u, 0u);
                 else hipLaunchKernelGGL(probe_persist<4>, dim3(g == 1 ? 256 : 512), dim3(512), lds + 16384, 0, big, 5120, srcr, mask);
             };
             go(); go();
@@ -541,7 +568,7 @@ int main() {
             for (int w = 0; w < 10; ++w) go();
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-            printf("short K, operand footprint %u MB, %s: %.1f us per launch; %s\n", (mask + 1) >> 20, g == 0 ? "one tile per workgroup" : g == 1 ? "persistent 256" : "persistent 512", ms * 1e3, hipGetErrorString(hipGetLastError()));
+            printf("short K, operand footprint %u MB, %s: %.1f us per launch; %s\n", (mask + 1) >> 20, g == -2 ? (fp == 0 ? "(168 MB) pointwise conv's loads: 512 B rows, 128 B per K-tile, tile shared by 4 workgroups on different XCDs" : fp == 1 ? "(168 MB) the same, the 4 workgroups on one XCD" : "(168 MB) the same, one XCD, K-tile-major activations") : g == -1 ? "one tile per workgroup, output rows of 512 floats shared by 4 tiles" : g == 0 ? "one tile per workgroup" : g == 1 ? "persistent 256" : "persistent 512", ms * 1e3, hipGetErrorString(hipGetLastError()));
         }
     }
     return 0;

@@ -10,7 +10,7 @@ f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summ
 find $O -name "*trace.csv" -delete
 python3 tools/bench_backbone.py > $O/backbone.json 2> $O/backbone.err
 python3 examples/train_synthetic.py > $O/example.log 2>&1; echo "example rc=$?" >> $O/example.log
-python3 bench.py --steps 3 --warmup 1 --cpu-batch 4 --cpu-threads 128 --cpu-steps 2 > $O/cpu_baseline_b4_t128.json 2> $O/cpu_b4_t128.err
-python3 bench.py --steps 3 --warmup 1 --cpu-batch 4 --cpu-threads 32 --cpu-steps 2 > $O/cpu_baseline_b4_t32.json 2> $O/cpu_b4_t32.err
+# (run once this round: profiles/r03_cpu_baseline.json)  python3 bench.py --steps 3 --warmup 1 --cpu-batch 4 --cpu-threads 128 --cpu-steps 2 > $O/cpu_baseline_b4_t128.json 2> $O/cpu_b4_t128.err
+# (run once this round: profiles/r03_cpu_baseline.json)  python3 bench.py --steps 3 --warmup 1 --cpu-batch 4 --cpu-threads 32 --cpu-steps 2 > $O/cpu_baseline_b4_t32.json 2> $O/cpu_b4_t32.err
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 tail -n 4 $O/pytest.log; tail -n 3 $O/example.log; cut -c1-300 $O/backbone.json; cut -c1-260 $O/bench.json
