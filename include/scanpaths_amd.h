@@ -35,7 +35,7 @@ int sp_abi_version(void);
  * hands in ZEROED, single-use max|.| slots, so the one-thread reset kernel in front of a producer is only added while the stream is
  * being captured into a HIP graph (a replay re-uses the slot).  Default 0: always reset.  Set it once before launching; every other
  * name returns SP_EINVAL.
- * Kernel-schedule variants and wrong-result timing modes ("h2_variant", "hw_variant", "h2_dbg", "hw_dbg", "b3_dbg", "s2", ...) are
+ * Wrong-result timing modes ("h2_dbg", "hw_dbg", "b3_dbg": no loads / no MFMAs / ...) and two A/B switches ("h2_halo", "hw_splits") are
  * compiled ONLY into libscanpaths_amd_timing.so (make -C scanpaths_amd/csrc timing; -DSP_TIMING_VARIANTS), which tools/ load for
  * A/B timing; the product library reads no environment variable and cannot be switched into a mode that changes results. */
 int sp_set_tuning(const char* name, int value);

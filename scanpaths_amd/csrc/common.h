@@ -14,12 +14,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 // Process-wide switches (include/scanpaths_amd.h sp_set_tuning); -1 = built-in default.  The PRODUCT library
-// (libscanpaths_amd.so) knows exactly one: "amax_reset".  Every other selector -- kernel schedule variants, wrong-result timing
-// modes (no loads / no MFMAs / ...), experimental kernels -- exists only in the TIMING build (-DSP_TIMING_VARIANTS ->
-// libscanpaths_amd_timing.so, `make timing`, loaded by tools/ through SP_LIBRARY=timing); the product build compiles the default
-// schedule plus one fallback per kernel and reads no environment variable.
-enum { SP_TUNE_H2_VARIANT = 0, SP_TUNE_HW_VARIANT = 1, SP_TUNE_HW_MAP = 2, SP_TUNE_HW_SPLITS = 3, SP_TUNE_AMAX_RESET = 4, SP_TUNE_S2 = 5,
-       SP_TUNE_LSTM_EPI = 6, SP_TUNE_H2_CHUNK = 7, SP_TUNE_H2_DBG = 8, SP_TUNE_HW_DBG = 9, SP_TUNE_B3_DBG = 10, SP_TUNE_H2_HALO = 11, SP_TUNE_TWOBAR = 12, SP_TUNE_COUNT = 13 };
+// (libscanpaths_amd.so) knows exactly one: "amax_reset".  Every other selector -- the halo-block A/B switch, a forced split count of the weight
+// gradient, wrong-result timing modes (no loads / no MFMAs / ...) -- exists only in the TIMING build (-DSP_TIMING_VARIANTS ->
+// libscanpaths_amd_timing.so, `make timing`, loaded by tools/ through SP_LIBRARY=timing); the product build reads no environment variable.
+// (Schedule variants that lost their A/B were removed in round 3; their measurements are in DESIGN.md.)
+enum { SP_TUNE_AMAX_RESET = 0, SP_TUNE_HW_SPLITS = 1, SP_TUNE_H2_HALO = 2, SP_TUNE_H2_DBG = 3, SP_TUNE_HW_DBG = 4, SP_TUNE_B3_DBG = 5,
+       SP_TUNE_COUNT = 6 };
 extern int sp_tuning_values[SP_TUNE_COUNT];
 #ifdef SP_TIMING_VARIANTS
 static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }

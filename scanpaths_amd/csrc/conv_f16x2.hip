@@ -3,7 +3,7 @@
 // Every fp32 operand tensor is scaled by a per-tensor power of two s (so that max|x*s| lies in [8192, 16384): exact, no
 // overflow, the residual plane stays a normal fp16 for everything within 2^-11 of the maximum) and split into two fp16 planes
 //     x*s = x1 + x2,   x1 = fp16(x*s),  x2 = fp16(x*s - x1)          |x*s - x1 - x2| <= 2^-22 |x*s|
-// and  a*b = (a1b1 + a1b2 + a2b1) / (sa*sb) + O(2^-22 |ab|)  is evaluated with THREE v_mfma_f32_32x32x16_f16 per fragment
+// and  a*b = (a1b1 + a1b2 + a2b1) / (sa*sb) + O(2^-22 |ab|)  is evaluated with THREE v_mfma_f32_16x16x32_f16 per fragment
 // pair (fp16 x fp16 products are exact in the fp32 accumulator; smallest first; two-level accumulation every 256 k as in the
 // other GEMM kernels).  The element-wise representation errors are independent, so a length-K dot product is off by
 // ~2^-22 rms|ab| sqrt(K) -- measured 7.6e-8 relative to rms(C) for K = 64 .. 18432, i.e. 2-4x CLOSER to the fp64 result than
@@ -37,10 +37,6 @@ constexpr int HALO_W = 64, HALO_ROWSLOTS = HALO_W + 2, HALO_NSLOT = 6 * HALO_ROW
 constexpr int HALO_PIECES = (HALO_NSLOT + 7) / 8;                                         // 50 LDS-DMA pieces of 1 KB
 constexpr int HALO_A_BYTES = HALO_PIECES * 1024;                                          // 51200 per block, two blocks in flight
 constexpr int HALO_LDS = 2 * HALO_A_BYTES + 3 * HB_BYTES;                                 // 151552
-constexpr int HW_DEFAULT_MAP = 0;                // sp_set_tuning("hw_map", 1): aligned-rounds workgroup order of hw_kernel
-constexpr int H2_DEFAULT_VARIANT = 17;           // schedule variant of h2_kernel (see there); sp_set_tuning("h2_variant", v)
-constexpr int HW_DEFAULT_VARIANT = 10;           // schedule variant of hw_kernel
-constexpr int TWOBAR_DEFAULT = 0;                // second barrier per K-tile (strictly alternating matrix segments), h2_kernel / hw_kernel
 
 struct H2Args {
     const uint16_t* X;    // [pixels][Kc/16][2][16]
@@ -70,45 +66,38 @@ struct H2Args {
     uint16_t* l_hplanes;    // nullable: h as the 2xfp16 split operand of its consumers, scale from l_hbound >= max|h|
     float* l_hscale;        // [2] {scale, bound}
     float l_hbound;
-    int l_direct_hc;
     int lC, lP, lKP;
     // BatchNorm batch statistics of the output, fused into the epilogue (forward, 16x16x32 build): per M-tile and output column
     // the sum and the sum of squares (fp64) and min / max (fp32) of the tile's valid rows, in the [G = M-tiles][2][Nout] layout
     // of bn_pool.hip's first reduction stage -- the BatchNorm behind this conv starts at its second stage
     double* st_partial;
     float* st_mm;
-    int chunk_kt;           // K-tiles per chunk of the two-level accumulation (power of two; HCHUNK_KT)
-    int twobar;             // 1: a second barrier per K-tile between the two halves' matrix segments (see the K loop)
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
 // staging in a 3-stage ring with counted vmcnt (the structure of b3_kernel, see there for why).  Rows are 128 B = half a
 // 256-byte LDS bank row, so the source-side swizzle is an XOR: chunk c of row r is stored at position c ^ ((r>>1)&7); the 16
 // rows of every ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) then hit 16 distinct 16-byte slots.
-// DBG (env SP_H2_DBG, timing experiments only): 1 = no global loads (MFMA + LDS side alone), 2 = no MFMAs (load side alone),
-// 3 = MFMAs only (no loads, no fragment reads, no barriers: what the matrix pipe sustains at the clock the chip holds)
-// VAR (schedule of the two waves that share a SIMD, waves w and w+4; MI355X_MICROARCH.md "Two waves per SIMD" items 1, 9):
-//   0  both run the same program in lockstep: fragment reads, then 24 MFMAs, then 6 LDS-DMA issues, wait, barrier -- the
-//      matrix pipe idles while BOTH waves read / issue loads / wait (round-1 kernel);
-//   1  half-tile stagger: waves 4-7 defer the second 16-k group's 12 MFMAs past the barrier (fragments stay in registers),
-//      so their MFMAs cover the read phase of waves 0-3;
-//   2  full ping-pong with ONE barrier per K-tile: waves 0-3 run  [issue loads(t+2)] [read(t)] [24 MFMA(t)] [wait] [barrier],
-//      waves 4-7 run  [24 MFMA(t-1)] [read(t)] [issue loads(t+2)] [wait] [barrier]  -- at any time one wave of a SIMD is in
-//      its matrix segment while its partner is in its LDS / DMA segment; waves 4-7 finish tile nkt-1 after the loop;
-//   3  = 2 with s_setprio 1 on waves 4-7 (the second-dispatched half loses VALU/issue arbitration otherwise).
-// All variants compute bit-identical results (same per-accumulator MFMA order, same fold points).
+// Schedule of the two waves that share a SIMD (waves w and w+4; MI355X_MICROARCH.md "Two waves per SIMD" items 1, 9): ping-pong with
+// ONE barrier per K-tile -- waves 0-3 run  [read(t)] [issue loads(t+2)] [48 MFMA(t)] [wait] [barrier],  waves 4-7 (s_setprio 1: the
+// second-dispatched half loses issue arbitration otherwise) run  [48 MFMA(t-1)] [read(t)] [issue loads(t+2)] [wait] [barrier]:  at
+// any time one wave of a SIMD is in its matrix segment while its partner is in its LDS / DMA segment; waves 4-7 finish tile nkt-1
+// after the loop.  The tap-major build (CBM = false) issues the early half's loads BEFORE its fragment reads (measured better there).
+// Schedules that lost their A/B (lockstep, half-tile stagger, LDS-DMA pieces spread through the matrix segment, a second barrier
+// per K-tile, 32x32x16 MFMAs, a 128x128-tile / two-workgroups-per-CU kernel for short K) are in the history of this file and in
+// DESIGN.md sections 5, 9g with their measurements; they are not built any more.
+// DBG (timing library only, -DSP_TIMING_VARIANTS; wrong results): 1 = no global loads (MFMA + LDS side alone), 2 = no MFMAs (load side
+// alone), 3 = MFMAs only (no loads, no fragment reads, no barriers), 9 = LDS-DMA loads only.
 // NPROD: 3 = fp32-faithful (the two cross terms, then the main product); 1 = THROUGHPUT MODE: only the main product a1*b1, i.e.
 // both operands rounded to ONE fp16 plane (fp16 in / fp32 accumulate) -- same operand storage, a third of the MFMA work.
-// M16: issue v_mfma_f32_16x16x32_f16 (4x4 tiles of 16x16 per wave, one 32-k block per K-tile) instead of 32x32x16 (2x2 tiles,
-// two 16-k groups): same fragments-per-FLOP from LDS, same cycles per FLOP, but the chip holds a higher clock on this shape
-// under MFMA load (MI355X_MICROARCH.md "DVFS give-back" item 7).  Per-accumulator summation order differs from the 32x32 build
-// (a 32-k block per MFMA instead of 16), so results agree to rounding, not bitwise.
+// MFMA shape: v_mfma_f32_16x16x32_f16 (4x4 tiles of 16x16 per wave, one 32-k block per K-tile): same fragments-per-FLOP from LDS and
+// cycles per FLOP as 32x32x16, but the chip holds a higher clock on this shape under MFMA load (MI355X_MICROARCH.md "DVFS give-back").
 // CBM: channel-block-major K order (for each 32-channel block: all filter taps) instead of tap-major.  Consecutive K-tiles then
 // re-read the SAME pixels shifted by one tap, so the activation panel of an M-tile is served from L2 for 8 of 9 taps instead of
 // being re-fetched from the Infinity Cache / HBM side per tap.  Per loader lane: the byte offset of its pixel at tap (0,0) and a
 // bit mask of the taps that fall inside the image; the tap's offset is one scalar per K-tile.  Needs KH*KW <= 32 and (dgrad)
 // stride 1; the sum order over K differs from the tap-major build, so results agree to rounding, not bitwise.
-// LSTM (forward, M16 only): the GEMM is the h-gate conv of the ConvLSTM and the epilogue is the whole cell.  The 128 weight rows of a
+// LSTM (forward): the GEMM is the h-gate conv of the ConvLSTM and the epilogue is the whole cell.  The 128 weight rows of a
 // workgroup are gathered as  4 gates x 32 channels  (tile row r -> gate (r>>4)&3, channel c0 + 16*(r>>6) + (r&15)): no data is
 // permuted, only the loader's row address, and a lane then holds the four gate pre-activations of ONE channel for its 16 pixels
 // in acc4[i][0..3].  Epilogue: + x-gate term + rank-1 gate term (spcol x wc, staged in the now idle LDS), sigmoid/tanh, cell and
@@ -124,15 +113,14 @@ __device__ __forceinline__ float h2_sigmoid(float x) { return 1.f / (1.f + expf(
 // -- 16 distinct 16-byte bank slots for every b (0 of 4800 conflict; enumerated in tests/test_cpu_host.py).
 __device__ __forceinline__ int halo_swz(int slot) { return ((slot >> 1) & 3) << 1; }
 
-template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false, bool HALO = false>
+template <int MODE, int NPROD, bool CBM, bool LSTM = false, bool HALO = false, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
-    static_assert(!LSTM || (M16 && MODE == 0), "the LSTM epilogue is written for the forward 16x16x32 build");
-    static_assert(!HALO || (M16 && CBM && VAR == 5 && NPROD == 3 && DBG == 0), "the halo build extends the default schedule only");
+    static_assert(!LSTM || MODE == 0, "the LSTM epilogue belongs to the forward build");
+    static_assert(!HALO || (CBM && NPROD == 3 && DBG == 0), "the halo build extends the channel-block-major schedule only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l32 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
     // the two operand scales (device words written by the split kernels): requested FIRST, used by the epilogue -- behind the K loop
@@ -204,7 +192,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
     }
     int ld_tap = 0;
-    int dbg_last_pieces = 6;      // DBG 10: LDS-DMA pieces of the most recently issued K-tile
     // HALO: the lane's source offsets of the activation block (per-lane constants over the whole K loop; only the channel block,
     // a scalar, changes).  LDS piece q = wave + 8 j holds pixel slots 8 q .. 8 q + 7; slot s = (block row s / 66, column s % 66 - 1),
     // block row 0 = the image row above the tile's first row.  Slots outside the image (halo columns, rows above / below the image,
@@ -287,28 +274,14 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const uint32_t koffA = (uint32_t)ld_cblk * 128u;
             const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
             const uint32_t zrelA = p.x_bytes - koffA;
-            // DBG 11 (timing proxy of ONE halo'd activation block per channel block shared by the three horizontal taps of a filter row:
-            // a third of the activation LDS-DMA pieces; wrong results): activation pieces only for the first tap of each filter row
-            if (DBG != 11 || ld_kx == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    SP_GLDS16(baseA + (((a_mask[j] >> ld_tap) & 1u) ? a_base0[j] + delta : zrelA), st + (wave + 8 * j) * 1024);
-                dbg_last_pieces = 6;
-            } else {
-                dbg_last_pieces = 2;
-            }
+            for (int j = 0; j < 4; ++j)
+                SP_GLDS16(baseA + (((a_mask[j] >> ld_tap) & 1u) ? a_base0[j] + delta : zrelA), st + (wave + 8 * j) * 1024);
             const uint32_t koffB = (uint32_t)(ld_tap * p.ncblk + ld_cblk) * 128u;
             const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
             const uint32_t zrelB = p.w_bytes - koffB;
-            // DBG 10 (timing proxy of a 128x64 wave tile in a 256x256 block: half the weight-side LDS traffic per MFMA): weight pieces
-            // and weight fragments only every second K-tile (wrong results)
-            if (DBG != 10 || (ld_tap & 1) == 0) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
-                if (DBG == 10) dbg_last_pieces = 6;
-            } else {
-                dbg_last_pieces = 4;
-            }
+            for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
             ++ld_tap;
             if (++ld_kx == p.KW) {
                 ld_kx = 0;
@@ -324,15 +297,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         const uint32_t koffA = (uint32_t)ld_cblk * 128u;                 // scalar: 32-channel block inside the pixel row
         const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
         const uint32_t zrelA = p.x_bytes - koffA;
-        // DBG 5 (timing proxy for a one-pixel-halo activation block shared by the three horizontal taps): the activation pieces
-        // are loaded for the first tap of each filter row only (results are wrong, timing and data statistics are realistic)
-        if (DBG != 5 || ld_kx == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(a_voff[j]));
-        }
+        for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
         const uint32_t koffB = (uint32_t)ld_kt * 128u;
         const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
         const uint32_t zrelB = p.w_bytes - koffB;
@@ -348,85 +314,17 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
     };
 
-    // VAR 4 ("spread"): the 6 LDS-DMA pieces of a K-tile are issued one at a time between groups of 8 MFMAs instead of as one
-    // block (an LDS-DMA issue costs the issuing wave ~60 cycles among MFMAs, 100-185 inside a load block); tap-major order only
-    uint32_t pc_off[6];
-    const unsigned char *pc_baseA = nullptr, *pc_baseB = nullptr;
-    int pc_stage = 0;
-    auto prepare_tile = [&](int stage) {
-        if constexpr (CBM) {
-            const int step = (ld_ky * p.Wi + ld_kx) * p.dil;
-            const uint32_t delta = (uint32_t)(MODE == 0 ? step : -step) * (uint32_t)rowbytes;
-            const uint32_t koffA = (uint32_t)ld_cblk * 128u;
-            pc_baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
-            const uint32_t zrelA = p.x_bytes - koffA;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pc_off[j] = ((a_mask[j] >> ld_tap) & 1u) ? a_base0[j] + delta : zrelA;
-            const uint32_t koffB = (uint32_t)(ld_tap * p.ncblk + ld_cblk) * 128u;
-            pc_baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
-            const uint32_t zrelB = p.w_bytes - koffB;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) pc_off[4 + j] = b_ok[j] ? b_voff[j] : zrelB;
-            pc_stage = stage;
-            ++ld_tap;
-            if (++ld_kx == p.KW) {
-                ld_kx = 0;
-                if (++ld_ky == p.KH) {
-                    ld_ky = 0;
-                    ld_tap = 0;
-                    ++ld_cblk;
-                }
-            }
-            return;
-        }
-        if (ld_cblk == 0) tap_update();
-        const uint32_t koffA = (uint32_t)ld_cblk * 128u;
-        pc_baseA = reinterpret_cast<const unsigned char*>(p.X) + koffA;
-        const uint32_t zrelA = p.x_bytes - koffA;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pc_off[j] = a_ok[j] ? a_voff[j] : zrelA;
-        const uint32_t koffB = (uint32_t)ld_kt * 128u;
-        pc_baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
-        const uint32_t zrelB = p.w_bytes - koffB;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) pc_off[4 + j] = b_ok[j] ? b_voff[j] : zrelB;
-        pc_stage = stage;
-        ++ld_kt;
-        if (++ld_cblk == p.ncblk) {
-            ld_cblk = 0;
-            if (++ld_kx == p.KW) {
-                ld_kx = 0;
-                ++ld_ky;
-            }
-        }
-    };
-    auto issue_piece = [&](int q) {
-        unsigned char* st = smem + pc_stage * HSTAGE;
-        __builtin_amdgcn_sched_barrier(0);
-        if (q < 4) SP_GLDS16(pc_baseA + pc_off[q], st + (wave + 8 * q) * 1024);
-        else SP_GLDS16(pc_baseB + pc_off[q], st + HA_BYTES + (wave + 8 * (q - 4)) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // fragment read offsets: row r, chunk c = kk*4 + plane*2 + h stored at position c ^ ((r>>1)&7)
-    //   32x32x16: lane = (row l32, k-half h) of 16-k group kk;   16x16x32: lane = (row l16, k-group g4 = 2*kk + h) of the 32-k block
+    // fragment read offsets: row r, chunk c = (k-group >> 1) * 4 + plane * 2 + (k-group & 1) stored at position c ^ ((r>>1)&7); lane = (row l16,
+    // k-group g4) of the 32-k block; the four 16-row tiles of a wave are reached by constant offsets
     const int l16 = lane & 15, g4 = lane >> 4;
-    const int rot = M16 ? ((l16 >> 1) & 7) : ((l32 >> 1) & 7);
-    int offA[2][2], offB[2][2];      // M32: [kk][plane];  M16: [0][plane] only (+ i * 16 rows)
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];            // [plane]
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            if constexpr (M16) {
-                const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
-                offA[kk][pl] = (wm * 64 + l16) * 128 + pos * 16;
-                offB[kk][pl] = HA_BYTES + (wn * 64 + l16) * 128 + pos * 16;
-            } else {
-                const int pos = (kk * 4 + pl * 2 + h) ^ rot;
-                offA[kk][pl] = (wm * 64 + l32) * 128 + pos * 16;
-                offB[kk][pl] = HA_BYTES + (wn * 64 + l32) * 128 + pos * 16;
-            }
-        }
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = HA_BYTES + (wn * 64 + l16) * 128 + pos * 16;
+    }
 
     // HALO: fragment row i*16 + l16 of wave row-group wm is pixel (image row wm of the tile, column i*16 + l16) -> block slot
     // (wm + dy) * 66 + column + dx with (dy, dx) = (ky, kx) forward, (2 - ky, 2 - kx) data gradient; the slot (hence the swizzle)
@@ -434,17 +332,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     const int h_slot0 = wm * HALO_ROWSLOTS + l16;
     const int h_chunk = (g4 >> 1) * 4 + (g4 & 1);
     int rd_tap = 0, rd_cb = 0;           // HALO: coordinates of the K-tile whose fragments are read next
-    f32x16 tot[2][2], acc[2][2];         // M32 accumulators (unused registers are dropped by the compiler in the M16 build)
-    f32x4 tot4[4][4], acc4[4][4];        // M16 accumulators
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                tot[i][j][r] = 0.f;
-                acc[i][j][r] = 0.f;
-            }
+    f32x4 tot4[4][4], acc4[4][4];        // two-level accumulation: chunk accumulator, total
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -501,14 +389,14 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 for (int i = 0; i < 2; ++i) {
                     af[kk][i][0] = *reinterpret_cast<const f16x8*>(stA + oa0 + (2 * kk + i) * 16 * 128);
                     af[kk][i][1] = *reinterpret_cast<const f16x8*>(stA + oa1 + (2 * kk + i) * 16 * 128);
-                    bf[kk][i][0] = *reinterpret_cast<const f16x8*>(stB + offB[0][0] + (2 * kk + i) * 16 * 128);
-                    bf[kk][i][1] = *reinterpret_cast<const f16x8*>(stB + offB[0][1] + (2 * kk + i) * 16 * 128);
+                    bf[kk][i][0] = *reinterpret_cast<const f16x8*>(stB + offB[0] + (2 * kk + i) * 16 * 128);
+                    bf[kk][i][1] = *reinterpret_cast<const f16x8*>(stB + offB[1] + (2 * kk + i) * 16 * 128);
                 }
             if (++rd_tap == 9) {
                 rd_tap = 0;
                 ++rd_cb;
             }
-        } else if constexpr (M16) {
+        } else {
             // af[kk][i][pl] holds row tile 2*kk + i (16 rows each) of the ONE 32-k block; bf likewise for column tiles
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -516,24 +404,13 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
-                        af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[0][pl] + (2 * kk + i) * 16 * 128);
-                        if (DBG != 10 || (kt_ & 1) == 0)
-                            bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[0][pl] + (2 * kk + i) * 16 * 128);
-                    }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
-                        af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[kk][pl] + i * 32 * 128);
-                        bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[kk][pl] + i * 32 * 128);
+                        af[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + (2 * kk + i) * 16 * 128);
+                        bf[kk][i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + (2 * kk + i) * 16 * 128);
                     }
         }
     };
     auto mma_group = [&](int kk) {
-        if constexpr (do_mma && M16) {
+        if constexpr (do_mma) {
             // group kk = row tiles 2kk, 2kk+1 against all four column tiles (24 of the K-tile's 48 MFMAs)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -546,18 +423,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     }
                     a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
                 }
-        } else if constexpr (do_mma) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // three products, the two cross terms (~2^-11 of the main one) first
-                    if constexpr (NPROD == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
-                }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -569,67 +434,31 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
     };
     auto fold = [&](int kt_) {           // two-level accumulation: fold the chunk accumulator into the total every 256 k
-        if constexpr (M16) {
-            if (((kt_ + 1) & (p.chunk_kt - 1)) == 0) {
+        if (((kt_ + 1) & (HCHUNK_KT - 1)) == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        tot4[i][j] += acc4[i][j];
+                for (int j = 0; j < 4; ++j) {
+                    tot4[i][j] += acc4[i][j];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
-                    }
-            }
-            return;
-        }
-        if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    tot[i][j] += acc[i][j];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
                 }
         }
     };
     auto wait_barrier = [&](int kt_) {
         // tile kt+1 must have landed: everything but the one younger tile (if it was issued)
-        if (DBG == 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // the younger tile has 2 or 6 pieces: never wait for fewer than needed
-        else if (DBG == 10 || DBG == 11) {                                    // the younger tile has 2, 4 or 6 pieces
-            if (kt_ + 2 >= p.nkt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (dbg_last_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (dbg_last_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
-        else if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (kt_ + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (do_bar) __builtin_amdgcn_s_barrier();
     };
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
-    // the 48 MFMAs of a K-tile with the six prepared LDS-DMA pieces issued one after every eighth (an issue among queued MFMAs
-    // costs ~60 cycles and the matrix pipe keeps draining its backlog meanwhile; as a block the six cost 100-185 cycles each)
-    auto mma_spread = [&](bool pre_) {
-        if constexpr (M16 && do_mma) {
-#pragma unroll
-            for (int pr = 0; pr < 16; ++pr) {
-                const int i = pr >> 2, j = pr & 3;
-                f32x4& a4 = acc4[i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                if (((pr + 1) * 6) / 16 != (pr * 6) / 16 && pre_) issue_piece((pr * 6) / 16);
-            }
-        }
-    };
-
     int stage = 0;
-    const bool late = ((VAR >= 1 && VAR <= 3) || VAR == 5 || VAR == 6 || VAR == 7) && wave >= 4;   // the half of the workgroup that runs behind (scalar: uniform branch)
-    if ((VAR == 3 || VAR == 5 || VAR == 6) && late) __builtin_amdgcn_s_setprio(1);
+    const bool late = wave >= 4;         // the half of the workgroup that runs behind (scalar: uniform branch)
+    if (late) __builtin_amdgcn_s_setprio(1);
     if constexpr (HALO) {
-        // Default schedule (VAR 5: ping-pong halves, fragment reads ahead of the LDS-DMA issue block, s_setprio on the late half) with
+        // The schedule above with
         // the activation operand staged as halo blocks: per K-tile every lane issues its 2 weight pieces (tile kt + 2); at the first tap
         // of channel block cb it then issues the 6-7 pieces of activation block cb + 1 (into the block buffer that block cb - 1 left at
         // the barrier before this channel block); the block is complete two barriers later, seven K-tiles before its first use.
@@ -660,17 +489,10 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 ++cur_cb;
             }
         };
-        // p.twobar: a SECOND barrier per K-tile, between the late half's matrix segment (tile kt-1) and the early half's (tile kt).
-        // With one barrier the early half starts its 48 MFMAs as soon as its reads and load issues are done -- in the middle of the
-        // late half's matrix segment: the two streams interleave on the SIMD's one matrix pipe (each hand-over costs cycles against
-        // a 16-cycle MFMA: two waves issuing concurrently sustain ~21 cycles per MFMA), the late half's segment stretches to the end
-        // of the early half's and its own read / issue phase is then exposed before the barrier.  With the second barrier the
-        // phases alternate strictly: [late: MFMA(kt-1) | early: read(kt), issue] barrier [early: MFMA(kt) | late: read(kt), issue] barrier.
         if (!late) {
             for (int kt = 0; kt < p.nkt; ++kt) {
                 read_frags(stage, kt);
                 halo_issue(kt);
-                if (p.twobar) __builtin_amdgcn_s_barrier();
                 mma_group(0);
                 mma_group(1);
                 fold(kt);
@@ -684,7 +506,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     mma_group(1);
                     fold(kt - 1);
                 }
-                if (p.twobar) __builtin_amdgcn_s_barrier();
                 read_frags(stage, kt);
                 halo_issue(kt);
                 halo_wait(kt);
@@ -694,85 +515,20 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             mma_group(1);
             fold(p.nkt - 1);
         }
-    } else if constexpr (VAR == 6 && M16 && do_mma && do_load) {
-        // VAR 6: ping-pong (as 3) with the LDS-DMA pieces spread through each wave's OWN matrix segment
-        if (!late) {
-            for (int kt = 0; kt < p.nkt; ++kt) {
-                const bool pre = kt + HNSTAGE - 1 < p.nkt;
-                read_frags(stage, kt);
-                if (pre) prepare_tile(prev_stage(stage));
-                mma_spread(pre);
-                fold(kt);
-                wait_barrier(kt);
-                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
-            }
-        } else {
-            for (int kt = 0; kt < p.nkt; ++kt) {
-                const bool pre = kt + HNSTAGE - 1 < p.nkt;
-                if (pre) prepare_tile(prev_stage(stage));
-                if (kt > 0) {
-                    mma_spread(pre);                        // tile kt-1 (fragments read before the last barrier) + loads of tile kt+2
-                    fold(kt - 1);
-                } else if (pre) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) issue_piece(q);
-                }
-                read_frags(stage, kt);
-                wait_barrier(kt);
-                stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
-            }
-            mma_spread(false);
-            fold(p.nkt - 1);
-        }
-    } else if constexpr (VAR == 4 && M16 && do_mma && do_load) {
-        for (int kt = 0; kt < p.nkt; ++kt) {
-            const bool pre = kt + HNSTAGE - 1 < p.nkt;
-            if (pre) prepare_tile(prev_stage(stage));
-            read_frags(stage, kt);
-#pragma unroll
-            for (int pr = 0; pr < 16; ++pr) {
-                const int i = pr >> 2, j = pr & 3;
-                f32x4& a4 = acc4[i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i >> 1][i & 1][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                if (((pr + 1) * 6) / 16 != (pr * 6) / 16 && pre) issue_piece((pr * 6) / 16);
-            }
-            fold(kt);
-            wait_barrier(kt);
-            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
-        }
     } else if (!late) {
         for (int kt = 0; kt < p.nkt; ++kt) {
             const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
-            // prefetch of tile kt+2 into the stage read in iteration kt-1: VAR >= 2 issues it FIRST (its partner wave is in its
-            // matrix segment now), the lockstep / half-stagger variants behind the MFMAs in program order (see b3_kernel)
-            if (VAR >= 2 && VAR != 5 && VAR != 7 && pre) issue_tile(prev_stage(stage));
+            // prefetch of tile kt+2 into the stage read in iteration kt-1 (its partner wave is in its matrix segment now): the tap-major
+            // build issues it ahead of the fragment reads, the channel-block-major build behind them
+            if (!CBM && pre) issue_tile(prev_stage(stage));
             read_frags(stage, kt);
-            if ((VAR == 5 || VAR == 7) && pre) issue_tile(prev_stage(stage));          // VAR 5 (= 3 with the fragment reads ahead of the issue block)
-            if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();                     // (see the halo loop)
+            if (CBM && pre) issue_tile(prev_stage(stage));
             mma_group(0);
             mma_group(1);
-            if (VAR < 2 && pre) issue_tile(prev_stage(stage));
             fold(kt);
             wait_barrier(kt);
             stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
         }
-    } else if (VAR == 1) {
-        for (int kt = 0; kt < p.nkt; ++kt) {
-            const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
-            if (kt > 0) {
-                mma_group(1);                           // second half of tile kt-1, fragments kept across the barrier
-                fold(kt - 1);
-            }
-            read_frags(stage, kt);
-            mma_group(0);
-            if (pre) issue_tile(prev_stage(stage));
-            wait_barrier(kt);
-            stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
-        }
-        mma_group(1);
-        fold(p.nkt - 1);
     } else {
         for (int kt = 0; kt < p.nkt; ++kt) {
             const bool pre = do_load && kt + HNSTAGE - 1 < p.nkt;
@@ -781,7 +537,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 mma_group(1);
                 fold(kt - 1);
             }
-            if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();
             read_frags(stage, kt);
             if (pre) issue_tile(prev_stage(stage));
             wait_barrier(kt);
@@ -791,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         mma_group(1);
         fold(p.nkt - 1);
     }
-    if ((VAR == 3 || VAR == 5 || VAR == 6) && late) __builtin_amdgcn_s_setprio(0);
+    if (late) __builtin_amdgcn_s_setprio(0);
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
@@ -873,10 +628,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 cv[i][r] = cn;
                 hv[i][r] = hn;
                 hmx = fmaxf(hmx, fabsf(hn));
-                if (p.l_direct_hc) {                        // A/B switch (sp_set_tuning("lstm_epi", 1)): 4-byte stores from the MFMA layout
-                    p.l_c[m * C + ch] = cn;
-                    p.l_h[m * C + ch] = hn;
-                }
             }
         __syncthreads();
 #pragma unroll
@@ -888,14 +639,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
         // h and c leave the same way ([256 rows][32 channels] each: 128-byte runs), and h also as the split operand of its consumers
         // (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <= t + 1, so the operand scale needs no max|h| pass
-        if (p.l_direct_hc) {
-            if (p.l_hamax) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) hmx = fmaxf(hmx, __shfl_xor(hmx, off));
-                if (lane == 0 && hmx > 0.f) atomicMax(p.l_hamax, __float_as_uint(hmx));
-            }
-            return;
-        }
         __syncthreads();
         float* hs = xs;
         float* cs2 = xs + HBM * 32;
@@ -942,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
         return;
     }
-    if constexpr (M16) {
+    {
         // C/D layout of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg.  Stored straight from the registers every instruction
         // writes 4 bytes per lane in 64-byte runs (16 columns of one row): 671 MB of output took ~0.4 ms, and the short-K pointwise
         // convs of the encoder -- whose run time IS their epilogue -- ran at 1.2 TB/s.  The wave's 64 x 64 tile is therefore staged
@@ -1047,277 +790,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 p.st_mm[(g * 2 + 1) * p.Nout + n0 + t] = mx;
             }
         }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l32;
-        if (n >= p.Nout) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < p.M) {
-                    float* dst = p.C + m * p.ldc + n;
-                    float v = p.alpha * (((tot[i][j][r] + acc[i][j][r]) * isx) * isw) + bv;
-                    if (p.beta) v += *dst;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    *dst = v;
-                }
-            }
-        }
     }
 }
-
-#ifdef SP_TIMING_VARIANTS      // experimental kernel (lost its A/B, see below): timing build only
-// ================================================================================================================
-// Short-K pointwise GEMM (1x1 convolutions of the ResNet bottlenecks with K <= 512, forward and stride-1 data gradient):
-//   C[m][n] = sum_k A[row(m)][k] * W[n][k],   row(m) = the input pixel of output pixel m (stride), same split operands and arithmetic
-//   as h2_kernel (16x16x32 MFMAs, 3 products, fold every 256 k).
-// These launches move 0.3-0.8 GB for 20-90 GFLOP: they are HBM-bound, and h2_kernel's 256x128 tile with a 144 KB ring (one
-// workgroup per CU, nothing to overlap its prologue latency and its 128 KB epilogue with) runs them at ~1.2 TB/s.  Here: 128x128 tile,
-// 4 waves (2x2, wave tile 64x64), two 32 KB stages -> 64 KB LDS, TWO workgroups per CU whose load / matrix / store phases overlap.
-// MEASURED (round 2, encoder at bs 32, 320x512): with 4-byte epilogue stores SLOWER than h2_kernel on the same launches (666 vs
-// 540 us on the M = 327 680, N = 512, K = 128 shape) -- what held these launches back was the store pattern of the epilogue, not
-// occupancy.  With float4 stores through the ring in both kernels: 328 vs 346 us on that shape, 111 vs 128 (K = 256, N = 64), equal
-// once the statistics epilogue is on, encoder forward + backward 79.68 vs 79.70 ms.  Kept as an opt-in experiment
-// (sp_set_tuning("s2", 1) / SP_S2=1); the default path does not use it.
-struct S2Args {
-    const uint16_t* A;    // [rows][K/16][2][16]
-    const uint16_t* W;    // [Nout][K/16][2][16]
-    const float* bias;
-    float* C;
-    const float* sx;
-    const float* sw;
-    int64_t M;
-    int K, Nout, ldc;
-    int Ho, Wo, Hi, Wi, stride;
-    int nkt, tiles_n;
-    float alpha;
-    int beta, relu;
-    uint32_t a_bytes, w_bytes;
-    double* st_partial;   // [M / 128 tiles][2][Nout] (see H2Args)
-    float* st_mm;
-};
-constexpr int S2_BM = 128, S2_BN = 128;
-constexpr int S2_A_BYTES = S2_BM * 128, S2_STAGE = (S2_BM + S2_BN) * 128;      // 16384, 32768
-
-__global__ __launch_bounds__(256, 2) void s2_kernel(S2Args p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l16 = lane & 15, g4 = lane >> 4;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;        // N-tiles of one M-tile are neighbours: its A panel is read once
-    const int64_t m0 = (int64_t)tmi * S2_BM;
-    const int n0 = tn * S2_BN;
-    const uint32_t rowbytes = (uint32_t)p.K * 4u;
-
-    // loader: LDS chunk g = t + 256 j -> row g/8, position g%8; source chunk = position ^ ((row>>1)&7)  (h2_kernel's layout)
-    uint32_t a_voff[4], b_voff[4];
-    bool a_ok[4], b_ok[4];
-    const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = t + 256 * j;
-        const int row = idx >> 3, pos = idx & 7;
-        const uint32_t c8 = (uint32_t)((pos ^ ((row >> 1) & 7)) * 16);
-        const int64_t m = m0 + row;
-        a_ok[j] = m < p.M;
-        int64_t src = a_ok[j] ? m : 0;
-        if (p.stride != 1) {
-            const int b = (int)(src / HoWo);
-            const int rem = (int)(src - (int64_t)b * HoWo);
-            const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
-            src = ((int64_t)b * p.Hi + yo * p.stride) * p.Wi + xo * p.stride;
-        }
-        a_voff[j] = (uint32_t)src * rowbytes + c8;
-        b_ok[j] = n0 + row < p.Nout;
-        b_voff[j] = b_ok[j] ? (uint32_t)(n0 + row) * rowbytes + c8 : 0u;
-    }
-    int ld_kt = 0;
-    auto issue_tile = [&](int stage) {
-        unsigned char* st = smem + stage * S2_STAGE;
-        const uint32_t koff = (uint32_t)ld_kt * 128u;
-        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.A) + koff;
-        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koff;
-        const uint32_t zrelA = p.a_bytes - koff, zrelB = p.w_bytes - koff;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 4 * j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + S2_A_BYTES + (wave + 4 * j) * 1024);
-        ++ld_kt;
-    };
-
-    const int rot = (l16 >> 1) & 7;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
-        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
-        offB[pl] = S2_A_BYTES + (wn * 64 + l16) * 128 + pos * 16;
-    }
-    f32x4 tot4[4][4], acc4[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                tot4[i][j][r] = 0.f;
-                acc4[i][j][r] = 0.f;
-            }
-
-    issue_tile(0);
-    if (p.nkt > 1) issue_tile(1);
-    for (int kt = 0; kt < p.nkt; ++kt) {
-        if (kt + 1 < p.nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile kt landed, tile kt+1 may be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const unsigned char* st = smem + (kt & 1) * S2_STAGE;
-        f16x8 af[4][2], bf[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + i * 16 * 128);
-                bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + i * 16 * 128);
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4& a4 = acc4[i][j];
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], a4, 0, 0, 0);
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], a4, 0, 0, 0);
-            }
-        if ((kt & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    tot4[i][j] += acc4[i][j];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
-                }
-        }
-        if (kt + 2 < p.nkt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                   // every wave has read stage kt & 1: refill it with tile kt + 2
-            issue_tile(kt & 1);
-        }
-    }
-
-    const float isx = 1.f / p.sx[0], isw = 1.f / p.sw[0];
-    const bool stats = p.st_partial != nullptr;
-    const bool wide = (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                           // every wave is done with the stages: they become staging / statistics space
-    // float4 stores through a wave-private staging slice (see h2_kernel's epilogue), here in two halves of 32 rows (4 x 8.7 KB)
-    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-    double cs[4], cq[4];
-    float cmn[4], cmx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        cs[j] = 0.0;
-        cq[j] = 0.0;
-        cmn[j] = INFINITY;
-        cmx[j] = -INFINITY;
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l16;
-            const bool n_ok = n < p.Nout;
-            const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = half * 2 + ii;
-                    const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
-                    float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
-                    if (wide) {
-                        stg[(ii * 16 + 4 * g4 + r) * 68 + j * 16 + l16] = v;
-                    } else if (n_ok && m < p.M) {
-                        float* dst = p.C + m * p.ldc + n;
-                        if (p.beta) v += *dst;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        *dst = v;
-                    }
-                    if (stats && n_ok && m < p.M) {
-                        cs[j] += (double)v;
-                        cq[j] += (double)v * (double)v;
-                        cmn[j] = fminf(cmn[j], v);
-                        cmx[j] = fmaxf(cmx[j], v);
-                    }
-                }
-        }
-        if (wide) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int cq4 = lane & 15, rsub = lane >> 4;
-            const int n = n0 + wn * 64 + 4 * cq4;
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const int row = ps * 4 + rsub;
-                const int64_t m = m0 + wm * 64 + half * 32 + row;
-                if (m < p.M && n < p.Nout) {
-                    float4 v = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
-                    float4* dst = reinterpret_cast<float4*>(p.C + m * p.ldc + n);
-                    if (p.beta) {
-                        const float4 o = *dst;
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    if (p.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    *dst = v;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slice is rewritten by the second half
-        }
-    }
-    if (stats) {
-        __syncthreads();
-        double* sh_s = reinterpret_cast<double*>(smem);                  // [2 wm][128 col][2]
-        float* sh_m = reinterpret_cast<float*>(smem + 2 * S2_BN * 2 * sizeof(double));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                cs[j] += __shfl_xor(cs[j], off);
-                cq[j] += __shfl_xor(cq[j], off);
-                cmn[j] = fminf(cmn[j], __shfl_xor(cmn[j], off));
-                cmx[j] = fmaxf(cmx[j], __shfl_xor(cmx[j], off));
-            }
-            if (g4 == 0) {
-                const int col = wn * 64 + j * 16 + l16;
-                sh_s[(wm * S2_BN + col) * 2 + 0] = cs[j];
-                sh_s[(wm * S2_BN + col) * 2 + 1] = cq[j];
-                sh_m[(wm * S2_BN + col) * 2 + 0] = cmn[j];
-                sh_m[(wm * S2_BN + col) * 2 + 1] = cmx[j];
-            }
-        }
-        __syncthreads();
-        if (t < S2_BN && n0 + t < p.Nout) {
-            const double a = sh_s[t * 2 + 0] + sh_s[(S2_BN + t) * 2 + 0], b = sh_s[t * 2 + 1] + sh_s[(S2_BN + t) * 2 + 1];
-            const float mn = fminf(sh_m[t * 2 + 0], sh_m[(S2_BN + t) * 2 + 0]), mx = fmaxf(sh_m[t * 2 + 1], sh_m[(S2_BN + t) * 2 + 1]);
-            const int64_t g = tmi;
-            p.st_partial[(g * 2 + 0) * p.Nout + n0 + t] = a;
-            p.st_partial[(g * 2 + 1) * p.Nout + n0 + t] = b;
-            p.st_mm[(g * 2 + 0) * p.Nout + n0 + t] = mn;
-            p.st_mm[(g * 2 + 1) * p.Nout + n0 + t] = mx;
-        }
-    }
-}
-
-#endif  // SP_TIMING_VARIANTS
 
 // ================================================================================================================
 // Weight gradient:  dW[co][tap][ci] = sum_m dY[m][co] * X[pix(m,tap)][ci]   (K = pixels), the structure of w3_kernel:
@@ -1335,12 +809,10 @@ struct HWArgs {
     int Hi, Wi, Ci, Ho, Wo, Co;
     int KH, KW, stride, pad, dil;
     int Ntot, ldo, tiles_n, splits;
-    int map_mode;          // 1: 1-D grid, per-XCD order in which the 32 workgroups running together share ONE pixel range (see hw_kernel)
     int64_t rows_per_split, slab_stride;
     float alpha;
     int beta;
     uint32_t x_bytes, y_bytes;
-    int twobar;            // as H2Args
 };
 
 constexpr int HWA_ROW = 1024, HWB_ROW = 512;
@@ -1359,8 +831,6 @@ __device__ __forceinline__ f16x8 tr_pair_h(const unsigned char* base, int off0, 
 }
 
 __device__ __forceinline__ int rot4(int q) { return 2 * (q & 1) + 8 * (q >> 1); }
-template <bool M16>
-__device__ __forceinline__ int rotx(int r) { return rot4(r & 3) + (M16 ? 4 * ((r >> 3) & 1) : 0); }
 // 16x16x32 layout of hw_kernel: the stored position of source chunk j of pixel row r is  perm(j) ^ swz16(r), where perm moves the
 // channel-tile index i to the TOP bits of the position (so the four tiles of a wave sit 256 B apart and are reached through the
 // instruction's immediate offset: 2 + 4 address registers instead of 32) and swz16(r) in {0,2,..,14} only touches bits 1-3: the
@@ -1370,13 +840,13 @@ __device__ __forceinline__ int permA16(int j) { return ((j & 0x0c) << 2) | ((j &
 __device__ __forceinline__ int permB16(int j) { return ((j & 0x0c) << 1) | ((j & 0x10) >> 2) | (j & 3); }            // [wn|i1 i0|pl|p] -> [i1 i0|wn|pl|p]
 __device__ __forceinline__ int unpermB16(int x) { return ((x & 0x18) >> 1) | ((x & 0x04) << 2) | (x & 3); }
 
-// VAR: schedule of the two waves sharing a SIMD, as h2_kernel: 0 lockstep (round 1), 2 ping-pong with one barrier per K-tile
-// (waves 0-3: [issue loads(t+2)] [read(t)] [24 MFMA(t)]; waves 4-7: [24 MFMA(t-1)] [read(t)] [issue loads(t+2)]), 3 = 2 + s_setprio.
-// M16: v_mfma_f32_16x16x32_f16 instead of 32x32x16 (see h2_kernel): one 32-pixel k-block per K-tile, 4x4 tiles of 16x16 per wave.
-// The two 16-lane groups of a 32-lane half then read pixel rows 8 apart at the SAME channels, so the stored rotation of pixel row
-// r becomes rot4(r&3) + 4*((r>>3)&1) chunks: the 4 rows x 2 k-groups of a half again cover all 8 32-byte slots of the bank row.
-// DBG (env SP_HW_DBG, timing experiments only): 1 = no global loads, 2 = no MFMAs, 3 = MFMAs only (no loads, no LDS reads, no barriers)
-template <int VAR, int NPROD = 3, bool M16 = false, int DBG = 0>
+// Schedule: h2_kernel's ping-pong halves with one barrier per K-tile, fragment reads ahead of the LDS-DMA issue block, no s_setprio
+// (measured best here); v_mfma_f32_16x16x32_f16, one 32-pixel k-block per K-tile, 4x4 tiles of 16x16 per wave.  The two 16-lane
+// groups of a 32-lane half read pixel rows 8 apart at the SAME channels, so the stored rotation of pixel row r is
+// rot4(r&3) + 4*((r>>3)&1) chunks: the 4 rows x 2 k-groups of a half cover all 8 32-byte slots of the bank row.
+// DBG (timing library only; wrong results): 1 = no global loads, 2 = no MFMAs, 3 = MFMAs only (no loads, no LDS reads, no barriers),
+// 5 = LDS-DMA loads only, 6 = fragment reads only, 7 / 8 = only the dY / only the X loads (+ everything else), 9 = no fragment reads
+template <int NPROD, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     // DBG 5: LDS-DMA loads only (no fragment reads, no MFMAs; barriers kept); DBG 6: fragment reads only (no loads, no MFMAs)
     // DBG 7: dY (A) loads only + everything else; DBG 8: X (B) loads only + everything else; DBG 9: loads + MFMAs, no fragment reads
@@ -1387,31 +857,10 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l32 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
     int tn, tmi, split;
-    if (p.map_mode == 1) {
-        // XCD x (= block id % 8 under round-robin dispatch) owns the output-channel tiles x, x+8, ...; its workgroups are ordered so
-        // that each group of 32 consecutive ones (one per CU: they run together) covers 32 N-tiles of ONE pixel range -- they stream the
-        // same dY rows and the same (tap-shifted) X rows through the XCD's L2 in step.  With tiles ordered n-fastest across all
-        // 36 N-tiles a round straddles two pixel ranges and each range is streamed twice.  The tiles_n % 32 left-over N-tiles of all
-        // pixel ranges come last.
-        const int q = blockIdx.x >> 3, S = p.splits;
-        const int per_cot = p.tiles_n * S;
-        const int cot = q / per_cot, q2 = q - cot * per_cot;
-        tmi = cot * 8 + (blockIdx.x & 7);
-        const int G = p.tiles_n >> 5, main = G * 32 * S;
-        if (q2 < main) {
-            const int g = q2 / (32 * S), r = q2 - g * 32 * S;
-            split = r >> 5;
-            tn = g * 32 + (r & 31);
-        } else {
-            const int q3 = q2 - main, rem = p.tiles_n - G * 32;
-            split = q3 / rem;
-            tn = G * 32 + (q3 - split * rem);
-        }
-    } else {
+    {
         const int lid = xcd_remap(blockIdx.x, gridDim.x);
         tn = lid % p.tiles_n;
         tmi = lid / p.tiles_n;
@@ -1431,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     for (int j = 0; j < 4; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 6, pos = g & 63;
-        const int js = M16 ? permA16(pos ^ swz16(r)) : ((pos - rot4(r & 3)) & 63);      // which source chunk lands at this position
+        const int js = permA16(pos ^ swz16(r));      // which source chunk lands at this position
         a_r[j] = r;
         a_cok[j] = co0 + (js >> 2) * 16 < p.Co;
         a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.Co) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
@@ -1444,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     for (int j = 0; j < 2; ++j) {
         const int g = t + 512 * j;
         const int r = g >> 5, pos = g & 31;
-        const int js = M16 ? unpermB16(pos ^ swz16(r)) : ((pos - rot4(r & 3)) & 31);
+        const int js = unpermB16(pos ^ swz16(r));
         const int col = n0 + (js >> 2) * 16;                      // first column of this lane's 16-channel group
         const int tap = col / p.Ci, ci = col - tap * p.Ci;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -1524,11 +973,10 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         ++ld_kt;
     };
 
-    // transposed-read offsets.  32x32x16: k-group kk adds 16 pixel rows; lane (g4 = (lane>>4)&1, q = (lane>>2)&3, pp = lane&3)
-    // addresses pixel row 8h + 4s + q, channels cbase + 16*g4 + 4pp .. +3 of plane pl.  16x16x32: the 16-lane group kg = lane>>4
-    // is the k-group, pixel row 8kg + 4s + q, channels cbase + 4pp .. +3 of the 16-channel tile.
-    const int g4 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
-    constexpr int NT = M16 ? 4 : 2;
+    // transposed-read offsets: the 16-lane group kg = lane >> 4 is the k-group; lane (q = (lane>>2)&3, pp = lane&3) addresses pixel
+    // row 8kg + 4s + q, channels cbase + 4pp .. +3 of the 16-channel tile.
+    const int q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
+    constexpr int NT = 4;
     int offA[NT][2][2], offB[NT][2][2];     // [i][plane][s]
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -1536,34 +984,16 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                if constexpr (M16) {
-                    // base registers only for i < 2 (A: i = 0; B: i = 0, 1) and s2 = 0; the other tiles / the +4-row group are
-                    // constant byte offsets from them (A: i * 256, B: (i >> 1) * 256, s2: 4 rows), see swz16
-                    const int row = 8 * kg + q;
-                    const int pa = (((wm << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row));
-                    offA[i][pl][s2] = row * HWA_ROW + pa * 16 + (pp & 1) * 8 + i * 256 + s2 * 4 * HWA_ROW;
-                    const int pb = ((((i & 1) << 3) | (wn << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row));
-                    offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + pb * 16 + (pp & 1) * 8 + (i >> 1) * 256 + s2 * 4 * HWB_ROW;
-                } else {
-                    const int row = 8 * h + 4 * s2 + q;
-                    const int ja = (wm * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
-                    offA[i][pl][s2] = row * HWA_ROW + ((ja + rot4(q)) & 63) * 16 + (pp & 1) * 8;
-                    const int jb = (wn * 4 + i * 2 + g4) * 4 + pl * 2 + (pp >> 1);
-                    offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + ((jb + rot4(q)) & 31) * 16 + (pp & 1) * 8;
-                }
+                // base registers only for i < 2 (A: i = 0; B: i = 0, 1) and s2 = 0; the other tiles / the +4-row group are
+                // constant byte offsets from them (A: i * 256, B: (i >> 1) * 256, s2: 4 rows), see swz16
+                const int row = 8 * kg + q;
+                const int pa = (((wm << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row));
+                offA[i][pl][s2] = row * HWA_ROW + pa * 16 + (pp & 1) * 8 + i * 256 + s2 * 4 * HWA_ROW;
+                const int pb = ((((i & 1) << 3) | (wn << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row));
+                offB[i][pl][s2] = HWA_BYTES + row * HWB_ROW + pb * 16 + (pp & 1) * 8 + (i >> 1) * 256 + s2 * 4 * HWB_ROW;
             }
 
-    f32x16 tot[2][2], acc[2][2];
     f32x4 tot4[4][4], acc4[4][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                tot[i][j][r] = 0.f;
-                acc[i][j][r] = 0.f;
-            }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1604,13 +1034,9 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < (NPROD == 3 ? 2 : 1); ++pl) {
-                if constexpr (M16) {     // group kk = 16-channel tiles 2kk, 2kk+1 of the ONE 32-pixel block
-                    af[kk][i][pl] = tr_pair_h(st, offA[(2 * kk + i) % NT][pl][0], offA[(2 * kk + i) % NT][pl][1]);
-                    bf[kk][i][pl] = tr_pair_h(st, offB[(2 * kk + i) % NT][pl][0], offB[(2 * kk + i) % NT][pl][1]);
-                } else {
-                    af[kk][i][pl] = tr_pair_h(st + kk * 16 * HWA_ROW, offA[i][pl][0], offA[i][pl][1]);
-                    bf[kk][i][pl] = tr_pair_h(st + kk * 16 * HWB_ROW, offB[i][pl][0], offB[i][pl][1]);
-                }
+                // group kk = 16-channel tiles 2kk, 2kk+1 of the ONE 32-pixel block
+                af[kk][i][pl] = tr_pair_h(st, offA[(2 * kk + i) % NT][pl][0], offA[(2 * kk + i) % NT][pl][1]);
+                bf[kk][i][pl] = tr_pair_h(st, offB[(2 * kk + i) % NT][pl][0], offB[(2 * kk + i) % NT][pl][1]);
             }
     };
     auto mma_group = [&](int kk) {
@@ -1624,53 +1050,27 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                 }
             return;
         }
-        if constexpr (M16) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4& a4 = acc4[2 * kk + i][j];
-                    if constexpr (NPROD == 3) {
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
-                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                    }
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
-                }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
+                f32x4& a4 = acc4[2 * kk + i][j];
                 if constexpr (NPROD == 3) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][1], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i][0], bf[kk][j][0], acc[i][j], 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
             }
     };
     auto fold = [&](int kt_) {
-        if constexpr (M16) {
-            if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        tot4[i][j] += acc4[i][j];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
-                    }
-            }
-            return;
-        }
         if ((kt_ & (HCHUNK_KT - 1)) == HCHUNK_KT - 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    tot[i][j] += acc[i][j];
+                for (int j = 0; j < 4; ++j) {
+                    tot4[i][j] += acc4[i][j];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
                 }
         }
     };
@@ -1685,26 +1085,15 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     auto prev_stage = [](int st_) { return st_ == 0 ? HNSTAGE - 1 : st_ - 1; };
 
     int stage = 0;
-    const bool late = VAR != 0 && wave >= 4;
-    if ((VAR == 3 || VAR == 4) && late) __builtin_amdgcn_s_setprio(1);
+    const bool late = wave >= 4;
     if (!late) {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
-            if (VAR >= 2 && VAR != 4 && VAR != 5 && VAR != 6 && pre) issue_tile(prev_stage(stage));
-            if (VAR == 0 && !M16) {         // round-1 order: reads of a 16-pixel group right before its MFMAs
-                read_group(stage, 0);
-                mma_group(0);
-                read_group(stage, 1);
-                mma_group(1);
-            } else {
-                read_group(stage, 0);
-                read_group(stage, 1);
-                if ((VAR == 4 || VAR == 5 || VAR == 6) && pre) issue_tile(prev_stage(stage));      // VAR 4 / 5 / 6 (5, 6: without s_setprio): fragment reads ahead of the LDS-DMA issue block
-                if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();      // second barrier: strictly alternating matrix segments (h2_kernel)
-                mma_group(0);
-                mma_group(1);
-            }
-            if (VAR < 2 && pre) issue_tile(prev_stage(stage));
+            read_group(stage, 0);
+            read_group(stage, 1);
+            if (pre) issue_tile(prev_stage(stage));      // fragment reads ahead of the LDS-DMA issue block
+            mma_group(0);
+            mma_group(1);
             fold(kt);
             wait_barrier(kt);
             stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
@@ -1712,16 +1101,14 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     } else {
         for (int kt = 0; kt < nkt; ++kt) {
             const bool pre = kt + HNSTAGE - 1 < nkt;
-            if (VAR == 6 && pre) issue_tile(prev_stage(stage));      // VAR 6: the late waves issue their loads at the START of the
-            if (kt > 0) {                                            // iteration (their issue block no longer sits right before the barrier)
+            if (kt > 0) {
                 mma_group(0);
                 mma_group(1);
                 fold(kt - 1);
             }
-            if (VAR == 5 && p.twobar) __builtin_amdgcn_s_barrier();
             read_group(stage, 0);
             read_group(stage, 1);
-            if (VAR != 6 && pre) issue_tile(prev_stage(stage));
+            if (pre) issue_tile(prev_stage(stage));
             wait_barrier(kt);
             stage = (stage == HNSTAGE - 1) ? 0 : stage + 1;
         }
@@ -1731,12 +1118,11 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             fold(nkt - 1);
         }
     }
-    if ((VAR == 3 || VAR == 4) && late) __builtin_amdgcn_s_setprio(0);
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
     const bool direct = p.splits == 1;
     const float isx = 1.f / sx_dev, isy = 1.f / sy_dev;
-    if constexpr (M16) {
+    {
         const int l16 = lane & 15;
         // float4 stores through a wave-private LDS staging tile (see h2_kernel's epilogue): 256-byte runs instead of 64-byte ones
         const bool wide = (p.ldo & 3) == 0 && (p.Ntot & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
@@ -1791,30 +1177,6 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                         }
                     }
                 }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l32;
-        if (n >= p.Ntot) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < p.Co) {
-                    float* dst = out + (int64_t)co * p.ldo + n;
-                    const float v = tot[i][j][r] + acc[i][j][r];
-                    if (direct) {
-                        float w = p.alpha * ((v * isx) * isy);
-                        if (p.beta) w += *dst;
-                        *dst = w;
-                    } else {
-                        *dst = v;
-                    }
-                }
-            }
         }
     }
 }
@@ -1940,9 +1302,9 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
-template <int MODE, int DBG, int VAR, int NPROD = 3, bool M16 = false, bool CBM = false, bool LSTM = false, bool HALO = false>
+template <int MODE, int NPROD, bool CBM, bool LSTM = false, bool HALO = false, int DBG = 0>
 int launch_h2(const H2Args& a, hipStream_t s) {
-    auto kern = h2_kernel<MODE, DBG, VAR, NPROD, M16, CBM, LSTM, HALO>;
+    auto kern = h2_kernel<MODE, NPROD, CBM, LSTM, HALO, DBG>;
     constexpr int lds = HALO ? HALO_LDS : HNSTAGE * HSTAGE;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1956,40 +1318,19 @@ int launch_h2(const H2Args& a, hipStream_t s) {
     return SP_OK;
 }
 
-template <int VAR, int NPROD = 3, bool M16 = false, int DBG = 0>
+template <int NPROD, int DBG = 0>
 int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
-    auto kern = hw_kernel<VAR, NPROD, M16, DBG>;
+    auto kern = hw_kernel<NPROD, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HNSTAGE * HWSTAGE);
         attr_set = true;
     }
     const int64_t grid = sp_cdiv(Co, 256) * a.tiles_n;
-    if (a.map_mode == 1) hipLaunchKernelGGL(kern, dim3((unsigned)(grid * a.splits)), dim3(512), HNSTAGE * HWSTAGE, s, a);
-    else hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)a.splits), dim3(512), HNSTAGE * HWSTAGE, s, a);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
-
-#ifdef SP_TIMING_VARIANTS
-int launch_s2(const S2Args& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S2_STAGE);
-        attr_set = true;
-    }
-    const int64_t grid = sp_cdiv(a.M, S2_BM) * a.tiles_n;
-    if (grid <= 0 || grid > 0x7fffffff) return SP_EINVAL;
-    hipLaunchKernelGGL(s2_kernel, dim3((unsigned)grid), dim3(256), 2 * S2_STAGE, s, a);
-    SP_LAUNCH_CHECK();
-    return SP_OK;
-}
-
-// the short-K pointwise kernel applies: 1x1, no padding, K <= 512, forward (any stride) or stride-1 data gradient
-bool s2_applies(const sp_conv_desc* d) {
-    return sp_tuning_get(SP_TUNE_S2, 0) == 1 && d->KH * d->KW == 1 && d->pad == 0 && d->Kc <= 512 && (d->mode == 0 || d->stride == 1);
-}
-#endif  // SP_TIMING_VARIANTS
 
 int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
     SP_RESET_AMAX_ALWAYS(amax, s);   // scratch word of the caller's scale buffer (not a pooled slot); a kernel node, not a memset node: see common.h
@@ -2049,8 +1390,6 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     if (((uintptr_t)Xs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
     H2Args a{};
-    a.chunk_kt = sp_tuning_get(SP_TUNE_H2_CHUNK, HCHUNK_KT);
-    a.twobar = sp_tuning_get(SP_TUNE_TWOBAR, TWOBAR_DEFAULT);
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
     a.sx = x_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * d->Ho * d->Wo;
@@ -2070,69 +1409,28 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     const bool f = d->mode == 0;
     // channel-block-major K order: only where it is defined (several taps, mask fits, stride-1 data gradient)
     const bool cbm_ok = d->KH * d->KW > 1 && d->KH * d->KW <= 32 && (f || d->stride == 1);
-#ifdef SP_TIMING_VARIANTS
-    const int dbg = sp_tuning_get(SP_TUNE_H2_DBG, 0);
-    if (nprod == 3 && dbg == 0 && s2_applies(d)) {
-        if (st_partial && (!f || !st_mm || d->beta || d->relu || bias)) return SP_EINVAL;
-        S2Args q{};
-        q.A = a.X; q.W = a.W; q.bias = bias; q.C = out; q.sx = x_scale; q.sw = w_scale;
-        q.M = a.M; q.K = d->Kc; q.Nout = d->Nout; q.ldc = d->ldc;
-        q.Ho = d->Ho; q.Wo = d->Wo; q.Hi = d->Hi; q.Wi = d->Wi; q.stride = f ? d->stride : 1;
-        q.nkt = d->Kc / 32; q.tiles_n = (int)sp_cdiv(d->Nout, S2_BN);
-        q.alpha = d->alpha; q.beta = d->beta; q.relu = d->relu;
-        q.a_bytes = a.x_bytes; q.w_bytes = a.w_bytes;
-        q.st_partial = st_partial; q.st_mm = st_mm;
-        return launch_s2(q, st);
-    }
-#endif
     if (st_partial) {        // fused BatchNorm statistics: forward, fp32-faithful
         if (!f || !st_mm || nprod != 3 || d->beta || d->relu || bias) return SP_EINVAL;
         a.st_partial = st_partial; a.st_mm = st_mm;
-        return cbm_ok ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<0, 0, 3, 3, true, false>(a, st);
+        return cbm_ok ? launch_h2<0, 3, true>(a, st) : launch_h2<0, 3, false>(a, st);
     }
-#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes and schedule variants (A/B tools only; sp_set_tuning("h2_dbg" / "h2_variant", n))
-    if (dbg == 1) return f ? launch_h2<0, 1, 0>(a, st) : launch_h2<1, 1, 0>(a, st);
-    if (dbg == 2) return f ? launch_h2<0, 2, 0>(a, st) : launch_h2<1, 2, 0>(a, st);
-    if (dbg == 3) return f ? launch_h2<0, 3, 0>(a, st) : launch_h2<1, 3, 0>(a, st);
-    if (dbg == 5) return f ? launch_h2<0, 5, 3, 3, true>(a, st) : launch_h2<1, 5, 3, 3, true>(a, st);
-    if (dbg == 6) return f ? launch_h2<0, 1, 3, 3, true>(a, st) : launch_h2<1, 1, 3, 3, true>(a, st);      // no loads, 16x16x32 ping-pong
-    if (dbg == 7) return f ? launch_h2<0, 2, 3, 3, true>(a, st) : launch_h2<1, 2, 3, 3, true>(a, st);      // no MFMAs
-    if (dbg == 8) return f ? launch_h2<0, 3, 3, 3, true>(a, st) : launch_h2<1, 3, 3, 3, true>(a, st);      // MFMAs only
-    if (dbg == 9) return f ? launch_h2<0, 9, 3, 3, true>(a, st) : launch_h2<1, 9, 3, 3, true>(a, st);      // LDS-DMA loads only
-    if (dbg == 10) return f ? launch_h2<0, 10, 5, 3, true, true>(a, st) : launch_h2<1, 10, 5, 3, true, true>(a, st);  // half the weight-side LDS traffic
-    if (dbg == 11) return f ? launch_h2<0, 11, 5, 3, true, true>(a, st) : launch_h2<1, 11, 5, 3, true, true>(a, st);  // a third of the activation LDS-DMA pieces
-    if (nprod == 3) {
-        int variant = sp_tuning_get(SP_TUNE_H2_VARIANT, H2_DEFAULT_VARIANT);
-        if ((variant == 17 || variant == 18 || variant == 19) && !cbm_ok) variant = 7;
-        if (variant < 16 && (variant & 8) && !cbm_ok) variant &= 7;
-        switch (variant) {
-            case 16: return f ? launch_h2<0, 0, 4, 3, true>(a, st) : launch_h2<1, 0, 4, 3, true>(a, st);      // 16x16x32, spread LDS-DMA issue
-            case 18: return f ? launch_h2<0, 0, 6, 3, true, true>(a, st) : launch_h2<1, 0, 6, 3, true, true>(a, st);      // ping-pong + LDS-DMA pieces spread through the matrix segment
-            case 19: return f ? launch_h2<0, 0, 7, 3, true, true>(a, st) : launch_h2<1, 0, 7, 3, true, true>(a, st);      // = 17 without s_setprio on the late waves
-            case 8: return f ? launch_h2<0, 0, 0, 3, false, true>(a, st) : launch_h2<1, 0, 0, 3, false, true>(a, st);
-            case 11: return f ? launch_h2<0, 0, 3, 3, false, true>(a, st) : launch_h2<1, 0, 3, 3, false, true>(a, st);
-            case 12: return f ? launch_h2<0, 0, 0, 3, true, true>(a, st) : launch_h2<1, 0, 0, 3, true, true>(a, st);
-            case 14: return f ? launch_h2<0, 0, 2, 3, true, true>(a, st) : launch_h2<1, 0, 2, 3, true, true>(a, st);
-            case 15: return f ? launch_h2<0, 0, 3, 3, true, true>(a, st) : launch_h2<1, 0, 3, 3, true, true>(a, st);
-            case 0: return f ? launch_h2<0, 0, 0>(a, st) : launch_h2<1, 0, 0>(a, st);
-            case 1: return f ? launch_h2<0, 0, 1>(a, st) : launch_h2<1, 0, 1>(a, st);
-            case 2: return f ? launch_h2<0, 0, 2>(a, st) : launch_h2<1, 0, 2>(a, st);
-            case 3: return f ? launch_h2<0, 0, 3>(a, st) : launch_h2<1, 0, 3>(a, st);
-            case 4: return f ? launch_h2<0, 0, 0, 3, true>(a, st) : launch_h2<1, 0, 0, 3, true>(a, st);      // 16x16x32, lockstep
-            case 5: return f ? launch_h2<0, 0, 1, 3, true>(a, st) : launch_h2<1, 0, 1, 3, true>(a, st);      // 16x16x32, half stagger
-            case 6: return f ? launch_h2<0, 0, 2, 3, true>(a, st) : launch_h2<1, 0, 2, 3, true>(a, st);      // 16x16x32, ping-pong
-            default: break;                                                                                  // 17 / 7: the product schedules below
-        }
+#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes of the tap-major build (A/B tools only; sp_set_tuning("h2_dbg", n))
+    switch (sp_tuning_get(SP_TUNE_H2_DBG, 0)) {
+        case 6: return f ? launch_h2<0, 3, false, false, false, 1>(a, st) : launch_h2<1, 3, false, false, false, 1>(a, st);      // no loads
+        case 7: return f ? launch_h2<0, 3, false, false, false, 2>(a, st) : launch_h2<1, 3, false, false, false, 2>(a, st);      // no MFMAs
+        case 8: return f ? launch_h2<0, 3, false, false, false, 3>(a, st) : launch_h2<1, 3, false, false, false, 3>(a, st);      // MFMAs only
+        case 9: return f ? launch_h2<0, 3, false, false, false, 9>(a, st) : launch_h2<1, 3, false, false, false, 9>(a, st);      // LDS-DMA loads only
+        default: break;
     }
 #endif
-    if (nprod == 1)      // throughput mode: load-bound, the ping-pong schedule
-        return f ? launch_h2<0, 0, 2, 1>(a, st) : launch_h2<1, 0, 2, 1>(a, st);
-    // product schedules: 16x16x32 MFMAs, ping-pong halves with s_setprio; channel-block-major K order with the fragment reads ahead
-    // of the LDS-DMA issue block where that order is defined, tap-major otherwise
-    if (cbm_ok && halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1)      // one halo'd activation block per channel block for all 9 taps
-        return f ? launch_h2<0, 0, 5, 3, true, true, false, true>(a, st) : launch_h2<1, 0, 5, 3, true, true, false, true>(a, st);
-    if (cbm_ok) return f ? launch_h2<0, 0, 5, 3, true, true>(a, st) : launch_h2<1, 0, 5, 3, true, true>(a, st);
-    return f ? launch_h2<0, 0, 3, 3, true>(a, st) : launch_h2<1, 0, 3, 3, true>(a, st);
+    if (nprod == 1)      // throughput mode (one product, both operands rounded to one fp16 plane): tap-major build
+        return f ? launch_h2<0, 1, false>(a, st) : launch_h2<1, 1, false>(a, st);
+    // channel-block-major K order where that order is defined (with one halo'd activation block per channel block for all 9 taps
+    // where the shape allows it), tap-major otherwise
+    if (cbm_ok && halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1)
+        return f ? launch_h2<0, 3, true, false, true>(a, st) : launch_h2<1, 3, true, false, true>(a, st);
+    if (cbm_ok) return f ? launch_h2<0, 3, true>(a, st) : launch_h2<1, 3, true>(a, st);
+    return f ? launch_h2<0, 3, false>(a, st) : launch_h2<1, 3, false>(a, st);
 }
 
 extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
@@ -2144,9 +1442,6 @@ extern "C" int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xs, const 
 // st_mm [tiles][2][Nout] floats (min, max), tiles = sp_conv_stats_tiles(M) -- the layout sp_bn_fwd_split accepts as pre_partial
 extern "C" int64_t sp_conv_stats_tiles(const sp_conv_desc* d) {
     if (!d) return 0;
-#ifdef SP_TIMING_VARIANTS
-    if (s2_applies(d)) return sp_cdiv((int64_t)d->N_img * d->Ho * d->Wo, S2_BM);
-#endif
     return sp_cdiv((int64_t)d->N_img * d->Ho * d->Wo, HBM);
 }
 extern "C" int sp_conv_igemm_f16x2_stats(const sp_conv_desc* d, const void* Xs, const float* x_scale, const void* Ws,
@@ -2174,8 +1469,6 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (P != d->Ho * d->Wo || P % HBM || KP < 1 || KP > 32) return SP_EINVAL;
     if (((uintptr_t)Hs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     H2Args a{};
-    a.chunk_kt = sp_tuning_get(SP_TUNE_H2_CHUNK, HCHUNK_KT);
-    a.twobar = sp_tuning_get(SP_TUNE_TWOBAR, TWOBAR_DEFAULT);
     a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
     a.sx = h_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * P;
@@ -2194,12 +1487,11 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (hout_planes && (!hout_scale || !(hout_bound > 0.f) || ((uintptr_t)hout_planes & 15))) return SP_EINVAL;
     a.l_gates = gates; a.l_c = c_out; a.l_h = h_out; a.l_hamax = h_amax;
     a.l_hplanes = (uint16_t*)hout_planes; a.l_hscale = hout_scale; a.l_hbound = hout_bound;
-    a.l_direct_hc = (!hout_planes && sp_tuning_get(SP_TUNE_LSTM_EPI, 0) == 1) ? 1 : 0;      // (timing build A/B switch; 0 in the product)
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);
-    if (halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1) return launch_h2<0, 0, 5, 3, true, true, true, true>(a, st);
-    return launch_h2<0, 0, 5, 3, true, true, true>(a, st);
+    if (halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1) return launch_h2<0, 3, true, true, true>(a, st);
+    return launch_h2<0, 3, true, true, false>(a, st);
 }
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
@@ -2214,7 +1506,6 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     if (d->Ci % 16 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
     if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
     HWArgs a;
-    a.twobar = sp_tuning_get(SP_TUNE_TWOBAR, TWOBAR_DEFAULT);
     a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;
     a.sx = x_scale; a.sy = y_scale;
     a.M = (int64_t)d->N_img * d->Ho * d->Wo;
@@ -2225,7 +1516,6 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     a.tiles_n = (int)sp_cdiv(a.Ntot, 128);
     a.splits = hw_splits(d);
     if (a.splits > 1 && !workspace) return SP_ENULL;
-    a.map_mode = (sp_tuning_get(SP_TUNE_HW_MAP, HW_DEFAULT_MAP) == 1 && sp_cdiv(d->Co, 256) % 8 == 0) ? 1 : 0;
     a.rows_per_split = sp_cdiv(sp_cdiv(a.M, a.splits), 32) * 32;
     a.slab_stride = (int64_t)d->Co * d->ldo;
     a.out = a.splits > 1 ? (float*)workspace : dW;
@@ -2235,35 +1525,21 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     if (xb + 64 >= (1LL << 32) || yb + 64 >= (1LL << 32) || d->Ho * d->Wo < 1) return SP_EINVAL;
     a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    rc = -1000;
-#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes and schedule variants (A/B tools only; sp_set_tuning("hw_dbg" / "hw_variant", n))
-    const int dbg = sp_tuning_get(SP_TUNE_HW_DBG, 0);
-    if (dbg == 1) rc = launch_hw<2, 3, true, 1>(a, d->Co, s);
-    else if (dbg == 2) rc = launch_hw<2, 3, true, 2>(a, d->Co, s);
-    else if (dbg == 3) rc = launch_hw<2, 3, true, 3>(a, d->Co, s);
-    else if (dbg == 4) rc = launch_hw<2, 3, false, 1>(a, d->Co, s);
-    else if (dbg == 5) rc = launch_hw<2, 3, true, 5>(a, d->Co, s);
-    else if (dbg == 6) rc = launch_hw<2, 3, true, 6>(a, d->Co, s);
-    else if (dbg == 7) rc = launch_hw<2, 3, true, 7>(a, d->Co, s);
-    else if (dbg == 8) rc = launch_hw<2, 3, true, 8>(a, d->Co, s);
-    else if (dbg == 9) rc = launch_hw<2, 3, true, 9>(a, d->Co, s);
-    else if (nprod == 3) switch (sp_tuning_get(SP_TUNE_HW_VARIANT, HW_DEFAULT_VARIANT)) {
-        case 0: rc = launch_hw<0>(a, d->Co, s); break;
-        case 2: rc = launch_hw<2>(a, d->Co, s); break;
-        case 3: rc = launch_hw<3>(a, d->Co, s); break;
-        case 4: rc = launch_hw<0, 3, true>(a, d->Co, s); break;      // 16x16x32, lockstep
-        case 6: rc = launch_hw<2, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong
-        case 8: rc = launch_hw<4, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong, fragment reads before the load issue
-        case 11: rc = launch_hw<6, 3, true>(a, d->Co, s); break;     // = 10 with the late waves' loads issued at the start of their iteration
-        case 7: rc = launch_hw<3, 3, true>(a, d->Co, s); break;      // 16x16x32, ping-pong + setprio
-        default: break;                                              // 10: the product schedule below
+    int rc = -1000;
+#ifdef SP_TIMING_VARIANTS      // wrong-result timing modes (A/B tools only; sp_set_tuning("hw_dbg", n))
+    switch (sp_tuning_get(SP_TUNE_HW_DBG, 0)) {
+        case 1: rc = launch_hw<3, 1>(a, d->Co, s); break;
+        case 2: rc = launch_hw<3, 2>(a, d->Co, s); break;
+        case 3: rc = launch_hw<3, 3>(a, d->Co, s); break;
+        case 5: rc = launch_hw<3, 5>(a, d->Co, s); break;
+        case 6: rc = launch_hw<3, 6>(a, d->Co, s); break;
+        case 7: rc = launch_hw<3, 7>(a, d->Co, s); break;
+        case 8: rc = launch_hw<3, 8>(a, d->Co, s); break;
+        case 9: rc = launch_hw<3, 9>(a, d->Co, s); break;
+        default: break;
     }
 #endif
-    if (rc == -1000) {
-        if (nprod == 1) rc = launch_hw<2, 1>(a, d->Co, s);           // throughput mode
-        else rc = launch_hw<5, 3, true>(a, d->Co, s);                // product schedule: 16x16x32, ping-pong, reads before the load issue, no setprio
-    }
+    if (rc == -1000) rc = nprod == 1 ? launch_hw<1>(a, d->Co, s) : launch_hw<3>(a, d->Co, s);      // 1: throughput mode
     if (rc != SP_OK) return rc;
     if (a.splits > 1) {
         const int64_t total = (int64_t)d->Co * a.Ntot;

@@ -193,12 +193,11 @@ extern "C" int sp_scale_by(const float* x, const float* scale, int64_t n, float*
 
 extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
 
-int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};
 
 extern "C" int sp_set_tuning(const char* name, int value) {
     if (!name) return SP_ENULL;
-    const char* names[SP_TUNE_COUNT] = {"h2_variant", "hw_variant", "hw_map", "hw_splits", "amax_reset", "s2", "lstm_epi", "h2_chunk",
-                                        "h2_dbg", "hw_dbg", "b3_dbg", "h2_halo", "twobar"};
+    const char* names[SP_TUNE_COUNT] = {"amax_reset", "hw_splits", "h2_halo", "h2_dbg", "hw_dbg", "b3_dbg"};
     for (int i = 0; i < SP_TUNE_COUNT; ++i) {
         const char *a = names[i], *b = name;
         while (*a && *a == *b) { ++a; ++b; }
@@ -213,7 +212,7 @@ extern "C" int sp_set_tuning(const char* name, int value) {
     return SP_EINVAL;
 }
 
-// 1 in libscanpaths_amd_timing.so (wrong-result timing modes and schedule variants compiled in), 0 in the product library
+// 1 in libscanpaths_amd_timing.so (wrong-result timing modes and A/B switches compiled in), 0 in the product library
 extern "C" int sp_timing_build(void) {
 #ifdef SP_TIMING_VARIANTS
     return 1;

@@ -164,10 +164,8 @@ def lib() -> C.CDLL:
         if _lib.sp_timing_build() != int(TIMING_LIB):
             raise RuntimeError(f"{LIB_PATH}: timing / product build mix-up")
         if TIMING_LIB:      # A/B timing / profiling knobs, honoured by the timing build only
-            for env, knob in (("SP_H2_VARIANT", b"h2_variant"), ("SP_HW_VARIANT", b"hw_variant"), ("SP_LSTM_EPI", b"lstm_epi"),
-                              ("SP_S2", b"s2"), ("SP_H2_CHUNK", b"h2_chunk"), ("SP_H2_DBG", b"h2_dbg"), ("SP_HW_DBG", b"hw_dbg"),
-                              ("SP_B3_DBG", b"b3_dbg"), ("SP_HW_MAP", b"hw_map"), ("SP_HW_SPLITS", b"hw_splits"),
-                              ("SP_H2_HALO", b"h2_halo"), ("SP_TWOBAR", b"twobar")):
+            for env, knob in (("SP_H2_DBG", b"h2_dbg"), ("SP_HW_DBG", b"hw_dbg"), ("SP_B3_DBG", b"b3_dbg"),
+                              ("SP_HW_SPLITS", b"hw_splits"), ("SP_H2_HALO", b"h2_halo")):
                 if os.environ.get(env):
                     check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib

@@ -676,8 +676,7 @@ def test_product_library_has_no_timing_modes():
     from scanpaths_amd import hip
     L = hip.lib()
     assert L.sp_timing_build() == 0 and hip.LIB_PATH.endswith("libscanpaths_amd.so")
-    for name in (b"h2_dbg", b"hw_dbg", b"b3_dbg", b"h2_variant", b"hw_variant", b"s2", b"lstm_epi", b"hw_map", b"hw_splits", b"h2_chunk",
-                 b"nonsense"):
+    for name in (b"h2_dbg", b"hw_dbg", b"b3_dbg", b"hw_splits", b"h2_halo", b"h2_variant", b"nonsense"):
         assert L.sp_set_tuning(name, 1) == -1, name
     assert L.sp_set_tuning(b"amax_reset", 1) == 0
 
