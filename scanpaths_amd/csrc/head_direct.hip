@@ -159,57 +159,105 @@ __global__ __launch_bounds__(256) void sal_gather_bwd_kernel(const float* __rest
 }
 
 // ---- duration sites ------------------------------------------------------------------------------------------
-// Dpre[i][b][s] = cbsum[src][cls(s)] + <W11[src][cls(s)], h[b, 5s-4 .. 5s+6, :]>.  grid (S, B, ceil(nsel/2)), 256 threads;
-// a block evaluates two head slots on one read of the window (AiR: good + poor head).
+// Dpre[i][b][s] = cbsum[src][cls(s)] + <W11[src][cls(s)], h[b, 5s-4 .. 5s+6, :]>.  grid (S, ceil(B/4), ceil(nsel/2)), 256 threads;
+// a block evaluates two head slots on one read of the window (AiR: good + poor head), and its site for a GROUP of up to four
+// samples: when they use the same source heads (always, except COCO's per-sample heads) the 2 x 248 KB of W11 are read once per
+// group instead of once per sample -- the kernel is bound by those L2 reads.  Per (sample, slot) the sum order is unchanged.
+constexpr int DRT_GB = 4;
 __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ h, const float* __restrict__ W11,
                                                       const float* __restrict__ cbsum, const int* __restrict__ hmap, int B,
                                                       int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
                                                       float* __restrict__ Dpre) {
     __shared__ float sh4[4];
-    const int s = blockIdx.x, b = blockIdx.y, i0 = blockIdx.z * 2;
+    const int s = blockIdx.x, b0 = blockIdx.y * DRT_GB, i0 = blockIdx.z * 2;
+    const int nb = min(DRT_GB, B - b0);
     const bool two = i0 + 1 < nsel;
     const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;
     const int sy = s / ax.n, sx = s % ax.n;
     const int cls = ay.cls[sy] * ax.ncls + ax.cls[sx];
-    const int src0 = hmap[b * nsel + i0], src1 = two ? hmap[b * nsel + i0 + 1] : src0;
     const int oy = 5 * sy - 4, ox = 5 * sx - 4;
-    const f32x4* H4 = reinterpret_cast<const f32x4*>(h) + (int64_t)b * Hm * Wm * C4;
-    const f32x4* W40 = reinterpret_cast<const f32x4*>(W11) + ((int64_t)src0 * ncls + cls) * NV * C4;
-    const f32x4* W41 = reinterpret_cast<const f32x4*>(W11) + ((int64_t)src1 * ncls + cls) * NV * C4;
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int idx = threadIdx.x; idx < NV * C4; idx += 256) {
-        const int v = idx / C4, c4 = idx - v * C4;
-        const int qy = oy + v / 11, qx = ox + v % 11;
-        if ((unsigned)qy >= (unsigned)Hm || (unsigned)qx >= (unsigned)Wm) continue;
-        const f32x4 a = H4[(int64_t)(qy * Wm + qx) * C4 + c4], w = W40[idx];
-        acc0 += a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
-        if (two) {
-            const f32x4 u = W41[idx];
-            acc1 += a[0] * u[0] + a[1] * u[1] + a[2] * u[2] + a[3] * u[3];
+    int src0[DRT_GB], src1[DRT_GB];
+    bool same = true;
+#pragma unroll
+    for (int j = 0; j < DRT_GB; ++j) {
+        const int b = min(b0 + j, B - 1);
+        src0[j] = hmap[b * nsel + i0];
+        src1[j] = two ? hmap[b * nsel + i0 + 1] : src0[j];
+        same = same && src0[j] == src0[0] && src1[j] == src1[0];
+    }
+    const int64_t wstride = (int64_t)ncls * NV * C4;
+    const f32x4* W4c = reinterpret_cast<const f32x4*>(W11) + (int64_t)cls * NV * C4;
+    const f32x4* H4 = reinterpret_cast<const f32x4*>(h);
+    const int64_t hb = (int64_t)Hm * Wm * C4;
+    float acc0[DRT_GB], acc1[DRT_GB];
+#pragma unroll
+    for (int j = 0; j < DRT_GB; ++j) acc0[j] = acc1[j] = 0.f;
+    // the taps inside the map form a rectangle [vy0, vy1] x [vx0, vx1] of the 11 x 11 window: a branch-free loop over it (with the
+    // bounds test inside the loop the compiler kept one iteration's loads in flight at a time)
+    const int vy0 = max(0, -oy), vy1 = min(10, Hm - 1 - oy), vx0 = max(0, -ox), vx1 = min(10, Wm - 1 - ox);
+    const int nvx = vx1 - vx0 + 1, cnt = max(0, vy1 - vy0 + 1) * max(0, nvx);
+#pragma unroll 4
+    for (int it = threadIdx.x; it < cnt * C4; it += 256) {
+        const int k = it / C4, c4 = it - k * C4;
+        const int ky = k / nvx, vy = vy0 + ky, vx = vx0 + (k - ky * nvx);
+        const int idx = (vy * 11 + vx) * C4 + c4;
+        const int64_t ho = (int64_t)((oy + vy) * Wm + ox + vx) * C4 + c4;
+        f32x4 a[DRT_GB];
+#pragma unroll
+        for (int j = 0; j < DRT_GB; ++j) a[j] = H4[(int64_t)min(b0 + j, B - 1) * hb + ho];
+        if (same) {
+            const f32x4 w = W4c[src0[0] * wstride + idx];
+#pragma unroll
+            for (int j = 0; j < DRT_GB; ++j) acc0[j] += a[j][0] * w[0] + a[j][1] * w[1] + a[j][2] * w[2] + a[j][3] * w[3];
+            if (two) {
+                const f32x4 u = W4c[src1[0] * wstride + idx];
+#pragma unroll
+                for (int j = 0; j < DRT_GB; ++j) acc1[j] += a[j][0] * u[0] + a[j][1] * u[1] + a[j][2] * u[2] + a[j][3] * u[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DRT_GB; ++j) {
+                const f32x4 w = W4c[src0[j] * wstride + idx];
+                acc0[j] += a[j][0] * w[0] + a[j][1] * w[1] + a[j][2] * w[2] + a[j][3] * w[3];
+                if (two) {
+                    const f32x4 u = W4c[src1[j] * wstride + idx];
+                    acc1[j] += a[j][0] * u[0] + a[j][1] * u[1] + a[j][2] * u[2] + a[j][3] * u[3];
+                }
+            }
         }
     }
-    acc0 = block_sum_256(acc0, sh4);
-    if (two) acc1 = block_sum_256(acc1, sh4);
-    if (threadIdx.x == 0) {
-        Dpre[((int64_t)i0 * B + b) * S + s] = acc0 + cbsum[src0 * ncls + cls];
-        if (two) Dpre[((int64_t)(i0 + 1) * B + b) * S + s] = acc1 + cbsum[src1 * ncls + cls];
+#pragma unroll
+    for (int j = 0; j < DRT_GB; ++j) {
+        if (j >= nb) break;                       // (uniform)
+        const float r0 = block_sum_256(acc0[j], sh4);
+        const float r1 = two ? block_sum_256(acc1[j], sh4) : 0.f;
+        if (threadIdx.x == 0) {
+            Dpre[((int64_t)i0 * B + b0 + j) * S + s] = r0 + cbsum[src0[j] * ncls + cls];
+            if (two) Dpre[((int64_t)(i0 + 1) * B + b0 + j) * S + s] = r1 + cbsum[src1[j] * ncls + cls];
+        }
     }
 }
 
-// dh[b][q][c] (+)= sum over the sites whose window covers q, over the head slots.
+// dh[b][q][c] (+)= sum over the sites whose window covers q, over the head slots.  A thread owns (pixel q, channel quad c4) for a
+// GROUP of up to four samples: the up to 9 sites x nsel filter rows it needs are the same for every sample that uses the same
+// source heads, so they are read once per group (the kernel is bound by these L2 reads: 18 float4 of W11 per float4 of dh).
 __global__ __launch_bounds__(256) void drt_bwd_data_kernel(const float* __restrict__ dD, const float* __restrict__ W11,
                                                            const int* __restrict__ hmap, int B, int C4, int nsel, int ncls,
                                                            AxisCls ay, AxisCls ax, int accumulate, float* __restrict__ dh) {
     const int Hm = ay.len, Wm = ax.len, P = Hm * Wm, S = ay.n * ax.n;
     const f32x4* W4 = reinterpret_cast<const f32x4*>(W11);
     f32x4* O4 = reinterpret_cast<f32x4*>(dh);
-    const int64_t n = (int64_t)B * P * C4;
+    const int NG = (B + DRT_GB - 1) / DRT_GB;
+    const int64_t n = (int64_t)NG * P * C4;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(t % C4);
-        const int64_t bq = t / C4;
-        const int q = (int)(bq % P), b = (int)(bq / P);
+        const int64_t gq = t / C4;
+        const int q = (int)(gq % P), b0 = (int)(gq / P) * DRT_GB;
+        const int nb = min(DRT_GB, B - b0);
         const int qy = q / Wm, qx = q % Wm;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[DRT_GB];
+#pragma unroll
+        for (int j = 0; j < DRT_GB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int sy_lo = qy >= 6 ? (qy - 6 + 4) / 5 : 0, sy_hi = min(ay.n - 1, (qy + 4) / 5);
         const int sx_lo = qx >= 6 ? (qx - 6 + 4) / 5 : 0, sx_hi = min(ax.n - 1, (qx + 4) / 5);
         for (int sy = sy_lo; sy <= sy_hi; ++sy)
@@ -217,21 +265,43 @@ __global__ __launch_bounds__(256) void drt_bwd_data_kernel(const float* __restri
                 const int v = (qy - 5 * sy + 4) * 11 + (qx - 5 * sx + 4);
                 const int cls = ay.cls[sy] * ax.ncls + ax.cls[sx];
                 for (int i = 0; i < nsel; ++i) {
-                    const float g = dD[((int64_t)i * B + b) * S + sy * ax.n + sx];
-                    const int src = hmap[b * nsel + i];
-                    acc += g * W4[(((int64_t)src * ncls + cls) * NV + v) * C4 + c4];
+                    const int src0 = hmap[b0 * nsel + i];
+                    f32x4 w0 = W4[(((int64_t)src0 * ncls + cls) * NV + v) * C4 + c4];
+#pragma unroll
+                    for (int j = 0; j < DRT_GB; ++j) {
+                        if (j >= nb) break;
+                        const int b = b0 + j;
+                        const float g = dD[((int64_t)i * B + b) * S + sy * ax.n + sx];
+                        const int src = hmap[b * nsel + i];
+                        const f32x4 w = src == src0 ? w0 : W4[(((int64_t)src * ncls + cls) * NV + v) * C4 + c4];
+                        acc[j] += g * w;
+                    }
                 }
             }
-        if (accumulate) acc += O4[t];
-        O4[t] = acc;
+#pragma unroll
+        for (int j = 0; j < DRT_GB; ++j) {
+            if (j >= nb) break;
+            const int64_t o = ((int64_t)(b0 + j) * P + q) * C4 + c4;
+            f32x4 r = acc[j];
+            if (accumulate) r += O4[o];
+            O4[o] = r;
+        }
     }
 }
 
 // per-(sample, slot) partial of dW11: slab[b][i][cls][v][c] = sum_{s in cls} dD[i][b][s] * h[b][win(s)+v][c].
 // grid (121*ncls, B, ceil(nsel/2)), 128 threads over c4; two head slots per read of h.
+// The block first compacts the sites of its class whose tap lands inside the map into LDS (site order kept: the sum order, hence the
+// result, is that of the plain nested loop), then streams their h rows eight loads at a time.  With the class test inside the load
+// loop every thread had ONE load in flight (the interior class of the 40x64 map has 66 sites: 66 dependent L2 round trips per block,
+// 292 us per launch for 0.4 GFLOP); the compacted form is bound by the L2 reads instead.
+constexpr int DRT_MAXS = MAXSITE * MAXSITE;
 __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __restrict__ dD, const float* __restrict__ h, int B,
                                                              int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
                                                              float* __restrict__ slab) {
+    __shared__ int s_pix[DRT_MAXS];
+    __shared__ float s_g0[DRT_MAXS], s_g1[DRT_MAXS];
+    __shared__ int s_cnt[2];
     const int v = blockIdx.x % NV, cls = blockIdx.x / NV, b = blockIdx.y, i0 = blockIdx.z * 2;
     const bool two = i0 + 1 < nsel;
     const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;
@@ -241,18 +311,37 @@ __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __rest
     const float* g1 = dD + ((int64_t)(two ? i0 + 1 : i0) * B + b) * S;
     f32x4* O40 = reinterpret_cast<f32x4*>(slab) + ((((int64_t)b * nsel + i0) * ncls + cls) * NV + v) * C4;
     f32x4* O41 = O40 + (int64_t)ncls * NV * C4;
-    for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int n = 0;
+    for (int s0 = 0; s0 < S; s0 += 128) {
+        const int s = s0 + tid;
+        const int sy = s / ax.n, sx = s - sy * ax.n;
+        const int qy = 5 * sy - 4 + vy, qx = 5 * sx - 4 + vx;
+        const bool valid = s < S && (unsigned)qy < (unsigned)Hm && (unsigned)qx < (unsigned)Wm && ay.cls[sy] * ax.ncls + ax.cls[sx] == cls;
+        const unsigned long long m = __ballot(valid);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        const int pos = n + (wave ? s_cnt[0] : 0) + __popcll(m & ((1ull << lane) - 1ull));
+        if (valid) {
+            s_pix[pos] = qy * Wm + qx;
+            s_g0[pos] = g0[s];
+            s_g1[pos] = g1[s];
+        }
+        n += s_cnt[0] + s_cnt[1];
+        __syncthreads();
+    }
+    for (int c4 = tid; c4 < C4; c4 += blockDim.x) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int sy = 0; sy < ay.n; ++sy) {
-            const int qy = 5 * sy - 4 + vy;
-            if ((unsigned)qy >= (unsigned)Hm) continue;
-            for (int sx = 0; sx < ax.n; ++sx) {
-                const int qx = 5 * sx - 4 + vx;
-                if ((unsigned)qx >= (unsigned)Wm || ay.cls[sy] * ax.ncls + ax.cls[sx] != cls) continue;
-                const f32x4 a = H4[(int64_t)(qy * Wm + qx) * C4 + c4];
-                acc0 += g0[sy * ax.n + sx] * a;
-                acc1 += g1[sy * ax.n + sx] * a;
-            }
+        for (int k = 0; k < n; k += 8) {
+            f32x4 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = H4[(int64_t)s_pix[min(k + u, n - 1)] * C4 + c4];      // (clamped: always a legal row)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k + u < n) {
+                    acc0 += s_g0[k + u] * a[u];
+                    acc1 += s_g1[k + u] * a[u];
+                }
         }
         O40[c4] = acc0;
         if (two) O41[c4] = acc1;
@@ -356,7 +445,7 @@ extern "C" int sp_drt_direct_fwd(const float* h, const float* W11, const float* 
     if (!h || !W11 || !cbsum || !hmap || !Dpre) return SP_ENULL;
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
-    hipLaunchKernelGGL(drt_fwd_kernel, dim3(ay.n * ax.n, B, (nsel + 1) / 2), dim3(256), 0, (hipStream_t)stream, h, W11, cbsum, hmap, B,
+    hipLaunchKernelGGL(drt_fwd_kernel, dim3(ay.n * ax.n, (B + DRT_GB - 1) / DRT_GB, (nsel + 1) / 2), dim3(256), 0, (hipStream_t)stream, h, W11, cbsum, hmap, B,
                        C / 4, nsel, ay.ncls * ax.ncls, ay, ax, Dpre);
     SP_LAUNCH_CHECK();
     return SP_OK;
@@ -367,7 +456,7 @@ extern "C" int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, cons
     if (!dDpre || !W11 || !hmap || !dh) return SP_ENULL;
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
-    hipLaunchKernelGGL(drt_bwd_data_kernel, dim3(ew_grid((int64_t)B * Hm * Wm * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(drt_bwd_data_kernel, dim3(ew_grid((int64_t)((B + DRT_GB - 1) / DRT_GB) * Hm * Wm * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                        dDpre, W11, hmap, B, C / 4, nsel, ay.ncls * ax.ncls, ay, ax, accumulate, dh);
     SP_LAUNCH_CHECK();
     return SP_OK;
