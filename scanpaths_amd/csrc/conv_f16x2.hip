@@ -47,9 +47,12 @@ struct H2Args {
     const float* sw;
     int64_t M;
     int Hi, Wi, Kc;
+    int ldx;              // channels per pixel row of X (>= Kc: a GEMM may take the first Kc channels of wider rows)
     int Ho, Wo, Nout, ldc;
     int KH, KW, stride, pad, dil;
     int64_t ldwb;         // bytes per weight row (4 * K)
+    int64_t w_bstride;    // tap-major build: bytes between the weight sets of consecutive batch items (0: one shared set)
+    int rows_per_batch;   // output rows per batch item (a multiple of the 256-row tile)
     int ncblk, nkt, tiles_n;
     float alpha;
     int beta, relu;
@@ -172,10 +175,20 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             b_voff[j] = b_ok[j] ? (uint32_t)((int64_t)(n0 + row) * p.ldwb + c8) : 0u;
         }
     }
+    // batched GEMM with one weight set per batch item (tap-major build: the cell backward's rank-1 terms): the tile lies inside one item
+    const unsigned char* Wl = reinterpret_cast<const unsigned char*>(p.W);
+    uint32_t w_left = p.w_bytes;              // bytes from Wl to the zero block behind the last weight set
+    if constexpr (!CBM) {
+        if (p.w_bstride) {
+            const int64_t off = (m0 / p.rows_per_batch) * p.w_bstride;
+            Wl += off;
+            w_left -= (uint32_t)off;
+        }
+    }
     int ld_ky = 0, ld_kx = 0, ld_cblk = 0, ld_kt = 0;
     uint32_t a_voff[4];
     bool a_ok[4];
-    const int rowbytes = p.Kc * 4;
+    const int rowbytes = p.ldx * 4;
     uint32_t a_base0[4], a_mask[4];      // CBM: offset of the lane's pixel at tap (0,0) (wrapping arithmetic), valid-tap bits
     if constexpr (CBM && !HALO) {
 #pragma unroll
@@ -300,8 +313,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + (a_ok[j] ? a_voff[j] : zrelA), st + (wave + 8 * j) * 1024);
         const uint32_t koffB = (uint32_t)ld_kt * 128u;
-        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(p.W) + koffB;
-        const uint32_t zrelB = p.w_bytes - koffB;
+        const unsigned char* baseB = Wl + koffB;
+        const uint32_t zrelB = w_left - koffB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) SP_GLDS16(baseB + (b_ok[j] ? b_voff[j] : zrelB), st + HA_BYTES + (wave + 8 * j) * 1024);
         ++ld_kt;
@@ -807,6 +820,9 @@ struct HWArgs {
     const float* sy;
     int64_t M;
     int Hi, Wi, Ci, Ho, Wo, Co;
+    int ldy;               // channels per pixel row of dY (>= Co: the GEMM may take the first Co channels of wider rows)
+    int Nvalid;            // output columns that exist (<= Ntot = KH*KW*Ci: a batched GEMM whose Ci was padded up to 16 k)
+    int batched;           // 1: blockIdx.y is a batch item (rows_per_split pixels each), its result goes to out + item * slab_stride, scaled
     int KH, KW, stride, pad, dil;
     int Ntot, ldo, tiles_n, splits;
     int64_t rows_per_split, slab_stride;
@@ -883,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         const int js = permA16(pos ^ swz16(r));      // which source chunk lands at this position
         a_r[j] = r;
         a_cok[j] = co0 + (js >> 2) * 16 < p.Co;
-        a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.Co) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
+        a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.ldy) + (uint32_t)(co0 * 4 + js * 16);    // bytes relative to pixel mt
     }
     // a 128-column tile of (tap, ci) may span several filter taps when Ci < 128: every 16-channel chunk group lies inside one
     // tap (Ci % 16 == 0), so the tap is a per-lane constant
@@ -932,8 +948,8 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         if constexpr (!do_load) return;
         unsigned char* st = smem + stage * HWSTAGE;
         const int64_t mt = m_begin + (int64_t)ld_kt * 32;
-        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (4 * (int64_t)p.Co);   // scalar
-        const uint32_t zrelA = (uint32_t)((int64_t)p.y_bytes - mt * (4 * (int64_t)p.Co));
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(p.dY) + mt * (4 * (int64_t)p.ldy);   // scalar
+        const uint32_t zrelA = (uint32_t)((int64_t)p.y_bytes - mt * (4 * (int64_t)p.ldy));
         const int rows_left = (int)min((int64_t)32, m_end - mt);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1120,12 +1136,12 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     }
 
     float* out = p.out + (p.splits > 1 ? (int64_t)split * p.slab_stride : 0);
-    const bool direct = p.splits == 1;
+    const bool direct = p.splits == 1 || p.batched;      // the result itself (scaled, beta) rather than a raw slab for the reduce pass
     const float isx = 1.f / sx_dev, isy = 1.f / sy_dev;
     {
         const int l16 = lane & 15;
         // float4 stores through a wave-private LDS staging tile (see h2_kernel's epilogue): 256-byte runs instead of 64-byte ones
-        const bool wide = (p.ldo & 3) == 0 && (p.Ntot & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        const bool wide = (p.ldo & 3) == 0 && (p.Nvalid & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
         if (wide) {
             float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 68);
 #pragma unroll
@@ -1144,7 +1160,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
             for (int ps = 0; ps < 16; ++ps) {
                 const int row = ps * 4 + rsub;
                 const int co = co0 + wm * 64 + row;
-                if (co < p.Co && n < p.Ntot) {
+                if (co < p.Co && n < p.Nvalid) {
                     float4 v = *reinterpret_cast<const float4*>(stg + row * 68 + 4 * cq4);
                     float4* dst = reinterpret_cast<float4*>(out + (int64_t)co * p.ldo + n);
                     if (direct && p.beta) {
@@ -1159,7 +1175,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l16;
-            if (n >= p.Ntot) continue;
+            if (n >= p.Nvalid) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1386,22 +1402,30 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
                           float* st_mm = nullptr) {
     if (!d || !Xs || !Ws || !x_scale || !w_scale || !out) return SP_ENULL;
     if (d->mode != 0 && d->mode != 1) return SP_EINVAL;
-    if (d->Kc % 32 || d->ldx != d->Kc) return SP_EINVAL;      // a 32-k K-tile must lie inside one filter tap
+    if (d->Kc % 32 || d->ldx < d->Kc || d->ldx % 16) return SP_EINVAL;      // a 32-k K-tile must lie inside one filter tap
     if (((uintptr_t)Xs | (uintptr_t)Ws) & 15) return SP_EINVAL;
-    if (d->nbatch != 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
+    if (d->nbatch < 1 || d->stride < 1 || d->dil < 1) return SP_EINVAL;
+    const int64_t rows_b = (int64_t)d->N_img * d->Ho * d->Wo;           // output rows per batch item
+    if (d->nbatch > 1) {      // batched pointwise GEMM, one weight set per item: dense, contiguous items, whole tiles per item
+        if (d->mode != 0 || d->KH * d->KW != 1 || d->stride != 1 || d->pad != 0 || rows_b % HBM || rows_b >= (1LL << 31)) return SP_EINVAL;
+        if (d->strideX != rows_b * d->ldx || d->strideC != rows_b * d->ldc || d->strideW != (int64_t)d->Nout * d->Kc) return SP_EINVAL;
+        if (st_partial || nprod != 3) return SP_EINVAL;
+    }
     H2Args a{};
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
     a.sx = x_scale; a.sw = w_scale;
-    a.M = (int64_t)d->N_img * d->Ho * d->Wo;
-    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc;
+    a.M = rows_b * d->nbatch;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->ldc;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.w_bstride = d->nbatch > 1 ? 4 * d->strideW : 0;
+    a.rows_per_batch = (int)rows_b;
     a.ldwb = 4 * (int64_t)d->KH * d->KW * d->Kc;
     a.ncblk = d->Kc / 32;
     a.nkt = d->KH * d->KW * a.ncblk;
     a.tiles_n = (int)sp_cdiv(d->Nout, HBN);
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
-    const int64_t xb = 4LL * d->N_img * d->Hi * d->Wi * d->Kc, wb = 4LL * d->Nout * d->KH * d->KW * d->Kc;
+    const int64_t xb = 4LL * d->nbatch * d->N_img * d->Hi * d->Wi * d->ldx, wb = 4LL * d->nbatch * d->Nout * d->KH * d->KW * d->Kc;
     if (xb + 64 >= (1LL << 32) || wb + 64 >= (1LL << 32)) return SP_EINVAL;      // 32-bit byte offsets in the loaders
     a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
     if (a.M <= 0 || a.M >= (1LL << 31) || a.Nout <= 0) return SP_EINVAL;             // 32-bit pixel arithmetic in the kernels
@@ -1472,7 +1496,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
     a.sx = h_scale; a.sw = w_scale;
     a.M = (int64_t)d->N_img * P;
-    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx = d->Kc;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->Nout;
     a.KH = d->KH; a.KW = d->KW; a.stride = 1; a.pad = d->pad; a.dil = d->dil;
     a.ldwb = 4 * (int64_t)d->KH * d->KW * d->Kc;
@@ -1496,6 +1520,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
 
 extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
     if (!d) return 0;
+    if (d->nbatch > 1) return 0;      // batched: every item writes its own result
     const int sp = hw_splits(d);
     return sp <= 1 ? 0 : (int64_t)sp * d->Co * d->ldo * (int64_t)sizeof(float);
 }
@@ -1503,25 +1528,35 @@ extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
 static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                           const float* y_scale, float* dW, void* workspace, void* stream, int nprod) {
     if (!d || !Xsplit || !dYsplit || !x_scale || !y_scale || !dW) return SP_ENULL;
-    if (d->Ci % 16 || d->Co % 16 || d->ldx != d->Ci || d->ldy != d->Co || d->nbatch != 1) return SP_EINVAL;
+    if (d->Ci % 16 || d->Co % 16 || d->ldx != d->Ci || d->ldy < d->Co || d->ldy % 16 || d->nbatch < 1) return SP_EINVAL;
     if (((uintptr_t)Xsplit | (uintptr_t)dYsplit) & 15) return SP_EINVAL;
+    const int64_t rows_b = (int64_t)d->N_img * d->Ho * d->Wo;      // pixels per batch item
+    const bool batched = d->nbatch > 1;
+    if (batched) {      // one TN GEMM per item (the cell backward's rank-1 filter gradient): pointwise, dense contiguous items
+        if (d->KH * d->KW != 1 || d->stride != 1 || d->pad != 0 || rows_b % 32 || nprod != 3) return SP_EINVAL;
+        if (d->strideX != rows_b * d->Ci || d->strideY != rows_b * d->ldy || d->strideO != (int64_t)d->Co * d->ldo) return SP_EINVAL;
+    } else if (d->ldo < d->KH * d->KW * d->Ci) {
+        return SP_EINVAL;
+    }
     HWArgs a;
     a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;
     a.sx = x_scale; a.sy = y_scale;
-    a.M = (int64_t)d->N_img * d->Ho * d->Wo;
-    a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.M = rows_b * d->nbatch;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
     a.Ntot = d->KH * d->KW * d->Ci;
     a.ldo = d->ldo;
     a.tiles_n = (int)sp_cdiv(a.Ntot, 128);
-    a.splits = hw_splits(d);
-    if (a.splits > 1 && !workspace) return SP_ENULL;
-    a.rows_per_split = sp_cdiv(sp_cdiv(a.M, a.splits), 32) * 32;
+    a.Nvalid = std::min(a.Ntot, d->ldo);          // batched with Ci padded up to 16 k: only the first ldo columns exist
+    a.batched = batched ? 1 : 0;
+    a.splits = batched ? d->nbatch : hw_splits(d);
+    if (!batched && a.splits > 1 && !workspace) return SP_ENULL;
+    a.rows_per_split = batched ? rows_b : sp_cdiv(sp_cdiv(a.M, a.splits), 32) * 32;
     a.slab_stride = (int64_t)d->Co * d->ldo;
-    a.out = a.splits > 1 ? (float*)workspace : dW;
+    a.out = (!batched && a.splits > 1) ? (float*)workspace : dW;
     a.alpha = d->alpha; a.beta = d->beta;
     if (a.M <= 0) return SP_EINVAL;
-    const int64_t xb = 4LL * d->N_img * d->Hi * d->Wi * d->Ci, yb = 4LL * a.M * d->Co;
+    const int64_t xb = 4LL * d->nbatch * d->N_img * d->Hi * d->Wi * d->Ci, yb = 4LL * a.M * d->ldy;
     if (xb + 64 >= (1LL << 32) || yb + 64 >= (1LL << 32) || d->Ho * d->Wo < 1) return SP_EINVAL;
     a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
     hipStream_t s = (hipStream_t)stream;
@@ -1541,7 +1576,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
 #endif
     if (rc == -1000) rc = nprod == 1 ? launch_hw<1>(a, d->Co, s) : launch_hw<3>(a, d->Co, s);      // 1: throughput mode
     if (rc != SP_OK) return rc;
-    if (a.splits > 1) {
+    if (a.splits > 1 && !batched) {
         const int64_t total = (int64_t)d->Co * a.Ntot;
         if (a.Ntot % 4 == 0 && d->ldo % 4 == 0 && a.slab_stride % 4 == 0 && (((uintptr_t)workspace | (uintptr_t)dW) & 15) == 0) {
             const int blocks = (int)std::min<int64_t>(sp_cdiv(total / 4, 256), 4096);

@@ -80,7 +80,7 @@ if SPLIT_SCHEME not in ("f16x2", "bf16x3"):
 # how often each fused pass ran (tests assert that the benchmark's kernel path, not a fallback, is the one under test)
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
-                 "conv_bn_stats": 0, "grad_merge": 0}
+                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0}
 
 
 def reset_fusion_counts():
@@ -1157,6 +1157,8 @@ def _cell_bounds(c_prev, c):
 
 
 LSTM_BWD_SPLIT = os.environ.get("SP_LSTM_BWD_SPLIT", "1") != "0"
+RANK1_DSP_SPLIT = os.environ.get("SP_RANK1_DSP_SPLIT", "1") != "0"
+RANK1_DWC_SPLIT = os.environ.get("SP_RANK1_DWC_SPLIT", "1") != "0"
 
 
 def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None)):
@@ -1196,12 +1198,33 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     dsp = dwc = None
     if need_dsp:
         dsp = torch.empty_like(spcol)
-        _igemm(dpre, wc, None, dsp, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1,
-               nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
+        if emit and RANK1_DSP_SPLIT and P % 256 == 0 and N3 % 32 == 0 and KP % 4 == 0 and not THROUGHPUT_MODE:
+            # gradient of the spatial-memory taps, dsp[b] = dpre[b][:, :3C] x wc[b]: a batched pointwise GEMM with one weight set
+            # per sample, on the split dpre the cell backward just wrote (its first 3C of 4C channels per row) -- the fp32-MFMA
+            # batched GEMM it replaces read the fp32 dpre (0.5 GB) at ~2 TB/s
+            FUSION_COUNTS["rank1_dsp_split"] += 1
+            xs = dpre._sp_cache["f16x2"]
+            ws = split_op(wc.transpose(1, 2).contiguous(), "f16x2")                   # [B][KP][3C]: K contiguous
+            d = ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
+            check(hip.lib().sp_conv_igemm_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(ws.buf), ptr(ws.scale), None, ptr(dsp),
+                                                hip.stream()), "sp_conv_igemm_f16x2 (batched)")
+        else:
+            _igemm(dpre, wc, None, dsp, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1,
+                   nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
     if need_dwc:
         dwc = torch.empty_like(wc)
         L = hip.lib()
-        if KP <= 24:
+        if emit and RANK1_DWC_SPLIT and P % 256 == 0 and N3 % 16 == 0 and KP <= 32 and KP % 4 == 0 and not THROUGHPUT_MODE:
+            # filter gradient of the rank-1 gate term, dwc[b] = dpre[b][:, :3C]^T x spcol[b]: one TN GEMM per sample (K = the sample's
+            # pixels) on the split dpre; spcol's KP tap columns are padded to 32 for the 16-channel groups of the split operand, the
+            # kernel stores the first KP columns.  The VALU kernel it replaces read the fp32 dpre at ~2 TB/s (250 us per launch)
+            FUSION_COUNTS["rank1_dwc_split"] += 1
+            ys = dpre._sp_cache["f16x2"]
+            xs = split_op(torch.nn.functional.pad(spcol, (0, 32 - KP)), "f16x2")
+            d = hip.WgradDesc(1, P // 64, 64, 32, 32, P // 64, 64, N3, C4, 1, 1, 1, 0, 1, KP, 0, 1.0, B, P * 32, P * C4, N3 * KP)
+            check(L.sp_conv_wgrad_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(ys.buf), ptr(ys.scale), ptr(dwc), None, hip.stream()),
+                  "sp_conv_wgrad_f16x2 (batched)")
+        elif KP <= 24:
             ws = hip.workspace(L.sp_rank1_dwc_workspace(B, P, N3, KP), dpre.device, slot=0)
             check(L.sp_rank1_dwc(ptr(dpre), ptr(spcol), B, P, C4, N3, KP, ptr(ws), ptr(dwc), hip.stream()), "sp_rank1_dwc")
         else:

@@ -670,6 +670,57 @@ def test_semantic_pool(S, B, P, C):
     _close(vd.grad, vr.grad, 3e-6, "d vf")
 
 
+def test_batched_pointwise_gemm_with_per_item_weights_on_wider_rows():
+    """the cell backward's spatial-tap gradient (AiR/models/baseline_attention.py:37-56, backward of ss+- x conv_pos/neg): a batched
+    GEMM out[b] = X[b][:, :Kc] x W[b]^T through sp_conv_igemm_f16x2 -- one weight set per batch item, X rows wider than Kc (the
+    first 3C of the 4C gate-gradient channels) -- against fp64; and the error codes of the shapes it does not take"""
+    import ctypes as C
+    from scanpaths_amd import functional as F, hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, P, Kc, ldx, N = 3, 512, 96, 128, 20
+    x = torch.randn(B, P, ldx, generator=g).to(dev)
+    w = (torch.randn(B, N, Kc, generator=g) * 0.1).to(dev)
+    xs, ws = F.split_op(x, "f16x2"), F.split_op(w, "f16x2")
+    out = torch.full((B, P, N), float("nan"), device=dev)
+    d = hip.ConvDesc(P, 1, 1, Kc, ldx, 1, 1, N, N, 1, 1, 1, 0, 1, 0, Kc, 1.0, 0, 0, B, P * ldx, N * Kc, P * N, 0, None)
+    L = hip.lib()
+    args = (hip.ptr(xs.buf), hip.ptr(xs.scale), hip.ptr(ws.buf), hip.ptr(ws.scale), None, hip.ptr(out), hip.stream())
+    assert L.sp_conv_igemm_f16x2(C.byref(d), *args) == 0
+    ref = torch.einsum("bpk,bnk->bpn", x[:, :, :Kc].double().cpu(), w.double().cpu())
+    err = (out.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-6, err
+    for bad in (dict(P=500), dict(sW=N * Kc + 16), dict(ldx=Kc - 16)):      # partial tiles per item / padded weight sets / ldx < Kc
+        Pb, sW, lx = bad.get("P", P), bad.get("sW", N * Kc), bad.get("ldx", ldx)
+        db = hip.ConvDesc(Pb, 1, 1, Kc, lx, 1, 1, N, N, 1, 1, 1, 0, 1, 0, Kc, 1.0, 0, 0, B, Pb * lx, sW, Pb * N, 0, None)
+        assert L.sp_conv_igemm_f16x2(C.byref(db), *args) == -1, bad
+
+
+def test_batched_weight_gradient_with_padded_taps_on_wider_rows():
+    """the cell backward's rank-1 filter gradient: one TN GEMM per sample, dwc[b] = dY[b][:, :Co]^T x X[b], through
+    sp_conv_wgrad_f16x2 with nbatch > 1 -- dY rows wider than Co, X's KP columns padded to 32, only the first KP output columns
+    stored (ldo = KP) -- against fp64, and the canary behind every item's result stays untouched"""
+    import ctypes as C
+    from scanpaths_amd import functional as F, hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, P, Co, ldy, KP = 3, 512, 80, 128, 20
+    dy = torch.randn(B, P, ldy, generator=g).to(dev)
+    x = torch.randn(B, P, KP, generator=g).to(dev)
+    ys, xs = F.split_op(dy, "f16x2"), F.split_op(torch.nn.functional.pad(x, (0, 32 - KP)), "f16x2")
+    out = torch.full((B * Co * KP + 64,), 7.0, device=dev)
+    d = hip.WgradDesc(1, P // 64, 64, 32, 32, P // 64, 64, Co, ldy, 1, 1, 1, 0, 1, KP, 0, 1.0, B, P * 32, P * ldy, Co * KP)
+    L = hip.lib()
+    assert L.sp_conv_wgrad_f16x2_workspace(C.byref(d)) == 0
+    assert L.sp_conv_wgrad_f16x2(C.byref(d), hip.ptr(xs.buf), hip.ptr(xs.scale), hip.ptr(ys.buf), hip.ptr(ys.scale), hip.ptr(out), None,
+                                 hip.stream()) == 0
+    ref = torch.einsum("bpc,bpk->bck", dy[:, :, :Co].double().cpu(), x.double().cpu())
+    got = out[:B * Co * KP].view(B, Co, KP).double().cpu()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-6, err
+    assert bool((out[B * Co * KP:] == 7.0).all())
+
+
 def test_product_library_has_no_timing_modes():
     """the shipped library cannot be switched into a wrong-result timing mode or another kernel schedule -- those
     selectors exist only in libscanpaths_amd_timing.so; the one process-wide switch left is "amax_reset"."""
