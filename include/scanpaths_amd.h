@@ -229,6 +229,11 @@ int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, vo
  * fan-in of a tensor consumed by every decode step (x-gate pre-activations), one pass instead of count-1 adds */
 int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out,
              unsigned* out_amax /* nullable: float bits of max|out|, as sp_bn_apply's y_amax */, void* stream);
+/* the same fan-in when some contributions exist only as 2xfp16 split operands (the gate gradient of a ConvLSTM step whose fp32 form
+ * was left unwritten, sp_lstm_pointwise_bwd_split with dpre == NULL): inputs[k] != NULL -> fp32 term, else planes[k] / scales[k]
+ * (sp_split2_f16 layout, device scale) -> the exact value of the split operand.  n % 16 == 0. */
+int sp_sum_n_mixed(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n, float* out,
+                   unsigned* out_amax, void* stream);
 int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
 /* out = a + b (residual joins in backward), n elements */
 int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream);
@@ -267,7 +272,8 @@ int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, 
 /* as above, and (planes != NULL) dpre also as the 2xfp16 split operand of the h-gate conv's backward GEMMs, scale from the bound
  * max(D, max|dh| * c_bound / 4, D * cprev_bound / 4), D = max|dh| + max|dc|  (dh_amax / dc_amax: device words with the float bits
  * of (bounds of) the maxima; c_bound >= max|c_out|, cprev_bound >= max|c_prev|: t + 1 and t after t + 1 steps).  dcp_amax
- * (nullable) receives max|dc_prev|.  planes: 2 * rows * 4C fp16 + 64 zero bytes; dpre_scale [2] = {scale, bound}.  C % 256 == 0. */
+ * (nullable) receives max|dc_prev|.  planes: 2 * rows * 4C fp16 + 64 zero bytes; dpre_scale [2] = {scale, bound}.  C % 256 == 0.
+ * dpre may be NULL when planes is given: the fp32 gate gradient is then not written (every consumer reads the split form). */
 int sp_lstm_pointwise_bwd_split(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* c_out,
                                 int64_t rows, int C, float* dpre, float* dc_prev, unsigned* dpre_amax, unsigned* dcp_amax,
                                 const unsigned* dh_amax, const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,

@@ -787,6 +787,51 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t
     }
     if (amax) block_amax_commit(mx, amax, sh4);
 }
+// The same fan-in when some inputs exist only as 2xfp16 split operands ([16-element group][plane][16] fp16 + device scale, as written
+// by lstm_bwd_kernel): input k contributes (plane0 + plane1) / scale_k -- exactly the value the GEMMs read (fp16 + fp16 of one
+// element is exact in fp32, the scale is a power of two).  One thread per 16-element group; list order.
+struct SumListMixed {
+    const float* f[32];          // fp32 form, or NULL
+    const uint16_t* pl[32];      // split form (used when f[k] is NULL)
+    const float* sc[32];
+    int n;
+};
+__global__ __launch_bounds__(256) void sum_n_mixed_kernel(SumListMixed l, float* o, int64_t n16, unsigned* amax) {
+    __shared__ float sh4[4];
+    float mx = 0.f;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int k = 0; k < l.n; ++k) {
+            if (l.f[k]) {
+                const float4* q = reinterpret_cast<const float4*>(l.f[k]) + i * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = q[j];
+                    acc[4 * j] += v.x; acc[4 * j + 1] += v.y; acc[4 * j + 2] += v.z; acc[4 * j + 3] += v.w;
+                }
+            } else {
+                const h8* q = reinterpret_cast<const h8*>(l.pl[k]) + i * 4;        // 64 bytes: plane 0 (2 x 8 halves), plane 1
+                const float inv = 1.f / l.sc[k][0];
+                const h8 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc[e] += ((float)a0[e] + (float)b0[e]) * inv;
+                    acc[8 + e] += ((float)a1[e] + (float)b1[e]) * inv;
+                }
+            }
+        }
+        float4* w = reinterpret_cast<float4*>(o) + i * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            mx = amax4(mx, acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        }
+    }
+    if (amax) block_amax_commit(mx, amax, sh4);
+}
 __global__ __launch_bounds__(256) void add_tail_kernel(const float* a, const float* b, float* o, int64_t start, int64_t n) {
     const int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = a[i] + b[i];
@@ -1055,6 +1100,25 @@ extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float*
     }
     SP_RESET_AMAX(out_amax, stream);
     hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4, out_amax);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+extern "C" int sp_sum_n_mixed(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n,
+                              float* out, unsigned* out_amax, void* stream) {
+    if (!inputs || !planes || !scales || !out) return SP_ENULL;
+    if (count < 1 || count > 32 || n % 16) return SP_EINVAL;
+    SumListMixed l;
+    l.n = count;
+    for (int k = 0; k < count; ++k) {
+        if (!inputs[k] && (!planes[k] || !scales[k])) return SP_ENULL;
+        if (!inputs[k] && ((uintptr_t)planes[k] & 15)) return SP_EINVAL;
+        l.f[k] = inputs[k];
+        l.pl[k] = (const uint16_t*)planes[k];
+        l.sc[k] = scales[k];
+    }
+    SP_RESET_AMAX(out_amax, stream);
+    hipLaunchKernelGGL(sum_n_mixed_kernel, dim3(ew_blocks(n / 16)), dim3(256), 0, (hipStream_t)stream, l, out, n / 16, out_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -346,11 +346,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const fl
         }
             CELLB(x) CELLB(y) CELLB(z) CELLB(w)
 #undef CELLB
-            float* pd = dpre + r * 4 * C + c;
-            *reinterpret_cast<float4*>(pd) = di;
-            *reinterpret_cast<float4*>(pd + C) = df;
-            *reinterpret_cast<float4*>(pd + 2 * C) = dov;
-            *reinterpret_cast<float4*>(pd + 3 * C) = dg;
+            if (dpre) {                // NULL: every consumer reads the split form (planes) -- 671 MB per step not written
+                float* pd = dpre + r * 4 * C + c;
+                *reinterpret_cast<float4*>(pd) = di;
+                *reinterpret_cast<float4*>(pd + C) = df;
+                *reinterpret_cast<float4*>(pd + 2 * C) = dov;
+                *reinterpret_cast<float4*>(pd + 3 * C) = dg;
+            }
             *reinterpret_cast<float4*>(dc_prev + r * C + c) = dcp;
             dmx = amax4(amax4(dmx, di.x, di.y, di.z, di.w), df.x, df.y, df.z, df.w);
             dmx = amax4(amax4(dmx, dov.x, dov.y, dov.z, dov.w), dg.x, dg.y, dg.z, dg.w);
@@ -760,7 +762,7 @@ extern "C" int sp_lstm_pointwise_bwd_split(const float* dh, const float* dc, con
                                            unsigned* dpre_amax, unsigned* dcp_amax, const unsigned* dh_amax,
                                            const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
                                            float* dpre_scale, void* stream) {
-    if (!gates || !c_out || !dpre || !dc_prev) return SP_ENULL;
+    if (!gates || !c_out || (!dpre && !planes) || !dc_prev) return SP_ENULL;      // dpre may be NULL when the split form is written
     if (C % 4) return SP_EINVAL;
     if (planes && (!dpre_scale || C % 256 || ((uintptr_t)planes & 15) || (dh && !dh_amax) || (dc && !dc_amax))) return SP_EINVAL;
     SP_RESET_AMAX(dpre_amax, stream);

@@ -80,7 +80,7 @@ if SPLIT_SCHEME not in ("f16x2", "bf16x3"):
 # how often each fused pass ran (tests assert that the benchmark's kernel path, not a fallback, is the one under test)
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
-                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0}
+                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0}
 
 
 def reset_fusion_counts():
@@ -148,12 +148,20 @@ def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
     return None if hint is None else hint.data_ptr() + 4
 
 
+def _fp32_required(x: torch.Tensor, what: str) -> None:
+    """a tensor whose fp32 form was left unwritten by its producer (bn skip_dx, cell backward skip) must never be read as fp32"""
+    if getattr(x, "_sp_skipped", False):
+        raise RuntimeError(f"scanpaths_amd: {what} needs the fp32 form of a gradient that exists only as a split operand; "
+                           "run with SP_LSTM_SKIP_DPRE=0")
+
+
 def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree)"""
     scheme = scheme or _scheme_for(x.shape[-1])
     cache = getattr(x, "_sp_cache", None)        # {scheme: SplitOperand} shared by every alias of a multi-consumer tensor (fanout)
     if cache is not None and scheme in cache:
         return cache[scheme]
+    _fp32_required(x, "split_op")
     if scheme == "bf16x3":
         op = SplitOperand(split3(x), None, scheme)
     else:
@@ -342,6 +350,20 @@ class _FanOut(Function):
         gs = [g.contiguous() for g in grads if g is not None]
         if not gs:
             return None, None
+        skipped = [getattr(g, "_sp_skipped", False) for g in gs]       # contributions that exist only as split operands (cell backward)
+        if any(skipped):
+            out = torch.empty_like(gs[0])
+            n = out.numel()
+            assert n % 16 == 0 and len(gs) <= 32, (n, len(gs))
+            ops = [g._sp_cache["f16x2"] if sk else None for g, sk in zip(gs, skipped)]
+            f = (C.c_void_p * len(gs))(*[None if sk else g.data_ptr() for g, sk in zip(gs, skipped)])
+            pl = (C.c_void_p * len(gs))(*[op.buf.data_ptr() if op is not None else None for op in ops])
+            sc = (C.c_void_p * len(gs))(*[op.scale.data_ptr() if op is not None else None for op in ops])
+            hint = _amax_hint(out.device)
+            check(hip.lib().sp_sum_n_mixed(f, pl, sc, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n_mixed")
+            if hint is not None:
+                out._sp_amax = hint
+            return out, None
         if len(gs) == 1:
             return gs[0], None
         out = torch.empty_like(gs[0])
@@ -367,6 +389,9 @@ def fanout(x: torch.Tensor, n: int):
         if v is not None:
             for o in outs:
                 setattr(o, attr, v)
+    if x.numel() % 16 == 0 and n <= 32:
+        for o in outs:
+            o._sp_split_grad_ok = True      # a consumer may hand back its gradient as a split operand only (see _FanOut.backward)
     return outs
 
 
@@ -623,6 +648,7 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
             _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
                       ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
         else:
+            _fp32_required(dy, "the fp32 data-gradient GEMM")
             _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
                    KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
     if need_dw:
@@ -636,6 +662,7 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
                       dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch), dwp, N_img=N, Hi=H,
                       Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
         else:
+            _fp32_required(dy, "the fp32 weight-gradient GEMM")
             _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
         dw = dwp.permute(0, 3, 1, 2)
@@ -1133,6 +1160,7 @@ class _LstmCellRank1(Function):
             h._sp_amax = hint
         h._sp_cache = {}                  # h feeds the saliency tap GEMM of this step and the h-gate conv of the next: split once
         ctx.has = (hg is not None, c_prev is not None)
+        ctx.skip_ok = hg is None and getattr(xg, "_sp_split_grad_ok", False)      # dpre's only consumer (xg's fan-in) takes a split operand
         ctx.set_materialize_grads(False)          # the last step's dc stays None instead of a zero tensor the kernel would read
         ctx.cbounds = _cell_bounds(c_prev, c)
         ctx.save_for_backward(gates, c_prev, c, spcol, wc)
@@ -1142,7 +1170,7 @@ class _LstmCellRank1(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[3],
-                                                   ctx.needs_input_grad[4], ctx.cbounds)
+                                                   ctx.needs_input_grad[4], ctx.cbounds, skip_fp32=ctx.skip_ok)
         has_hg, has_c = ctx.has
         return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
 
@@ -1159,9 +1187,10 @@ def _cell_bounds(c_prev, c):
 LSTM_BWD_SPLIT = os.environ.get("SP_LSTM_BWD_SPLIT", "1") != "0"
 RANK1_DSP_SPLIT = os.environ.get("SP_RANK1_DSP_SPLIT", "1") != "0"
 RANK1_DWC_SPLIT = os.environ.get("SP_RANK1_DWC_SPLIT", "1") != "0"
+LSTM_SKIP_DPRE = os.environ.get("SP_LSTM_SKIP_DPRE", "1") != "0"
 
 
-def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None)):
+def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None), skip_fp32=False):
     """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint or -- when bounds of max|dh|, max|dc| and
     max|c| are known -- its 2xfp16 split operand, written by the same pass), c_prev, spcol and wc"""
     dh_h = getattr(dh, "_sp_amax", None) if dh is not None else None
@@ -1176,12 +1205,20 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     dpre = torch.empty_like(gates)
     dcp = torch.empty_like(c)
     hint, chint = _amax_hint(gates.device), _amax_hint(gates.device)
+    rank1_split_ok = P % 256 == 0 and N3 % 32 == 0 and KP <= 32 and KP % 4 == 0 and not THROUGHPUT_MODE
     emit = (LSTM_BWD_SPLIT and hint is not None and Cc % 256 == 0 and cbounds[0] is not None and (dh is None or dh_h is not None)
             and (dc is None or dc_h is not None) and _scheme_for(C4) == "f16x2")
     if emit:
         FUSION_COUNTS["lstm_bwd_split"] += 1
         planes = torch.empty(2 * dpre.numel() + 32, dtype=torch.float16, device=dpre.device)
-        check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre), ptr(dcp),
+        # skip_fp32 (the caller's other consumers of dpre read its split form): when the two rank-1 gradients do too, the fp32
+        # tensor is allocated (autograd wants one) but never written -- 671 MB per step at the benchmark size
+        skip = (skip_fp32 and LSTM_SKIP_DPRE and (not need_dsp or (RANK1_DSP_SPLIT and rank1_split_ok))
+                and (not need_dwc or (RANK1_DWC_SPLIT and rank1_split_ok)))
+        if skip:
+            FUSION_COUNTS["lstm_skip_dpre"] += 1
+            dpre._sp_skipped = True
+        check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, None if skip else ptr(dpre), ptr(dcp),
                                                     None, _hint_ptr(chint), _hint_ptr(dh_h), _hint_ptr(dc_h), float(cbounds[0]),
                                                     float(cbounds[1]), ptr(planes), ptr(hint), hip.stream()),
               "sp_lstm_pointwise_bwd_split")
@@ -1198,7 +1235,7 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     dsp = dwc = None
     if need_dsp:
         dsp = torch.empty_like(spcol)
-        if emit and RANK1_DSP_SPLIT and P % 256 == 0 and N3 % 32 == 0 and KP % 4 == 0 and not THROUGHPUT_MODE:
+        if emit and RANK1_DSP_SPLIT and rank1_split_ok:
             # gradient of the spatial-memory taps, dsp[b] = dpre[b][:, :3C] x wc[b]: a batched pointwise GEMM with one weight set
             # per sample, on the split dpre the cell backward just wrote (its first 3C of 4C channels per row) -- the fp32-MFMA
             # batched GEMM it replaces read the fp32 dpre (0.5 GB) at ~2 TB/s
@@ -1214,7 +1251,7 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     if need_dwc:
         dwc = torch.empty_like(wc)
         L = hip.lib()
-        if emit and RANK1_DWC_SPLIT and P % 256 == 0 and N3 % 16 == 0 and KP <= 32 and KP % 4 == 0 and not THROUGHPUT_MODE:
+        if emit and RANK1_DWC_SPLIT and rank1_split_ok:
             # filter gradient of the rank-1 gate term, dwc[b] = dpre[b][:, :3C]^T x spcol[b]: one TN GEMM per sample (K = the sample's
             # pixels) on the split dpre; spcol's KP tap columns are padded to 32 for the 16-channel groups of the split operand, the
             # kernel stores the first KP columns.  The VALU kernel it replaces read the fp32 dpre at ~2 TB/s (250 us per launch)
@@ -1306,6 +1343,11 @@ class _GateConvLstm(Function):
             and xs.scheme == _wgrad_scheme(Ci, Co)
         ctx.xs_scheme = xs.scheme if keep else None
         ctx.wcache = wcache
+        # the gate gradient dpre of this step has three consumers: xg's fan-in, the h-gate conv's data and weight gradient.  When all
+        # of them read its split form, its fp32 form is never written (_lstm_rank1_backward skip_fp32)
+        ctx.skip_ok = (getattr(xg, "_sp_split_grad_ok", False) and _scheme_for(Co) == "f16x2"
+                       and (not ctx.needs_input_grad[0] or _b3_pays(N * P, Ci, KH * KW * Co, Co, a_elems=xg.numel(), free_a=True))
+                       and (not ctx.needs_input_grad[1] or (keep and _wgrad_scheme(Ci, Co) == "f16x2")))
         ctx.save_for_backward(gates, c_prev, c, spcol, wc, h_prev, wp, xs.buf if keep else None, xs.scale if keep else None)
         return h, c
 
@@ -1313,7 +1355,7 @@ class _GateConvLstm(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc, h_prev, wp, xs_buf, xs_scale = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
-                                                   ctx.needs_input_grad[5], ctx.cbounds)
+                                                   ctx.needs_input_grad[5], ctx.cbounds, skip_fp32=ctx.skip_ok)
         xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
         dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                  defer_final=ctx.defer_final)

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sp_conv_igemm_f16x2_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_bn_bwd_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_sum_n": (_I, [_P, _I, _L, _P, _P, _P]),
+    "sp_sum_n_mixed": (_I, [_P, _P, _P, _I, _L, _P, _P, _P]),
     "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
     "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sp_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),

@@ -403,7 +403,7 @@ def test_air_320x512_matches_oracle():
 
 
 BENCH_PATH_COUNTERS = ("gateconv_lstm", "gateconv_lstm_hplanes", "lstm_bwd_split", "bn_fwd_split", "bn_fwd_split_operand", "bn_skip_z",
-                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split")
+                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split", "lstm_skip_dpre")
 
 
 def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
@@ -436,7 +436,7 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     torch.cuda.empty_cache()
     assert bench_counts["gateconv_lstm"] == T - 1 and bench_counts["gateconv_lstm_hplanes"] == T - 1, bench_counts
     assert bench_counts["lstm_bwd_split"] == T and bench_counts["bn_skip_z"] > 0 and bench_counts["bn_skip_dx"] > 0, bench_counts
-    assert bench_counts["rank1_dsp_split"] == T and bench_counts["rank1_dwc_split"] == T, bench_counts
+    assert bench_counts["rank1_dsp_split"] == T and bench_counts["rank1_dwc_split"] == T and bench_counts["lstm_skip_dpre"] == T, bench_counts
 
     # ---- the oracle on the host: fp64 and fp32, train (loss + gradients) and eval -- two worker processes side by side ----------
     import concurrent.futures as cf

@@ -721,6 +721,51 @@ def test_batched_weight_gradient_with_padded_taps_on_wider_rows():
     assert bool((out[B * Co * KP:] == 7.0).all())
 
 
+def test_fan_in_of_split_only_gradients_and_cell_backward_without_fp32_output():
+    """the x-gate fan-in when steps hand back their gate gradient as a split operand only (sp_sum_n_mixed; the fp32 tensor of such
+    a contribution is poisoned here and must not be read), and sp_lstm_pointwise_bwd_split with dpre == NULL writing the same
+    split operand as with it"""
+    import ctypes as C
+    from scanpaths_amd import functional as F, hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    n = 4096 * 16
+    ts = [(torch.randn(n, generator=g) * s).to(dev) for s in (1.0, 30.0, 0.01)]
+    ops = [F.split_op(t.view(-1, 256), "f16x2") for t in ts]
+    poison = torch.full((n,), float("nan"), device=dev)
+    f = (C.c_void_p * 3)(None, ts[1].data_ptr(), None)
+    pl = (C.c_void_p * 3)(ops[0].buf.data_ptr(), None, ops[2].buf.data_ptr())
+    sc = (C.c_void_p * 3)(ops[0].scale.data_ptr(), None, ops[2].scale.data_ptr())
+    out = torch.empty(n, device=dev)
+    amax = torch.zeros(2, dtype=torch.int32, device=dev)
+    L = hip.lib()
+    assert L.sp_sum_n_mixed(f, pl, sc, 3, n, hip.ptr(out), hip.ptr(amax), hip.stream()) == 0
+    ref = ts[0].double() + ts[1].double() + ts[2].double()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-6 * 30.0 * 5, err                         # split representation: 2^-22 of each tensor's maximum
+    assert float(amax.view(torch.float32)[0]) == float(out.abs().max())                      # fused max|sum| (float bits)
+    assert L.sp_sum_n_mixed(f, pl, sc, 3, n - 8, hip.ptr(out), None, hip.stream()) == -1
+    del poison
+    # cell backward: same planes with and without the fp32 output
+    rows, Cc = 64, 256
+    gates = torch.rand(rows, 4 * Cc, generator=g).to(dev)
+    c_prev, c = torch.randn(rows, Cc, generator=g).to(dev), torch.randn(rows, Cc, generator=g).to(dev)
+    dh, dc = torch.randn(rows, Cc, generator=g).to(dev), torch.randn(rows, Cc, generator=g).to(dev)
+    am = lambda t: torch.tensor([0.0, float(t.abs().max())], device=dev).view(torch.int32)
+    res = []
+    for skip in (False, True):
+        dpre, dcp = torch.empty_like(gates), torch.empty_like(c)
+        planes = torch.empty(2 * gates.numel() + 32, dtype=torch.float16, device=dev)
+        scale = torch.zeros(2, device=dev)
+        dh_a, dc_a = am(dh), am(dc)
+        rc = L.sp_lstm_pointwise_bwd_split(hip.ptr(dh), hip.ptr(dc), hip.ptr(gates), hip.ptr(c_prev), hip.ptr(c), rows, Cc,
+                                           None if skip else hip.ptr(dpre), hip.ptr(dcp), None, None, hip.ptr(dh_a[1:]), hip.ptr(dc_a[1:]),
+                                           4.0, 3.0, hip.ptr(planes), hip.ptr(scale), hip.stream())
+        assert rc == 0
+        res.append((planes.clone(), dcp.clone(), scale.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 def test_product_library_has_no_timing_modes():
     """the shipped library cannot be switched into a wrong-result timing mode or another kernel schedule -- those
     selectors exist only in libscanpaths_amd_timing.so; the one process-wide switch left is "amax_reset"."""
