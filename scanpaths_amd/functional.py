@@ -22,6 +22,13 @@ from .hip import ConvDesc, WgradDesc, check, ptr
 # ----------------------------------------------------------------------------------------------------
 # raw launches
 # ----------------------------------------------------------------------------------------------------
+# split-K of the fp32-MFMA pure GEMMs with few output tiles (embeddings, tiny heads): from 8 K-tiles on, 4 K-tiles per split.  The
+# kernel has no deep prefetch, so a workgroup's time is its K-tile count times a global-load round trip: the semantic embedding
+# (K = 512: 4 workgroups x 16 K-tiles) ran 35 us per launch, 51 launches per step.  A/B in the step (same box, interleaved):
+# 298.2 / 298.9 ms against 301.3 / 304.9 with the round-2 rule (from 32 K-tiles on, 8 per split).
+_KSPLIT_MIN_NKT, _KSPLIT_KT = 8, 4
+
+
 def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1,
            mode=0, alpha=1.0, beta=0, relu=0, nbatch=1, sX=0, sW=0, sC=0):
     # split-K when a pure GEMM has too few output tiles to fill 256 CUs (e.g. M = batch rows, K = 13824)
@@ -29,8 +36,8 @@ def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, K
     if KH * KW == 1 and nbatch == 1:
         tiles = ((N_img * Ho * Wo + 127) // 128) * ((Nout + 127) // 128)
         nkt = (Kc + 31) // 32
-        if tiles <= 64 and nkt >= 32:
-            ksplit = max(2, min(nkt // 8, 512 // tiles))
+        if tiles <= 64 and nkt >= _KSPLIT_MIN_NKT:
+            ksplit = max(2, min(nkt // _KSPLIT_KT, 512 // tiles))
             ws = hip.workspace(ksplit * N_img * Ho * Wo * Nout * 4, X.device, slot=2)
     d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
                  int(relu), nbatch, sX, sW, sC, ksplit, ptr(ws))
