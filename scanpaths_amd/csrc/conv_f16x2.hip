@@ -1239,10 +1239,10 @@ __global__ void hw_reduce4_kernel(const float* slab, float* out, int Co, int Nto
 
 int hw_splits(const sp_wgrad_desc* d) {
     const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
-    const int forced = sp_tuning_get(SP_TUNE_HW_SPLITS, 0);      // experiments only
-    if (forced > 0) return (int)std::min<int64_t>(forced, std::max<int64_t>(1, M / 32));
+    const int forced = sp_tuning_get(SP_TUNE_HW_SPLITS, 0);      // timing build only: < 256 = split count, >= 256 = workgroup target
+    if (forced > 0 && forced < 256) return (int)std::min<int64_t>(forced, std::max<int64_t>(1, M / 32));
     const int64_t tiles = sp_cdiv(d->Co, 256) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, 128);
-    int64_t want = sp_cdiv(2048, tiles);                          // 1 workgroup per CU: aim for >= 8 rounds of 256
+    int64_t want = sp_cdiv(forced >= 256 ? forced : 2048, tiles); // 1 workgroup per CU: aim for >= 8 rounds of 256
     want = std::min<int64_t>(want, std::max<int64_t>(1, M / 1024));   // >= 32 K-tiles per split
     want = std::min<int64_t>(want, 64);
     return (int)std::max<int64_t>(1, want);
