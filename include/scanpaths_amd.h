@@ -114,7 +114,7 @@ int sp_conv_wgrad_bf16x3(const sp_wgrad_desc* d, const void* Xsplit, const void*
  * power-of-two scale s (amax * s in [8192, 16384)), a*b = (a1b1 + a1b2 + a2b1)/(sa*sb); still closer to fp64 than a CPU fp32
  * GEMM (7.6e-8 vs 1.2e-7..3e-7 relative) at half the MFMA work of the bf16x3 scheme.  sp_split2_f16: fp32 [rows][K]
  * (K % 16 == 0) -> [rows][K/16][2][16] fp16 + 64-byte zero block (2n+32 halfs); scale_amax = 2 device words {scale (written),
- * scratch}.  igemm: Kc % 32 == 0 (a 32-k K-tile must lie inside one tap); wgrad: Ci % 16 == 0, Co % 16 == 0.
+ * scratch: zeroed by the launcher -- after sp_set_tuning("amax_reset", 1) only under stream capture, the caller then passes a ZERO word}.  igemm: Kc % 32 == 0 (a 32-k K-tile must lie inside one tap); wgrad: Ci % 16 == 0, Co % 16 == 0.
  * Row strides: ldx >= Kc (igemm) / ldy >= Co (wgrad), multiples of 16 -- a GEMM may take the first channels of wider rows (the
  * i, f, o columns of the [pixels][4C] gate gradient).  Batched forms (the two rank-1 gradients of the ConvLSTM cell's backward,
  * AiR/models/baseline_attention.py:37-56; they replace the fp32 batched sp_conv_igemm / sp_rank1_dwc on that path):

@@ -47,13 +47,6 @@ static inline bool sp_reset_needed(hipStream_t s) {
     if (hipStreamIsCapturing(s, &st) != hipSuccess) return true;
     return st != hipStreamCaptureStatusNone;
 }
-#define SP_RESET_AMAX_ALWAYS(ptr, stream)                                                                                   \
-    do {                                                                                                                    \
-        if (ptr) {                                                                                                          \
-            hipLaunchKernelGGL(sp_zero_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)(stream), (unsigned*)(ptr), 1);     \
-            SP_LAUNCH_CHECK();                                                                                              \
-        }                                                                                                                   \
-    } while (0)
 #define SP_RESET_AMAX(ptr, stream)                                                                                          \
     do {                                                                                                                    \
         if ((ptr) && sp_reset_needed((hipStream_t)(stream))) {                                                              \

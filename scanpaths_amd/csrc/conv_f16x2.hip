@@ -1349,7 +1349,7 @@ int launch_hw(const HWArgs& a, int Co, hipStream_t s) {
 }
 
 int launch_amax(const float* x, int64_t n, unsigned* amax, hipStream_t s) {
-    SP_RESET_AMAX_ALWAYS(amax, s);   // scratch word of the caller's scale buffer (not a pooled slot); a kernel node, not a memset node: see common.h
+    SP_RESET_AMAX(amax, s);   // scratch word of the caller's scale buffer: zeroed here unless the host hands in zeroed single-use slots (see common.h)
     const int64_t n4 = n / 4;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256 * 4), 1024));
     hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, n, amax);

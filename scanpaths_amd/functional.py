@@ -151,6 +151,14 @@ def _amax_hint_active() -> bool:
     return bool(USE_BF16X3 and SPLIT_SCHEME == "f16x2" and FUSED_AMAX)
 
 
+def _scale_slot(device) -> torch.Tensor:
+    """{scale, amax scratch} words for a split pass that computes max|x| itself: a ZEROED single-use slot of the hint pool (the amax
+    kernel's atomicMax needs a zero word; with sp_set_tuning("amax_reset", 1) the launcher then adds its one-thread reset kernel only
+    under stream capture -- ~160 launches per training step otherwise)"""
+    slot = _amax_hint(device)
+    return slot if slot is not None else torch.zeros(2, dtype=torch.float32, device=device)
+
+
 def _hint_ptr(hint: Optional[torch.Tensor]) -> Optional[int]:
     return None if hint is None else hint.data_ptr() + 4
 
@@ -176,7 +184,7 @@ def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
         xc = x.contiguous()
         n = xc.numel()
         out = torch.empty(2 * n + 32, dtype=torch.float16, device=x.device)
-        scale = hint if hint is not None else torch.empty(2, dtype=torch.float32, device=x.device)
+        scale = hint if hint is not None else _scale_slot(x.device)
         check(hip.lib().sp_split2_f16(ptr(xc), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
         op = SplitOperand(out, scale, scheme)
     if cache is not None:                        # set by producers whose output feeds several GEMMs (the ConvLSTM state h)
@@ -190,7 +198,7 @@ def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
     if scheme == "bf16x3":
         return SplitOperand(split3_wT(wp), None, scheme)
     out = torch.empty(2 * wp.numel() + 32, dtype=torch.float16, device=wp.device)
-    scale = torch.empty(2, dtype=torch.float32, device=wp.device)
+    scale = _scale_slot(wp.device)
     check(hip.lib().sp_split2_f16_wT(ptr(wp), Co, KH * KW, Ci, ptr(out), ptr(scale), hip.stream()), "sp_split2_f16_wT")
     return SplitOperand(out, scale, scheme)
 
