@@ -34,8 +34,8 @@ def step():
     hn, cn = F.gateconv_lstm(h, w, xg, c, spcol, wc, {})
     # gradients arrive with their max|.| hints in the model (fan-in pass): reproduce that so the cell backward writes the split dpre
     gg = gh.clone()
-    hint = F._amax_hint(dev)
-    hint[1] = float(gg.abs().max())
+    hint = torch.zeros(2, device=dev)          # its own tensor: an in-place torch write into a POOL slot would bump the version counter
+    hint[1] = float(gg.abs().max())            # every saved pool slot shares (autograd then refuses the saved operand scales)
     gg._sp_amax = hint
     torch.autograd.backward([hn], [gg])
 

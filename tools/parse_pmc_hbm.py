@@ -12,7 +12,7 @@ import os
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
-KEEP = ("bn_apply_split_kernel", "bn_bwd_apply_split_kernel", "lstm_bwd_kernel", "sum_n_kernel", "clip_adam_kernel", "bn_apply_kernel",
+KEEP = ("bn_apply_split_kernel", "bn_bwd_apply_split_kernel", "lstm_bwd_kernel", "sum_n_kernel", "sum_n_mixed_kernel", "clip_adam_kernel", "bn_apply_kernel",
         "split2_kernel", "sempool_bwd_kernel", "lstm_rank1_fwd_kernel")
 
 

@@ -3,7 +3,7 @@
 O=gpurun_out/r03pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-RX='bn_apply_split_kernel|bn_bwd_apply_split_kernel|lstm_bwd_kernel|sum_n_kernel|clip_adam_kernel'
+RX='bn_apply_split_kernel|bn_bwd_apply_split_kernel|lstm_bwd_kernel|sum_n_kernel|sum_n_mixed_kernel|clip_adam_kernel'
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RX" --output-format csv -d $O/hbm/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/hbm_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$RX" --output-format csv -d $O/hbm/write -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/hbm_write.log 2>&1
 rocprofv3 --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $O/hbm/trace -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/hbm_trace.log 2>&1
