@@ -142,7 +142,9 @@ def _amax_hint(device) -> Optional[torch.Tensor]:
     if pool is None or pool[1] >= pool[0].shape[0] or (pool[2] and not capturing):
         pool = [torch.zeros((2048, 2), dtype=torch.float32, device=device), 0, capturing]      # one zero-fill per 2048 hints
         _HINT_POOL[key] = pool
-    hint = pool[0][pool[1]]
+    # an independent tensor over the pool's storage, NOT a view: views share one version counter, so a single in-place torch op on any
+    # slot would make autograd reject every slot saved for backward (operand scales are)
+    hint = torch.empty(0, dtype=torch.float32, device=device).set_(pool[0].untyped_storage(), 2 * pool[1], (2,))
     pool[1] += 1
     return hint
 
