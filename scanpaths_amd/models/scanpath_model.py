@@ -399,7 +399,7 @@ class ScanpathModel(nn.Module):
             wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight-gradient GEMMs run on a side stream, summed in place
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t in range(T):
-            se = se_mem.view(S, B, Cc)
+            se = se_mem.view(S, B, Cc).unbind(0)      # (unbind: ONE stack in backward instead of a zero-fill + copy per stream and an add)
             parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk").view(B, 3 * 512, 9) for s in range(S)]
             wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
