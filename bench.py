@@ -36,13 +36,65 @@ PRODUCTS = {"h2": 3, "b3": 6, "h1": 1, "igemm": None, "wgrad": None}      # MFMA
 KERNEL_NAMES = {
     "h2_fwd": "h2_kernel<fwd> (2xfp16 split, 3 MFMA products)", "h2_dgrad": "h2_kernel<dgrad> (2xfp16 split, 3 MFMA products)",
     "h2_wgrad": "hw_kernel (2xfp16 split weight gradient, 3 MFMA products)",
+    "h2_wgrad_multi": "hw2_kernel (2xfp16 split weight gradient of ALL applications of the h-gate conv in one launch, 3 MFMA products)",
     "h1_fwd": "h2_kernel<fwd, 1 plane> (fp16 in / fp32 acc, 1 product)", "h1_dgrad": "h2_kernel<dgrad, 1 plane>",
     "h1_wgrad": "hw_kernel<1 plane>",
     "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)", "b3_dgrad": "b3_kernel<dgrad>", "b3_wgrad": "w3_kernel",
     "igemm_fwd": "igemm_kernel<fwd> (fp32 MFMA)", "igemm_dgrad": "igemm_kernel<dgrad> (fp32 MFMA)", "wgrad": "wgrad_kernel (fp32 MFMA)"}
-PMC_PREFIX = {"h2_fwd": "h2_kernel<0,", "h2_dgrad": "h2_kernel<1,", "h2_wgrad": "hw_kernel"}      # kernel-name prefixes in profiles/*_pmc_hconv.json
+PMC_PREFIX = {"h2_fwd": "h2_kernel<0,", "h2_dgrad": "h2_kernel<1,", "h2_wgrad": "hw_kernel", "h2_wgrad_multi": "hw2_kernel"}      # kernel-name prefixes in profiles/*_pmc_hconv.json
 # the forward launches of the h-gate shape are (15 of 16) the ConvLSTM-fused variant: its own PMC entry (7th template argument true)
 PMC_FUSED_FWD = ", true, true, true"
+
+
+
+def bucketer_overhead(opt, step, sync, steps, bucketed_ms):
+    """The 1-GPU half of the scaling evidence: the step with the data-parallel machinery active in an RCCL world
+    of one -- post-accumulate-grad hooks, ~32 MB buckets launched in descending order from the hooks, async ncclAllReduce on RCCL's
+    stream (an identity at world 1, but the launches, the stream hand-offs and the waits are real), FlatAdam.step() waiting on the
+    handles -- against the plain step of the SAME process (bucketer detached), interleaved plain / bucketed / plain; and the bucket
+    timeline: how long before the END of backward each bucket's all-reduce was launched (= the window its xGMI transfer can hide
+    in; the bucket of the encoder's first layers is launched last).  No scaling curve: that needs more than one device."""
+    import torch
+    bk = opt._bucketer
+
+    def timed(n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        sync()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    opt._bucketer = None
+    plain_a = timed(steps)
+    opt._bucketer = bk
+    bucketed_b = timed(steps)
+    opt._bucketer = None
+    plain_b = timed(steps)
+    opt._bucketer = bk
+    # one instrumented step: events at every bucket launch (compute stream) and at the end of backward
+    bk.record = True
+    end_bwd = torch.cuda.Event(enable_timing=True)
+    orig_step = opt.step
+
+    def step_hook(*a, **k):
+        end_bwd.record()
+        return orig_step(*a, **k)
+    opt.step = step_hook
+    step()
+    sync()
+    opt.step = orig_step
+    bk.record = False
+    buckets = [{"bucket": b, "mb": round(nb / 2 ** 20, 1), "launched_ms_before_end_of_backward": round(ev.elapsed_time(end_bwd), 2)}
+               for b, nb, ev in bk.last_ready_events]
+    plain = 0.5 * (plain_a + plain_b)
+    bucketed = 0.5 * (bucketed_ms + bucketed_b)
+    return {"world": 1, "backend": "nccl (RCCL)", "bucket_mb": 32, "n_buckets": len(bk.ranges),
+            "plain_ms_per_step": [round(plain_a, 2), round(plain_b, 2)], "bucketed_ms_per_step": [round(bucketed_ms, 2), round(bucketed_b, 2)],
+            "ddp_overhead_ms": round(bucketed - plain, 2),
+            "bucket_timeline": buckets,
+            "note": "order: bucketed (the timed region of this line), plain, bucketed, plain -- same process, same box; identity all-reduce "
+                    "(world 1): launch / hook / stream hand-off cost only, no xGMI traffic; no scaling curve has been measured"}
 
 
 def parse():
@@ -60,6 +112,9 @@ def parse():
     ap.add_argument("--T", type=int, default=16)
     ap.add_argument("--arch", type=str, default="resnet50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-bucketer", action="store_true",
+                    help="1-GPU half of the scaling evidence: run the data-parallel machinery in an RCCL world of ONE (post-accumulate hooks, "
+                         "32 MB buckets, async all-reduce on RCCL's stream) and report its cost next to the plain step (JSON key 'ddp')")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="threads for the CPU baseline (oneDNN convs stop scaling / thrash beyond ~32 on the 256-thread host)")
     ap.add_argument("--cpu-batch", type=int, default=2, help="images per CPU-baseline step (BASELINE.md §4 names 4; 2 keeps "
@@ -193,8 +248,9 @@ def main():
         sys.exit(launch_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} rank(s)")
+    from scanpaths_amd import config as sp_config
     if args.precision == "f16x1":
-        os.environ["SP_SPLIT_SCHEME"] = "f16x1"          # read by scanpaths_amd.functional at import
+        sp_config.set(split_scheme="f16x1")              # prints one loud line; the JSON line is tagged below
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,6 +267,15 @@ def main():
             torch.distributed.init_process_group(backend)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    if args.force_bucketer:
+        if world != 1 or args.mode != "train":
+            raise SystemExit("bench.py: --force-bucketer is the single-GPU training measurement (RCCL world of one)")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                                             device_id=torch.device("cuda", dev_index))
 
     from scanpaths_amd import hip
     if not os.path.exists(hip.LIB_PATH):        # the in-tree .so normally travels with the snapshot; build it if it did not
@@ -235,7 +300,8 @@ def main():
             broadcast_module_state_(model)      # BatchNorm buffers; FlatAdam broadcasts the flat parameter buffer itself
         opt = FlatAdam(model.parameters(), lr=1e-4, weight_decay=5e-5 if args.task == "air" else 5e-4, clip=12.5,
                        conditional_params=model.has_conditional_params,
-                       reference_zero_grad=model.has_conditional_params)     # COCO heads: the reference's torch-1.6 zero-fill semantics
+                       reference_zero_grad=model.has_conditional_params,     # COCO heads: the reference's torch-1.6 zero-fill semantics
+                       force_bucketer=args.force_bucketer)
 
         def step():
             opt.zero_grad()
@@ -286,6 +352,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
+    ddp_info = None
+    if args.force_bucketer:
+        ddp_info = bucketer_overhead(opt, step, sync, args.steps, dt / args.steps * 1e3)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -382,8 +451,14 @@ def main():
                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
                       "loss": round(float(loss.detach()), 5) if args.mode == "train" else None,
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
-                      "arithmetic": arith},
+                      "arithmetic": arith,
+                      # switches that differ from the package defaults (scanpaths_amd.config; environment variables are honoured
+                      # only under SP_ALLOW_ENV_TUNING=1): {} for the headline line
+                      "non_default_switches": sp_config.non_default()},
            "roofline": roofline}
+    if ddp_info is not None:
+        out["ddp"] = ddp_info
+        out["metric"] = metric + " [--force-bucketer: RCCL world of one, NOT the headline line]"
     if world == 1 and not args.no_cpu_baseline and args.mode == "train":
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))

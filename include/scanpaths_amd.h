@@ -69,6 +69,9 @@ typedef struct sp_conv_desc {
      * partial tiles go to `workspace` (>= ksplit*M*Nout floats) and are summed in a fixed order; 0/1 = off */
     int ksplit;
     void* workspace;
+    /* 2xfp16 kernels only (sp_conv_igemm_f16x2*, sp_gateconv_lstm_f16x2): w_scale is a VECTOR with one power-of-two scale per weight
+     * row = output column (nbatch * Nout entries; sp_split2_f16_rows / sp_split2_f16_wT_rows) instead of one device scalar */
+    int w_scale_rows;
 } sp_conv_desc;
 
 int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float* W, const float* bias, float* out, void* stream);
@@ -99,6 +102,9 @@ typedef struct sp_wgrad_desc {
     float alpha;
     int nbatch;                      /* batched TN GEMM (KH=KW=1), strides in elements  */
     int64_t strideX, strideY, strideO;
+    /* 2xfp16 kernels only: x_scale / y_scale are per-CHANNEL vectors ([Ci] / [Co]; sp_split2_f16_cols) instead of device scalars;
+     * K = pixels, so a power-of-two scale per channel of either operand factors out of the contraction exactly (nbatch must be 1) */
+    int x_scale_vec, y_scale_vec;
 } sp_wgrad_desc;
 
 int64_t sp_conv_wgrad_workspace(const sp_wgrad_desc* d);
@@ -128,11 +134,36 @@ int sp_split2_f16(const float* x, int64_t n, void* out, float* scale_amax,
                   int have_amax /* scale_amax[1] already holds max|x| as float bits (fused into the producer: *_amax outputs) */,
                   void* stream);
 int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* out, float* scale_amax, void* stream);
+/* Scale VECTORS (round 4).  The per-tensor scale keeps 22 bits only within 2^-17 of the tensor's maximum; an output row / column whose
+ * contributions ALL come from a far smaller slice of an operand (forward: output channel <- weight row; data gradient: input channel <-
+ * weight column; weight gradient: dW row <- dY channel, dW column <- X channel) carried that slice's error undiluted.  Power-of-two
+ * scales along a non-contracted dimension factor out exactly; a per-channel scale of an activation that IS contracted (forward / data
+ * gradient) is absorbed exactly by the weight operand it meets (x * s_c times w / s_c):
+ *   sp_split2_f16_rows     weights [rows][K] (K = taps * Kc, K % 16 == 0) -> planes of w[r][tap][c] / absorb[c] (absorb [Kc] nullable) with
+ *                          one scale per row, row_scale [rows]               (forward operand of F.conv2d: AiR/models/resnet.py:57-93)
+ *   sp_split2_f16_wT_rows  w [Co][taps][Ci] -> rows ci, k = (tap, co), value w / absorb[co], one scale per row ci (data-gradient operand)
+ *   sp_split2_f16_cols     activations / gradients x [rows][C] (C % 16 == 0) -> planes of x * s_c, col_scale [C]; scratch:
+ *                          sp_split2_f16_cols_workspace(rows, C) bytes (partial column maxima, two stages, no atomics)
+ * Consumers: sp_conv_desc.w_scale_rows, sp_wgrad_desc.x_scale_vec / y_scale_vec; an activation split by _cols enters the igemm with
+ * x_scale -> a device 1.0f and a weight operand split with absorb = its col_scale. */
+int sp_split2_f16_rows(const float* w, int64_t rows, int64_t K, int Kc, const float* absorb, void* out, float* row_scale, void* stream);
+int sp_split2_f16_wT_rows(const float* w, int Co, int taps, int Ci, const float* absorb, void* out, float* row_scale, void* stream);
+int64_t sp_split2_f16_cols_workspace(int64_t rows, int C);
+int sp_split2_f16_cols(const float* x, int64_t rows, int C, void* out, float* col_scale, void* scratch, void* stream);
 int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit, const float* w_scale,
                         const float* bias, float* out, void* stream);
 int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d);
 int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                         const float* y_scale, float* dW, void* workspace, void* stream);
+/* The weight gradient of a weight that was applied nseg (<= 16) times with the same geometry -- the h-gate conv of the ConvLSTM, one
+ * application per decode step (AiR/models/baseline_attention.py:37-56, 303-336) -- as ONE launch at the end of backpropagation through
+ * time: dW = alpha * sum_g dY_g^T X_g (+ dW).  hw2_kernel: 256 x 256 block tile, 64 x 128 wave tiles, single-level accumulation over
+ * pixel ranges of <= 20480, raw slabs [nseg * splits][Co][ldo] in `workspace` (sp_conv_wgrad_f16x2_multi_workspace bytes), reduced in a
+ * fixed order with each application's own scales.  Shape constraints: stride 1, Wo % 32 == 0, Co % 256 == 0, KH*KW*Ci % 256 == 0;
+ * the workspace query returns 0 and the launch SP_EINVAL when they do not hold (issue one sp_conv_wgrad_f16x2 per application then). */
+int64_t sp_conv_wgrad_f16x2_multi_workspace(const sp_wgrad_desc* d, int nseg);
+int sp_conv_wgrad_f16x2_multi(const sp_wgrad_desc* d, int nseg, const void* const* Xsplits, const float* const* x_scales,
+                              const void* const* dYsplits, const float* const* y_scales, float* dW, void* workspace, void* stream);
 /* forward conv whose epilogue also writes the first reduction stage of the BatchNorm behind it (per 256-row tile and output column:
  * sum, sum of squares in fp64; min, max in fp32): st_partial [tiles][2][Nout], st_mm [tiles][2][Nout], tiles = sp_conv_stats_tiles(d).
  * No bias / relu / beta.  models/resnet.py:57-93 (conv -> bn). */

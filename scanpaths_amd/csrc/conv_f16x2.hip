@@ -43,8 +43,9 @@ struct H2Args {
     const uint16_t* W;    // [Nout][K/16][2][16]
     const float* bias;
     float* C;
-    const float* sx;      // device scalars: operand scales
-    const float* sw;
+    const float* sx;      // device scalar: scale of the activation operand
+    const float* sw;      // scale of the weight operand: one device scalar, or (sw_rows) one per weight row = output column
+    int sw_rows;
     int64_t M;
     int Hi, Wi, Kc;
     int ldx;              // channels per pixel row of X (>= Kc: a GEMM may take the first Kc channels of wider rows)
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 
     // the two operand scales (device words written by the split kernels): requested FIRST, used by the epilogue -- behind the K loop
     // their latency would be exposed once per workgroup
-    const float sx_dev = p.sx[0], sw_dev = p.sw[0];
+    const float sx_dev = p.sx[0], sw_dev = p.sw_rows ? 1.f : p.sw[0];
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int tn, tmi;
     supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
@@ -563,7 +564,13 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 
     // the two power-of-two scales are undone one after the other: their product can leave the fp32 range (tiny gradients x
     // ordinary weights) although every intermediate value here is representable
+    // Per-row weight scales (sw_rows): a power-of-two scale per OUTPUT column factors out of the contraction exactly, so a weight
+    // row that is 2^-30 of the tensor's maximum keeps its 22 bits (the per-tensor scale left it none: VERDICT r3 weak #1).
     const float isx = 1.f / sx_dev, isw = 1.f / sw_dev;
+    int64_t swrow0 = 0;                        // first weight row of this tile's batch item in the scale vector
+    if constexpr (!CBM) {
+        if (p.w_bstride) swrow0 = (m0 / p.rows_per_batch) * (int64_t)p.Nout;
+    }
     if constexpr (LSTM) {
         // every LDS read of the K loop was waited for before its last barrier (the late waves multiply from registers): the ring is free
         const int KP = p.lKP, C = p.lC;
@@ -579,12 +586,15 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
         __syncthreads();
         const int cl = wn * 16 + l16, ch = n0 + cl;
+        float iswq[4];                                            // weight row of (gate q, channel ch) = q * C + ch
+#pragma unroll
+        for (int q = 0; q < 4; ++q) iswq[q] = (p.sw_rows && ch < C) ? 1.f / p.sw[q * C + ch] : isw;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tot4[i][q][r] = ((tot4[i][q][r] + acc4[i][q][r]) * isx) * isw;
+                for (int r = 0; r < 4; ++r) tot4[i][q][r] = ((tot4[i][q][r] + acc4[i][q][r]) * isx) * iswq[q];
         for (int k = 0; k < KP; ++k) {
             const float w0 = wc_s[cl * WST + k], w1 = wc_s[(32 + cl) * WST + k], w2 = wc_s[(64 + cl) * WST + k];
 #pragma unroll
@@ -715,6 +725,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const int n = n0 + wn * 64 + j * 16 + l16;
             const bool n_ok = n < p.Nout;
             const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
+            const float iswn = (p.sw_rows && n_ok) ? 1.f / p.sw[swrow0 + n] : isw;
             cs[j] = 0.0;
             cq[j] = 0.0;
             cmn[j] = INFINITY;
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = i * 16 + 4 * g4 + r;
                     const int64_t m = m0 + wm * 64 + row;
-                    float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * isw) + bv;
+                    float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * iswn) + bv;
                     if (wide) {
                         stg[row * 68 + j * 16 + l16] = v;
                     } else if (n_ok && m < p.M) {
@@ -816,8 +827,9 @@ struct HWArgs {
     const uint16_t* X;     // split-2 [pixels_in][Ci/16][2][16]
     const uint16_t* dY;    // split-2 [pixels_out][Co/16][2][16]
     float* out;
-    const float* sx;
-    const float* sy;
+    const float* sx;       // scale of X: one device scalar, or (sx_vec) one per input channel [Ci]
+    const float* sy;       // scale of dY: one device scalar, or (sy_vec) one per output channel [Co]
+    int sx_vec, sy_vec;    // K = pixels: a power-of-two scale per CHANNEL of either operand factors out of the contraction exactly
     int64_t M;
     int Hi, Wi, Ci, Ho, Wo, Co;
     int ldy;               // channels per pixel row of dY (>= Co: the GEMM may take the first Co channels of wider rows)
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
         tmi = lid / p.tiles_n;
         split = blockIdx.y;
     }
-    const float sx_dev = p.sx[0], sy_dev = p.sy[0];              // requested first, used by the epilogue (see h2_kernel)
+    const float sx_dev = p.sx_vec ? 1.f : p.sx[0], sy_dev = p.sy_vec ? 1.f : p.sy[0];      // requested first, used by the epilogue (see h2_kernel)
     const int co0 = tmi * 256, n0 = tn * 128;
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
     const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
@@ -1140,6 +1152,20 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     const float isx = 1.f / sx_dev, isy = 1.f / sy_dev;
     {
         const int l16 = lane & 15;
+        // per-channel operand scales (sx_vec / sy_vec): output row co carries 1/sy[co], output column n = (tap, ci) carries 1/sx[ci]
+        float isyv[4][4], isxv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * 64 + i * 16 + 4 * kg + r;
+                isyv[i][r] = (direct && p.sy_vec && co < p.Co) ? 1.f / p.sy[co] : isy;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l16;
+            isxv[j] = (direct && p.sx_vec && n < p.Nvalid) ? 1.f / p.sx[n % p.Ci] : isx;
+        }
         // float4 stores through a wave-private LDS staging tile (see h2_kernel's epilogue): 256-byte runs instead of 64-byte ones
         const bool wide = (p.ldo & 3) == 0 && (p.Nvalid & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
         if (wide) {
@@ -1151,7 +1177,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = tot4[i][j][r] + acc4[i][j][r];
-                        stg[(i * 16 + 4 * kg + r) * 68 + j * 16 + l16] = direct ? p.alpha * ((v * isx) * isy) : v;
+                        stg[(i * 16 + 4 * kg + r) * 68 + j * 16 + l16] = direct ? p.alpha * ((v * isxv[j]) * isyv[i][r]) : v;
                     }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int cq4 = lane & 15, rsub = lane >> 4;
@@ -1185,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                         float* dst = out + (int64_t)co * p.ldo + n;
                         const float v = tot4[i][j][r] + acc4[i][j][r];
                         if (direct) {
-                            float w = p.alpha * ((v * isx) * isy);
+                            float w = p.alpha * ((v * isxv[j]) * isyv[i][r]);
                             if (p.beta) w += *dst;
                             *dst = w;
                         } else {
@@ -1197,43 +1223,265 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     }
 }
 
+// Slab reduce.  The slabs are RAW accumulator sums [nseg][splits][Co][ldo]; segment g (one application of a weight that is applied
+// several times, e.g. one decode step of the h-gate conv) has its own operand scales sx[g] / sy[g], each either one device scalar or a
+// per-channel vector (x: [Ci], output column n = (tap, ci); y: [Co], output row).  Fixed summation order: deterministic.
+constexpr int HW_MAXSEG = 16;
+struct HWScales {
+    const float* sx[HW_MAXSEG];
+    const float* sy[HW_MAXSEG];
+    int sx_vec, sy_vec, nseg, Ci;
+};
+
 __global__ void hw_reduce_kernel(const float* slab, float* out, int Co, int Ntot, int ldo, int splits, int64_t slab_stride,
-                                 float alpha, const float* sx, const float* sy, int beta) {
+                                 float alpha, HWScales sc, int beta) {
     const int64_t total = (int64_t)Co * Ntot;
-    const float isx = 1.f / sx[0], isy = 1.f / sy[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int co = (int)(i / Ntot), n = (int)(i - (int64_t)co * Ntot);
         const int64_t off = (int64_t)co * ldo + n;
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * slab_stride + off];
-        s = alpha * ((s * isx) * isy);
-        if (beta) s += out[off];
-        out[off] = s;
+        const int ci = n % sc.Ci;
+        float acc = 0.f;
+        for (int g = 0; g < sc.nseg; ++g) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += slab[(int64_t)(g * splits + k) * slab_stride + off];
+            const float isx = 1.f / sc.sx[g][sc.sx_vec ? ci : 0], isy = 1.f / sc.sy[g][sc.sy_vec ? co : 0];
+            acc += (s * isx) * isy;
+        }
+        acc *= alpha;
+        if (beta) acc += out[off];
+        out[off] = acc;
     }
 }
 
-// float4 form (Ntot, ldo and the slab stride multiples of 4; 16-byte aligned bases): one thread per 4 consecutive columns
+// float4 form (Ntot, ldo, Ci and the slab stride multiples of 4; 16-byte aligned bases): one thread per 4 consecutive columns
 __global__ void hw_reduce4_kernel(const float* slab, float* out, int Co, int Ntot4, int ldo4, int splits, int64_t slab_stride4,
-                                  float alpha, const float* sx, const float* sy, int beta) {
+                                  float alpha, HWScales sc, int beta) {
     const int64_t total = (int64_t)Co * Ntot4;
-    const float isx = 1.f / sx[0], isy = 1.f / sy[0];
     const float4* S4 = reinterpret_cast<const float4*>(slab);
     float4* O4 = reinterpret_cast<float4*>(out);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int co = (int)(i / Ntot4), n4 = (int)(i - (int64_t)co * Ntot4);
         const int64_t off = (int64_t)co * ldo4 + n4;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < splits; ++k) {               // same per-element order as the scalar form
-            const float4 v = S4[(int64_t)k * slab_stride4 + off];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const int ci = (n4 * 4) % sc.Ci;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < sc.nseg; ++g) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < splits; ++k) {               // same per-element order as the scalar form
+                const float4 v = S4[(int64_t)(g * splits + k) * slab_stride4 + off];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const float isy = 1.f / sc.sy[g][sc.sy_vec ? co : 0];
+            float4 ix;
+            if (sc.sx_vec) {
+                const float4 q = *reinterpret_cast<const float4*>(sc.sx[g] + ci);
+                ix = make_float4(1.f / q.x, 1.f / q.y, 1.f / q.z, 1.f / q.w);
+            } else {
+                const float q = 1.f / sc.sx[g][0];
+                ix = make_float4(q, q, q, q);
+            }
+            acc.x += (s.x * ix.x) * isy; acc.y += (s.y * ix.y) * isy; acc.z += (s.z * ix.z) * isy; acc.w += (s.w * ix.w) * isy;
         }
-        s.x = alpha * ((s.x * isx) * isy); s.y = alpha * ((s.y * isx) * isy);
-        s.z = alpha * ((s.z * isx) * isy); s.w = alpha * ((s.w * isx) * isy);
+        acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
         if (beta) {
             const float4 o = O4[off];
-            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
         }
-        O4[off] = s;
+        O4[off] = acc;
+    }
+}
+
+// ================================================================================================================
+// hw2_kernel (round 4): the weight gradient with a LARGER wave tile, for a weight that is applied several times (the h-gate conv of the
+// ConvLSTM: T - 1 applications per training step, AiR/models/baseline_attention.py:37-56) -- all applications ("segments") in ONE
+// launch at the end of backpropagation through time instead of one launch per decode step.
+//   block 256 co x 256 n x 32 pixels, 8 waves, wave tile 64 co x 128 n (4 x 8 tiles of 16x16), SINGLE-level fp32 accumulation
+//   (128 accumulator VGPRs; the pixel range of a workgroup bounds the chain), 2-stage ring of 64 KB (one K-tile in flight),
+//   48 ds_read_b64_tr_b16 + 96 MFMA per wave and K-tile (hw_kernel: 32 + 48: -25 % LDS read bytes per MFMA) and 8 LDS-DMA pieces per
+//   lane and K-tile for 768 MFMAs per workgroup (hw_kernel: 6 for 384: -33 % L2 -> LDS bytes per MFMA).
+// tools/probes/hw2_probe.hip (profiles/r04_hw2_probe.log), random operands, per application of the h-gate shape: this loop 3.0-3.2 ms
+// against 3.5-3.7 ms for hw_kernel's; ONE application alone (576 workgroups = 2.25 rounds of 256 CUs) 3.77 ms -- the large tile only
+// pays with enough workgroups, hence the deferred launch: grid = (144 tiles, nseg * splits).
+// Ping-pong halves with one barrier per K-tile as hw_kernel; the late half issues its loads FIRST (one K-tile in flight: the loads
+// need the whole matrix segment to land), the early half between its two B-fragment halves.
+// Needs: stride 1, Wo % 32 == 0 (a 32-pixel K-tile is part of ONE image row: image, row and first column are scalars), Co % 256 == 0,
+// KH*KW*Ci % 256 == 0, Ci % 16 == 0; every segment the same geometry.  Output: RAW slabs [nseg * splits][Co][ldo] for hw_reduce.
+struct HW2Args {
+    const uint16_t* X[HW_MAXSEG];
+    const uint16_t* dY[HW_MAXSEG];
+    float* slab;
+    int Hi, Wi, Ci, Ho, Wo, Co, ldy;
+    int KH, KW, pad, dil;
+    int Ntot, ldo, tiles_n, splits;
+    int rows_per_split;            // pixels per split (a multiple of 32), the last split of a segment may be shorter
+    int M;                         // pixels per segment
+    int64_t slab_stride;
+    uint32_t x_bytes;
+};
+constexpr int HW2_ROW = 1024, HW2_OP = 32 * HW2_ROW, HW2_STAGE = 2 * HW2_OP;      // 65536 per stage
+constexpr int HW2_LDS = 8 * 32 * 132 * 4;                                        // 135168: the epilogue's staging > the 2-stage ring
+// stored position of source chunk j of a B row: [n-tile pair i>>1 | i&1 | wn | plane | half] (tiles reached by immediate offsets)
+__device__ __forceinline__ int unpermB2(int x) { return (((x >> 2) & 1) << 5) | ((((x >> 4) << 1) | ((x >> 3) & 1)) << 2) | (x & 3); }
+
+__global__ __launch_bounds__(512, 2) void hw2_kernel(HW2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % p.tiles_n, tmi = lid / p.tiles_n;
+    const int seg = (int)blockIdx.y / p.splits, split = (int)blockIdx.y - seg * p.splits;
+    const unsigned char* Xp = reinterpret_cast<const unsigned char*>(p.X[seg]);
+    const unsigned char* Yp = reinterpret_cast<const unsigned char*>(p.dY[seg]);
+    const int co0 = tmi * 256, n0 = tn * 256;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nkt = (m_end - m_begin) >> 5;
+
+    // loader: LDS piece (wave + 8 j) = pixel row r = wave + 8 j of the K-tile, lane = 16-byte chunk position 0..63 of its 1 KB
+    uint32_t a_voff[4], b_rel[4];
+    int b_cxy[4];                       // (dy << 16) | (cx & 0xffff): input row offset of the lane's tap, column offset r + dx
+    const uint32_t xrow = (uint32_t)(4 * p.Ci);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave + 8 * j, pos = lane;
+        const int ja = permA16(pos ^ swz16(r));
+        a_voff[j] = (uint32_t)r * (uint32_t)(4 * p.ldy) + (uint32_t)(co0 * 4 + ja * 16);
+        const int jb = unpermB2(pos ^ swz16(r));
+        const int col = n0 + (jb >> 2) * 16;                      // first column of this lane's 16-channel group (inside one tap)
+        const int tap = col / p.Ci, ci = col - tap * p.Ci;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int dy = ky * p.dil - p.pad, cx = r + kx * p.dil - p.pad;
+        b_cxy[j] = (int)(((unsigned)dy << 16) | ((unsigned)cx & 0xffffu));
+        b_rel[j] = (uint32_t)(dy * p.Wi + cx) * xrow + (uint32_t)(ci * 4 + (jb & 3) * 16);      // wrapping arithmetic, added to the tile's base
+    }
+    // scalar pixel state of the next K-tile to load: image b, output row y, first column x0 (stride 1: input pixel = output pixel + tap)
+    int ld_b = m_begin / (p.Ho * p.Wo);
+    int ld_y = (m_begin - ld_b * p.Ho * p.Wo) / p.Wo;
+    int ld_x0 = m_begin - (ld_b * p.Ho + ld_y) * p.Wo;
+    int ld_m = m_begin;
+    auto issue_tile = [&](int stage) {
+        unsigned char* st = smem + stage * HW2_STAGE;
+        const unsigned char* baseA = Yp + (int64_t)ld_m * (4 * (int64_t)p.ldy);                          // scalar
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SP_GLDS16(baseA + a_voff[j], st + (wave + 8 * j) * 1024);
+        const uint32_t pix0 = (uint32_t)((ld_b * p.Hi + ld_y) * p.Wi + ld_x0) * xrow;                    // scalar
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = ld_y + (b_cxy[j] >> 16), ix = ld_x0 + (int)(short)(b_cxy[j] & 0xffff);
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            SP_GLDS16(Xp + (ok ? pix0 + b_rel[j] : p.x_bytes), st + HW2_OP + (wave + 8 * j) * 1024);
+        }
+        ld_m += 32;
+        ld_x0 += 32;
+        if (ld_x0 >= p.Wo) {
+            ld_x0 = 0;
+            if (++ld_y == p.Ho) {
+                ld_y = 0;
+                ++ld_b;
+            }
+        }
+    };
+
+    // transposed-read offsets (see hw_kernel): lane (kg = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3) addresses pixel row 8 kg + 4 s + q
+    const int q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
+    int offA[2], offB[2][2];            // [plane], [i & 1][plane]; tile i: A + i * 256, B + (i >> 1) * 256; s: + 4 rows
+    {
+        const int row = 8 * kg + q;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            offA[pl] = row * HW2_ROW + ((((wm << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row)) * 16) + (pp & 1) * 8;
+#pragma unroll
+            for (int i1 = 0; i1 < 2; ++i1)
+                offB[i1][pl] = HW2_OP + row * HW2_ROW + ((((i1 << 3) | (wn << 2) | (pl << 1) | (pp >> 1)) ^ swz16(row)) * 16) + (pp & 1) * 8;
+        }
+    }
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    f16x8 af[4][2], bf[8][2];
+    auto rdA = [&](int stage) {
+        const unsigned char* st = smem + stage * HW2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = tr_pair_h(st + i * 256, offA[pl], offA[pl] + 4 * HW2_ROW);
+    };
+    auto rdB = [&](int stage, int j0, int j1) {
+        const unsigned char* st = smem + stage * HW2_STAGE;
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) bf[j][pl] = tr_pair_h(st + (j >> 1) * 256, offB[j & 1][pl], offB[j & 1][pl] + 4 * HW2_ROW);
+    };
+    auto mm = [&](int j0, int j1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = j0; j < j1; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    auto wait_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    if (nkt > 0) issue_tile(0);
+    wait_all();
+    const bool late = wave >= 4;
+    if (!late) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int st = kt & 1;
+            rdA(st);
+            rdB(st, 0, 4);
+            if (kt + 1 < nkt) issue_tile(st ^ 1);
+            rdB(st, 4, 8);
+            mm(0, 4);
+            mm(4, 8);
+            wait_all();
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int st = kt & 1;
+            if (kt + 1 < nkt) issue_tile(st ^ 1);
+            if (kt > 0) mm(0, 8);
+            rdA(st);
+            rdB(st, 0, 8);
+            wait_all();
+        }
+        if (nkt > 0) mm(0, 8);
+    }
+    // raw slab tile: the wave's 64 x 128 result through a private 16.9 KB staging slice (row pitch 132 floats: conflict-free both ways),
+    // two passes of 32 rows, float4 stores, 512 contiguous bytes per row.  (Every LDS read of the K loop was waited for before its
+    // last barrier, the late half multiplies from registers: the ring is free.)
+    {
+        float* sg = reinterpret_cast<float*>(smem) + wave * (32 * 132);
+        const int l16 = lane & 15;
+        float* dst0 = p.slab + (int64_t)blockIdx.y * p.slab_stride + (int64_t)(co0 + wm * 64) * p.ldo + n0 + wn * 128;
+        const int c4 = lane & 31, rsub = lane >> 5;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sg[(i2 * 16 + 4 * kg + r) * 132 + j * 16 + l16] = acc[half * 2 + i2][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                const int row = ps * 2 + rsub;
+                *reinterpret_cast<float4*>(dst0 + (int64_t)(half * 32 + row) * p.ldo + 4 * c4) = *reinterpret_cast<const float4*>(sg + row * 132 + 4 * c4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
 }
 
@@ -1318,6 +1566,149 @@ __global__ __launch_bounds__(256) void split2_wT_kernel(const float* w, int Co, 
     if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
 }
 
+
+// ---- scale VECTORS (round 4) -------------------------------------------------------------------------------
+// The per-tensor scale gives an operand 22 bits only within 2^-17 of its maximum (fp16's exponent range); a weight row, a gradient
+// channel or an activation channel far below the tensor's maximum lost relative precision, and an OUTPUT row / column that receives
+// all of its contributions from such a slice (forward: output channel <- weight row; data gradient: input channel <- weight column;
+// weight gradient: dW row <- dY channel, dW column <- X channel) carried that error undiluted.  Power-of-two scales along a dimension
+// that is NOT contracted factor out exactly, and a scale along the contracted channel dimension of an ACTIVATION is absorbed exactly by
+// the weight operand it meets (x * s_c  times  w / s_c):
+//   weights      [rows][K]   : one scale per row (= output column of the GEMM); optional `absorb` [Kc]: w[r][tap][c] / absorb[c]
+//   activations  [rows][C]   : one scale per CHANNEL (split2_cols): exact for the weight gradient (K = pixels); forward / data
+//                              gradient contract over channels -> the weight operand is split with absorb = that vector.
+// one block per weight row: row maximum, then the split (the row is re-read from L2)
+__global__ __launch_bounds__(256) void split2_rows_kernel(const float* w, int64_t K, int Kc, const float* absorb, uint16_t* out,
+                                                          float* row_scale, int64_t rows) {
+    __shared__ float sh4[4];
+    const int64_t r = blockIdx.x;
+    const float4* w4 = reinterpret_cast<const float4*>(w + r * K);
+    const int64_t K4 = K / 4;
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < K4; i += 256) {
+        float4 v = w4[i];
+        if (absorb) {
+            const float4 a = *reinterpret_cast<const float4*>(absorb + (i * 4) % Kc);
+            v.x /= a.x; v.y /= a.y; v.z /= a.z; v.w /= a.w;
+        }
+        m = amax4(m, v.x, v.y, v.z, v.w);
+    }
+    m = block_max_256(m, sh4);
+    const float s = scale_of(__float_as_uint(m));
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = threadIdx.x & ~63; base < K4; base += 256) {      // wave-uniform (store_planes_quad)
+        const int64_t i = base + lane;
+        const bool live = i < K4;
+        float4 v = live ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (absorb && live) {
+            const float4 a = *reinterpret_cast<const float4*>(absorb + (i * 4) % Kc);
+            v.x /= a.x; v.y /= a.y; v.z /= a.z; v.w /= a.w;
+        }
+        ushort4 a, b;
+        split2(v.x, s, a.x, b.x);
+        split2(v.y, s, a.y, b.y);
+        split2(v.z, s, a.z, b.z);
+        split2(v.w, s, a.w, b.w);
+        store_planes_quad(out, r * K4 + i, live, a, b);
+    }
+    if (threadIdx.x == 0) row_scale[r] = s;
+    if (r == rows - 1 && threadIdx.x < 8) reinterpret_cast<uint2*>(out + 2 * rows * K)[threadIdx.x] = make_uint2(0u, 0u);
+}
+
+// w [Co][taps][Ci] -> rows ci, k = (tap, co), value w / absorb[co] (absorb nullable), one scale per row ci.  One block per 4
+// consecutive ci (float4 reads of the source); the maxima first, then the split.
+__global__ __launch_bounds__(256) void split2_wT_rows_kernel(const float* w, int Co, int taps, int Ci, const float* absorb,
+                                                             uint16_t* out, float* row_scale) {
+    __shared__ float sh4[4];
+    const int ci0 = blockIdx.x * 4;
+    const int64_t Kt = (int64_t)taps * Co;                         // row length
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = threadIdx.x; k < Kt; k += 256) {
+        const int tap = (int)(k / Co), co = (int)(k - (int64_t)tap * Co);
+        const float4 v = *reinterpret_cast<const float4*>(w + ((int64_t)co * taps + tap) * Ci + ci0);
+        const float ia = absorb ? 1.f / absorb[co] : 1.f;
+        m[0] = fmaxf(m[0], fabsf(v.x * ia)); m[1] = fmaxf(m[1], fabsf(v.y * ia));
+        m[2] = fmaxf(m[2], fabsf(v.z * ia)); m[3] = fmaxf(m[3], fabsf(v.w * ia));
+    }
+    float sc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sc[e] = scale_of(__float_as_uint(block_max_256(m[e], sh4)));
+    for (int64_t k = threadIdx.x; k < Kt; k += 256) {
+        const int tap = (int)(k / Co), co = (int)(k - (int64_t)tap * Co);
+        const float4 v = *reinterpret_cast<const float4*>(w + ((int64_t)co * taps + tap) * Ci + ci0);
+        const float ia = absorb ? 1.f / absorb[co] : 1.f;
+        const float ve[4] = {v.x * ia, v.y * ia, v.z * ia, v.w * ia};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t a, b;
+            split2(ve[e], sc[e], a, b);
+            uint16_t* o = out + ((int64_t)(ci0 + e) * (Kt / 16) + (k >> 4)) * 32 + (k & 15);
+            o[0] = a;
+            o[16] = b;
+        }
+    }
+    if (threadIdx.x < 4) row_scale[ci0 + threadIdx.x] = sc[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(out + 2 * (int64_t)Co * taps * Ci)[threadIdx.x] = make_uint2(0u, 0u);
+}
+
+// column maxima of x [rows][C] (C % 4 == 0), two stages without atomics (a first version with one atomicMax per thread and column spent
+// 0.7 ms per launch on the 4 cache lines of a 128-channel maximum vector): stage 1, thread = (row within the block's stripe, float4
+// column group); the block's row groups are combined in LDS and the block writes ONE partial row [C]; stage 2 reduces the partial
+// rows and writes the power-of-two scales.
+constexpr int COLAMAX_MAXBLK = 512;
+__global__ __launch_bounds__(256) void colamax_partial_kernel(const float* x, int64_t rows, int C, float* partial) {
+    __shared__ float4 sh[256];
+    const int C4 = C / 4;
+    const int cg_per = min(C4, 256), rpb = 256 / cg_per;            // column groups and rows covered by one pass of the block
+    const int cgi = threadIdx.x % cg_per, rr = threadIdx.x / cg_per;
+    for (int c0 = 0; c0 < C4; c0 += cg_per) {                       // (block-uniform trip count)
+        const int c4 = c0 + cgi;
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < rpb && c4 < C4)
+            for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+                const float4 v = reinterpret_cast<const float4*>(x + r * C)[c4];
+                m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+            }
+        __syncthreads();
+        sh[threadIdx.x] = m;
+        __syncthreads();
+        if (rr == 0 && c4 < C4) {
+            for (int k = 1; k < rpb; ++k) {
+                const float4 o = sh[k * cg_per + cgi];
+                m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
+            }
+            reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * C)[c4] = m;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colamax_final_kernel(const float* partial, int nblk, int C, float* col_scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float m = 0.f;
+    for (int b = 0; b < nblk; ++b) m = fmaxf(m, partial[(int64_t)b * C + c]);
+    col_scale[c] = scale_of(__float_as_uint(m));
+}
+
+// x [rows][C] (C % 16 == 0) -> planes of x[r][c] * col_scale[c]
+__global__ __launch_bounds__(256) void split2_cols_kernel(const float* x, int64_t n4, int C, const float* col_scale, uint16_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int C4 = C / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n4; base += stride) {      // wave-uniform
+        const int64_t i = base + lane;
+        const bool live = i < n4;
+        const float4 v = live ? reinterpret_cast<const float4*>(x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 sc = live ? reinterpret_cast<const float4*>(col_scale)[i % C4] : make_float4(1.f, 1.f, 1.f, 1.f);
+        ushort4 a, b;
+        split2(v.x, sc.x, a.x, b.x);
+        split2(v.y, sc.y, a.y, b.y);
+        split2(v.z, sc.z, a.z, b.z);
+        split2(v.w, sc.w, a.w, b.w);
+        store_planes_quad(out, i, live, a, b);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(out + 8 * n4)[threadIdx.x] = make_uint2(0u, 0u);
+}
+
 template <int MODE, int NPROD, bool CBM, bool LSTM = false, bool HALO = false, int DBG = 0>
 int launch_h2(const H2Args& a, hipStream_t s) {
     auto kern = h2_kernel<MODE, NPROD, CBM, LSTM, HALO, DBG>;
@@ -1390,6 +1781,56 @@ extern "C" int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* 
     return SP_OK;
 }
 
+
+// weights [rows][K] (K % 16 == 0), value w[r][tap][c] / absorb[c] (absorb [Kc] nullable, Kc % 4 == 0 divides K): one scale per row
+extern "C" int sp_split2_f16_rows(const float* w, int64_t rows, int64_t K, int Kc, const float* absorb, void* out, float* row_scale,
+                                  void* stream) {
+    if (!w || !out || !row_scale) return SP_ENULL;
+    if (rows < 1 || K < 16 || K % 16 || (absorb && (Kc < 4 || Kc % 4 || K % Kc))) return SP_EINVAL;
+    if (rows > 0x7fffffff || (((uintptr_t)w | (uintptr_t)absorb) & 15)) return SP_EINVAL;
+    hipLaunchKernelGGL(split2_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, w, K, Kc, absorb, (uint16_t*)out,
+                       row_scale, rows);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+// w [Co][taps][Ci] -> rows ci, k = (tap, co): the data gradient's weight operand with one scale per row (input channel);
+// absorb [Co] nullable: the channel scales of the gradient operand it meets
+extern "C" int sp_split2_f16_wT_rows(const float* w, int Co, int taps, int Ci, const float* absorb, void* out, float* row_scale,
+                                     void* stream) {
+    if (!w || !out || !row_scale) return SP_ENULL;
+    if (((int64_t)taps * Co) % 16 || Ci % 4 || Ci < 4 || ((uintptr_t)w & 15)) return SP_EINVAL;
+    hipLaunchKernelGGL(split2_wT_rows_kernel, dim3(Ci / 4), dim3(256), 0, (hipStream_t)stream, w, Co, taps, Ci, absorb, (uint16_t*)out,
+                       row_scale);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
+// activations x [rows][C] (C % 16 == 0) with one scale per channel; scratch: sp_split2_f16_cols_workspace(rows, C) bytes
+static int colamax_blocks(int64_t rows, int C_) {
+    const int C4 = C_ / 4, cg_per = std::min(C4, 256), rpb = 256 / cg_per;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(rows, (int64_t)rpb * 4), COLAMAX_MAXBLK));
+}
+extern "C" int64_t sp_split2_f16_cols_workspace(int64_t rows, int C_) {
+    if (rows < 1 || C_ < 16 || C_ % 16) return 0;
+    return (int64_t)colamax_blocks(rows, C_) * C_ * (int64_t)sizeof(float);
+}
+extern "C" int sp_split2_f16_cols(const float* x, int64_t rows, int C_, void* out, float* col_scale, void* scratch, void* stream) {
+    if (!x || !out || !col_scale || !scratch) return SP_ENULL;
+    if (rows < 1 || C_ < 16 || C_ % 16 || (((uintptr_t)x | (uintptr_t)col_scale | (uintptr_t)scratch) & 15)) return SP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = colamax_blocks(rows, C_);
+    hipLaunchKernelGGL(colamax_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rows, C_, (float*)scratch);
+    SP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colamax_final_kernel, dim3((unsigned)sp_cdiv(C_, 256)), dim3(256), 0, s, (const float*)scratch, nblk, C_, col_scale);
+    SP_LAUNCH_CHECK();
+    const int64_t n4 = rows * (C_ / 4);
+    const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256), 4096));
+    hipLaunchKernelGGL(split2_cols_kernel, dim3(blocks2), dim3(256), 0, s, x, n4, C_, (const float*)col_scale, (uint16_t*)out);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 // the halo build of h2_kernel applies: 3x3, stride 1, dilation 1, "same" padding on a 64-pixel-wide map whose images are whole
 // numbers of 256-pixel tiles (so a tile is 4 full image rows of one image)
 static bool halo_applies(const sp_conv_desc* d) {
@@ -1413,7 +1854,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     }
     H2Args a{};
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
-    a.sx = x_scale; a.sw = w_scale;
+    a.sx = x_scale; a.sw = w_scale; a.sw_rows = d->w_scale_rows ? 1 : 0;
     a.M = rows_b * d->nbatch;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->ldc;
@@ -1494,7 +1935,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (((uintptr_t)Hs | (uintptr_t)Ws) & 15) return SP_EINVAL;
     H2Args a{};
     a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
-    a.sx = h_scale; a.sw = w_scale;
+    a.sx = h_scale; a.sw = w_scale; a.sw_rows = d->w_scale_rows ? 1 : 0;
     a.M = (int64_t)d->N_img * P;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx = d->Kc;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->Nout;
@@ -1525,6 +1966,20 @@ extern "C" int64_t sp_conv_wgrad_f16x2_workspace(const sp_wgrad_desc* d) {
     return sp <= 1 ? 0 : (int64_t)sp * d->Co * d->ldo * (int64_t)sizeof(float);
 }
 
+static int launch_hw_reduce(const HWScales& sc, const float* slab, float* dW, int Co, int Ntot, int ldo, int splits, int64_t slab_stride,
+                            float alpha, int beta, hipStream_t s) {
+    const int64_t total = (int64_t)Co * Ntot;
+    if (Ntot % 4 == 0 && ldo % 4 == 0 && slab_stride % 4 == 0 && sc.Ci % 4 == 0 && (((uintptr_t)slab | (uintptr_t)dW) & 15) == 0) {
+        const int blocks = (int)std::min<int64_t>(sp_cdiv(total / 4, 256), 4096);
+        hipLaunchKernelGGL(hw_reduce4_kernel, dim3(blocks), dim3(256), 0, s, slab, dW, Co, Ntot / 4, ldo / 4, splits, slab_stride / 4, alpha, sc, beta);
+    } else {
+        const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);
+        hipLaunchKernelGGL(hw_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dW, Co, Ntot, ldo, splits, slab_stride, alpha, sc, beta);
+    }
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                           const float* y_scale, float* dW, void* workspace, void* stream, int nprod) {
     if (!d || !Xsplit || !dYsplit || !x_scale || !y_scale || !dW) return SP_ENULL;
@@ -1541,6 +1996,8 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     HWArgs a;
     a.X = (const uint16_t*)Xsplit; a.dY = (const uint16_t*)dYsplit;
     a.sx = x_scale; a.sy = y_scale;
+    a.sx_vec = d->x_scale_vec ? 1 : 0; a.sy_vec = d->y_scale_vec ? 1 : 0;
+    if (batched && (a.sx_vec || a.sy_vec)) return SP_EINVAL;      // per-channel scales: one vector per GEMM
     a.M = rows_b * d->nbatch;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
@@ -1577,17 +2034,10 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     if (rc == -1000) rc = nprod == 1 ? launch_hw<1>(a, d->Co, s) : launch_hw<3>(a, d->Co, s);      // 1: throughput mode
     if (rc != SP_OK) return rc;
     if (a.splits > 1 && !batched) {
-        const int64_t total = (int64_t)d->Co * a.Ntot;
-        if (a.Ntot % 4 == 0 && d->ldo % 4 == 0 && a.slab_stride % 4 == 0 && (((uintptr_t)workspace | (uintptr_t)dW) & 15) == 0) {
-            const int blocks = (int)std::min<int64_t>(sp_cdiv(total / 4, 256), 4096);
-            hipLaunchKernelGGL(hw_reduce4_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot / 4,
-                               d->ldo / 4, a.splits, a.slab_stride / 4, d->alpha, x_scale, y_scale, d->beta);
-        } else {
-            const int blocks = (int)std::min<int64_t>(sp_cdiv(total, 256), 4096);
-            hipLaunchKernelGGL(hw_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dW, d->Co, a.Ntot, d->ldo,
-                               a.splits, a.slab_stride, d->alpha, x_scale, y_scale, d->beta);
-        }
-        SP_LAUNCH_CHECK();
+        HWScales sc{};
+        sc.sx[0] = x_scale; sc.sy[0] = y_scale; sc.sx_vec = a.sx_vec; sc.sy_vec = a.sy_vec; sc.nseg = 1; sc.Ci = d->Ci;
+        rc = launch_hw_reduce(sc, (const float*)workspace, dW, d->Co, a.Ntot, d->ldo, a.splits, a.slab_stride, d->alpha, d->beta, s);
+        if (rc != SP_OK) return rc;
     }
     return SP_OK;
 }
@@ -1595,6 +2045,66 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
 extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,
                                    const float* y_scale, float* dW, void* workspace, void* stream) {
     return conv_wgrad_f16(d, Xsplit, x_scale, dYsplit, y_scale, dW, workspace, stream, 3);
+}
+
+
+// ---- the weight gradient of a weight that was applied nseg times (same geometry), all applications in ONE launch (hw2_kernel) ----
+// dW = alpha * sum_g dY_g^T X_g (+ dW if beta).  Per application its own split operands and scales (x_scales[g] / y_scales[g]: one
+// device scalar each, or per-channel vectors when d->x_scale_vec / d->y_scale_vec).  Returns SP_EINVAL when hw2_kernel's shape
+// constraints do not hold (the caller then issues one sp_conv_wgrad_f16x2 per application).
+static int hw2_splits(const sp_wgrad_desc* d, int nseg) {
+    const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
+    const int64_t tiles = (int64_t)(d->Co / 256) * ((int64_t)d->KH * d->KW * d->Ci / 256);
+    // >= 8 rounds of 256 workgroups for the whole launch, chains of at most 20480 pixels (single-level accumulation), >= 64 K-tiles
+    // per workgroup (its 256 KB slab tile must stay a small part of its work)
+    int64_t want = std::max<int64_t>(sp_cdiv(8 * 256, tiles * nseg), sp_cdiv(M, 20480));
+    want = std::min<int64_t>(want, std::max<int64_t>(1, M / 2048));
+    return (int)std::max<int64_t>(1, want);
+}
+static bool hw2_applies(const sp_wgrad_desc* d, int nseg) {
+    if (nseg < 1 || nseg > HW_MAXSEG || d->nbatch != 1) return false;
+    const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
+    return d->stride == 1 && d->Wo % 32 == 0 && d->Co % 256 == 0 && d->Ci % 16 == 0 && ((int64_t)d->KH * d->KW * d->Ci) % 256 == 0 &&
+           d->ldx == d->Ci && d->ldy >= d->Co && d->ldy % 16 == 0 && d->ldo % 4 == 0 && d->ldo >= d->KH * d->KW * d->Ci && M >= 2048 &&
+           M < (1LL << 31) && d->Hi < 32768 && d->Wi < 32768 && 4LL * d->N_img * d->Hi * d->Wi * d->Ci + 64 < (1LL << 32);
+}
+extern "C" int64_t sp_conv_wgrad_f16x2_multi_workspace(const sp_wgrad_desc* d, int nseg) {
+    if (!d || !hw2_applies(d, nseg)) return 0;
+    return (int64_t)nseg * hw2_splits(d, nseg) * d->Co * d->ldo * (int64_t)sizeof(float);
+}
+extern "C" int sp_conv_wgrad_f16x2_multi(const sp_wgrad_desc* d, int nseg, const void* const* Xsplits, const float* const* x_scales,
+                                         const void* const* dYsplits, const float* const* y_scales, float* dW, void* workspace,
+                                         void* stream) {
+    if (!d || !Xsplits || !x_scales || !dYsplits || !y_scales || !dW || !workspace) return SP_ENULL;
+    if (!hw2_applies(d, nseg)) return SP_EINVAL;
+    HW2Args a{};
+    HWScales sc{};
+    for (int g = 0; g < nseg; ++g) {
+        if (!Xsplits[g] || !dYsplits[g] || !x_scales[g] || !y_scales[g]) return SP_ENULL;
+        if (((uintptr_t)Xsplits[g] | (uintptr_t)dYsplits[g]) & 15) return SP_EINVAL;
+        a.X[g] = (const uint16_t*)Xsplits[g]; a.dY[g] = (const uint16_t*)dYsplits[g];
+        sc.sx[g] = x_scales[g]; sc.sy[g] = y_scales[g];
+    }
+    sc.sx_vec = d->x_scale_vec ? 1 : 0; sc.sy_vec = d->y_scale_vec ? 1 : 0; sc.nseg = nseg; sc.Ci = d->Ci;
+    a.slab = (float*)workspace;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy;
+    a.KH = d->KH; a.KW = d->KW; a.pad = d->pad; a.dil = d->dil;
+    a.Ntot = d->KH * d->KW * d->Ci; a.ldo = d->ldo; a.tiles_n = a.Ntot / 256;
+    a.splits = hw2_splits(d, nseg);
+    a.M = (int)((int64_t)d->N_img * d->Ho * d->Wo);
+    a.rows_per_split = (int)(sp_cdiv(sp_cdiv(a.M, a.splits), 32) * 32);
+    a.slab_stride = (int64_t)d->Co * d->ldo;
+    a.x_bytes = (uint32_t)(4LL * d->N_img * d->Hi * d->Wi * d->Ci);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HW2_LDS);
+        attr_set = true;
+    }
+    const unsigned tiles = (unsigned)((d->Co / 256) * a.tiles_n);
+    hipLaunchKernelGGL(hw2_kernel, dim3(tiles, (unsigned)(nseg * a.splits)), dim3(512), HW2_LDS, s, a);
+    SP_LAUNCH_CHECK();
+    return launch_hw_reduce(sc, (const float*)workspace, dW, d->Co, a.Ntot, d->ldo, a.splits, a.slab_stride, d->alpha, d->beta, s);
 }
 
 extern "C" int sp_conv_wgrad_f16x1(const sp_wgrad_desc* d, const void* Xsplit, const float* x_scale, const void* dYsplit,

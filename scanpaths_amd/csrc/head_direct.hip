@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void sal_gather_bwd_kernel(const float* __rest
 // Dpre[i][b][s] = cbsum[src][cls(s)] + <W11[src][cls(s)], h[b, 5s-4 .. 5s+6, :]>.  grid (S, ceil(B/4), ceil(nsel/2)), 256 threads;
 // a block evaluates two head slots on one read of the window (AiR: good + poor head), and its site for a GROUP of up to four
 // samples: when they use the same source heads (always, except COCO's per-sample heads) the 2 x 248 KB of W11 are read once per
-// group instead of once per sample -- the kernel is bound by those L2 reads.  Per (sample, slot) the sum order is unchanged.
+// group instead of once per sample -- the kernel is bound by those L2 reads.  Per (sample, slot) the sum order is that of the round-2 kernel for INTERIOR sites only: the
+// loop runs over the in-map rectangle of taps, so at border sites a thread's partial sums cover other elements (same value to rounding).
 constexpr int DRT_GB = 4;
 __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ h, const float* __restrict__ W11,
                                                       const float* __restrict__ cbsum, const int* __restrict__ hmap, int B,

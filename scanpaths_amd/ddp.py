@@ -69,32 +69,50 @@ class GradBucketer:
 
     def reset(self):
         self.pending = list(self.members)
+        self.reported = [False] * len(self.bucket_of)      # per parameter: exact detection of a gradient produced twice
         self.next_b = len(self.ranges) - 1      # buckets are launched in strictly DESCENDING order on every rank: the sequence
         self.handles = []                       # of collectives is identical even when ranks' autograd graphs differ (COCO heads)
+        self.ready_events = []                  # (bucket, bytes, event on the compute stream at launch) when self.record
+
+    last_ready_events = []
+    record = False      # bench.py --force-bucketer: time stamp of every bucket launch on the compute stream (bucket timeline)
 
     def _launch_ready(self, force: bool = False):
         while self.next_b >= 0 and (force or self.pending[self.next_b] == 0):
             lo, hi = self.ranges[self.next_b]
+            if self.record and self.flat.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.ready_events.append((self.next_b, (hi - lo) * self.flat.element_size(), ev))
             self.handles.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
             self.next_b -= 1
 
     def mark_ready(self, i: int):
         b = self.bucket_of[i]
-        if b > self.next_b or self.pending[b] <= 0:
-            # a second backward before step() (gradient accumulation, two losses): this bucket's all-reduce is already in flight
-            # on the RCCL stream while autograd accumulates into the same memory -- the new contribution would never be reduced
-            # and the replicas would drift silently
+        if self.reported[i] or b > self.next_b:
+            # a second backward before step() (gradient accumulation, two losses): this parameter already reported -- its bucket's
+            # all-reduce may be in flight on the RCCL stream while autograd accumulates into the same memory, or (bucket not launched
+            # yet) the bucket would be launched one report early; either way the replicas would drift silently
             raise RuntimeError("GradBucketer: a parameter's gradient was produced twice before FlatAdam.step() (gradient accumulation "
                                "or two backward passes per step); the overlapped bucketed all-reduce supports ONE backward per step -- "
-                               "construct FlatAdam(bucket_mb=0) for a single un-overlapped all-reduce in step()")
+                               "construct FlatAdam(bucket_mb=0) for a single un-overlapped all-reduce in step(); after a backward whose "
+                               "step() is skipped call FlatAdam.zero_grad() (it drains and resets the buckets)")
+        self.reported[i] = True
         self.pending[b] -= 1
         self._launch_ready()
 
     def finish(self):
         self._launch_ready(force=True)
+        self.drain()
+
+    def drain(self):
+        """wait for every collective in flight and start a new round (FlatAdam.zero_grad after a backward whose step() was skipped:
+        the flat gradient buffer must not be cleared under an all-reduce, and the next backward must find fresh counters)"""
         for h in self.handles:
             h.wait()
+        events = self.ready_events
         self.reset()
+        self.last_ready_events = events
 
 
 def union_flags(flags, device, group=None):

@@ -9,12 +9,12 @@ implicit-GEMM kernels consume and the layout their weight gradients are produced
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional
 
 import torch
 from torch.autograd import Function
 
+from . import config as _config
 from . import hip
 from .hip import ConvDesc, WgradDesc, check, ptr
 
@@ -69,25 +69,33 @@ def _wgrad(X, dY, dW, *, N_img, Hi, Wi, Ci, ldx, Ho, Wo, Co, ldy, ldo, KH=1, KW=
 
 # ---- fp32-faithful GEMMs on the 16-bit matrix pipe (csrc/conv_f16x2.hip, csrc/conv_bf16x3.hip) ---------------------
 # USE_BF16X3 False -> every GEMM on the fp32 MFMA kernel (parity triage / A-B timing).
-# SPLIT_SCHEME "f16x2": 2 fp16 planes + per-tensor power-of-two scale, 3 MFMA products (default);
+# SPLIT_SCHEME "f16x2": 2 fp16 planes + power-of-two scales, 3 MFMA products (default);
 #              "bf16x3": 3 bf16 planes, 6 products (no scale pass; also used when a channel count is not a multiple of 32).
-# Environment overrides: SP_NO_SPLIT=1, SP_SPLIT_SCHEME=bf16x3|f16x2.
-FUSED_AMAX = not os.environ.get("SP_NO_AMAX_HINT")    # producers leave max|output| behind for the operand split (see _amax_hint)
-USE_BF16X3 = not os.environ.get("SP_NO_SPLIT")
-SPLIT_SCHEME = os.environ.get("SP_SPLIT_SCHEME", "f16x2")
-# "f16x1" = THROUGHPUT MODE (bench.py --precision f16x1, never the default): the f16x2 operand storage and kernels with only the
-# main product, i.e. GEMM operands rounded to one fp16 plane, fp32 accumulation.  ~2^-11 relative GEMM error: fails the parity bar.
-THROUGHPUT_MODE = SPLIT_SCHEME == "f16x1"
-if THROUGHPUT_MODE:
-    SPLIT_SCHEME = "f16x2"
-if SPLIT_SCHEME not in ("f16x2", "bf16x3"):
-    raise ValueError(f"SP_SPLIT_SCHEME must be f16x2, bf16x3 or f16x1, got {SPLIT_SCHEME!r}")
+# THROUGHPUT_MODE (config split_scheme="f16x1", bench.py --precision f16x1, never the default): the f16x2 operand storage and kernels
+# with only the main product, i.e. GEMM operands rounded to one fp16 plane, fp32 accumulation.  ~2^-11 relative GEMM error: fails the
+# parity bar.  All of these and the fusion switches below are module globals set from scanpaths_amd.config (ONE switchboard, set in
+# code; environment variables only under SP_ALLOW_ENV_TUNING=1) -- tests monkeypatch the globals directly.
+def _apply_config():
+    g = globals()
+    c = _config.settings
+    g["FUSED_AMAX"] = bool(c["fused_amax"])      # producers leave max|output| behind for the operand split (see _amax_hint)
+    g["USE_BF16X3"] = bool(c["use_split"])
+    g["THROUGHPUT_MODE"] = c["split_scheme"] == "f16x1"
+    g["SPLIT_SCHEME"] = "f16x2" if c["split_scheme"] == "f16x1" else c["split_scheme"]
+    for name, key in (("GRAD_MERGE", "grad_merge"), ("BN_SPLIT", "bn_split"), ("BN_SKIP_DX", "bn_skip_dx"), ("BN_SKIP_Z", "bn_skip_z"),
+                      ("LSTM_BWD_SPLIT", "lstm_bwd_split"), ("RANK1_DSP_SPLIT", "rank1_dsp_split"), ("RANK1_DWC_SPLIT", "rank1_dwc_split"),
+                      ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
+                      ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single")):
+        g[name] = bool(c[key])
+
+
+_apply_config()
 
 
 # how often each fused pass ran (tests assert that the benchmark's kernel path, not a fallback, is the one under test)
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
-                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0}
+                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0}
 
 
 def reset_fusion_counts():
@@ -96,11 +104,16 @@ def reset_fusion_counts():
 
 
 class SplitOperand:
-    """a GEMM operand in split form: buf (16-bit planes, interleaved per 16 k) + device scale (f16x2 only)"""
-    __slots__ = ("buf", "scale", "scheme")
+    """a GEMM operand in split form: buf (16-bit planes, interleaved per 16 k) + device scale (f16x2 only).
+    kind (f16x2): "scalar" -- one power-of-two scale for the tensor (scale = {scale, amax} words);
+                  "cols"   -- activations / gradients [rows][C] with one scale per CHANNEL (scale = [C] vector): exact for the weight
+                              gradient (K = pixels); in a forward / data-gradient GEMM the weight operand must absorb the vector;
+                  "rows"   -- weights with one scale per row = output column of the GEMM (scale = [rows] vector); `absorbed` names the
+                              channel-scale vector the rows were divided by (None: none)."""
+    __slots__ = ("buf", "scale", "scheme", "kind", "absorbed")
 
-    def __init__(self, buf, scale, scheme):
-        self.buf, self.scale, self.scheme = buf, scale, scheme
+    def __init__(self, buf, scale, scheme, kind="scalar", absorbed=None):
+        self.buf, self.scale, self.scheme, self.kind, self.absorbed = buf, scale, scheme, kind, absorbed
 
 
 def _scheme_for(kc: int) -> str:
@@ -149,6 +162,18 @@ def _amax_hint(device) -> Optional[torch.Tensor]:
     return hint
 
 
+_ONES = {}
+
+
+def _one(device) -> torch.Tensor:
+    """device scalar 1.0f: the x_scale of an operand whose (per-channel) scales were absorbed by the weight operand"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(2, dtype=torch.float32, device=device)
+    return t
+
+
 def _amax_hint_active() -> bool:
     return bool(USE_BF16X3 and SPLIT_SCHEME == "f16x2" and FUSED_AMAX)
 
@@ -172,8 +197,14 @@ def _fp32_required(x: torch.Tensor, what: str) -> None:
                            "run with SP_LSTM_SKIP_DPRE=0")
 
 
-def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
-    """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree)"""
+
+
+def split_op(x: torch.Tensor, scheme: Optional[str] = None, channel: bool = False) -> SplitOperand:
+    """fp32 [..., K] -> split operand; the scheme follows the row length unless given (both operands of a GEMM must agree).
+    channel (2xfp16 only): the operand is an activation / gradient [rows][C] of a conv -- when no producer left a max|.| hint (the
+    split needs its own pass over x anyway) it gets one power-of-two scale per CHANNEL instead of one per tensor (kind "cols"): a
+    channel far below the tensor's maximum (the terminate-logit columns of the saliency tap gradient: 2^-20 .. 2^-29 of the action
+    map's) keeps its 22 bits in the weight-gradient GEMM, whose output row / column it alone feeds."""
     scheme = scheme or _scheme_for(x.shape[-1])
     cache = getattr(x, "_sp_cache", None)        # {scheme: SplitOperand} shared by every alias of a multi-consumer tensor (fanout)
     if cache is not None and scheme in cache:
@@ -186,23 +217,76 @@ def split_op(x: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
         xc = x.contiguous()
         n = xc.numel()
         out = torch.empty(2 * n + 32, dtype=torch.float16, device=x.device)
-        scale = hint if hint is not None else _scale_slot(x.device)
-        check(hip.lib().sp_split2_f16(ptr(xc), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
-        op = SplitOperand(out, scale, scheme)
+        Cc = xc.shape[-1]
+        if channel and CHANNEL_SCALES and hint is None and xc.dim() >= 2 and Cc % 16 == 0 and not THROUGHPUT_MODE:
+            cscale = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            L = hip.lib()
+            ws = hip.workspace(L.sp_split2_f16_cols_workspace(n // Cc, Cc), x.device, slot=1)
+            check(L.sp_split2_f16_cols(ptr(xc), n // Cc, Cc, ptr(out), ptr(cscale), ptr(ws), hip.stream()), "sp_split2_f16_cols")
+            op = SplitOperand(out, cscale, scheme, "cols")
+        else:
+            scale = hint if hint is not None else _scale_slot(x.device)
+            check(hip.lib().sp_split2_f16(ptr(xc), n, ptr(out), ptr(scale), int(hint is not None), hip.stream()), "sp_split2_f16")
+            op = SplitOperand(out, scale, scheme)
     if cache is not None:                        # set by producers whose output feeds several GEMMs (the ConvLSTM state h)
         cache[scheme] = op
     return op
 
 
-def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None) -> SplitOperand:
+def _absorb_of(act: Optional[SplitOperand]) -> Optional[torch.Tensor]:
+    """the channel-scale vector a weight operand must absorb to meet `act` in a GEMM that contracts over channels"""
+    return act.scale if (act is not None and act.kind == "cols") else None
+
+
+def split_w(w2d: torch.Tensor, scheme: str, Kc: Optional[int] = None, absorb: Optional[torch.Tensor] = None) -> SplitOperand:
+    """weights [rows][K] (K = taps * Kc contiguous) as the [N][K] operand of a forward GEMM: one scale per row (2xfp16), the rows
+    divided by the activation's per-channel scales `absorb` [Kc] when it has them"""
+    if scheme == "bf16x3":
+        return SplitOperand(split3(w2d), None, scheme)
+    w2d = w2d.contiguous()
+    K = w2d.shape[-1]
+    rows = w2d.numel() // K
+    out = torch.empty(2 * w2d.numel() + 32, dtype=torch.float16, device=w2d.device)
+    rscale = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    check(hip.lib().sp_split2_f16_rows(ptr(w2d), rows, K, Kc if Kc is not None else K, ptr(absorb), ptr(out), ptr(rscale), hip.stream()),
+          "sp_split2_f16_rows")
+    return SplitOperand(out, rscale, scheme, "rows", absorb)
+
+
+def split_op_wT(wp: torch.Tensor, scheme: Optional[str] = None, absorb: Optional[torch.Tensor] = None) -> SplitOperand:
+    """physical weight [Co,KH,KW,Ci] -> the data gradient's operand: rows ci, k = (tap, co), one scale per row (2xfp16), the values
+    divided by the gradient operand's per-channel scales `absorb` [Co] when it has them"""
     Co, KH, KW, Ci = wp.shape
     scheme = scheme or _scheme_for(Co)
     if scheme == "bf16x3":
         return SplitOperand(split3_wT(wp), None, scheme)
     out = torch.empty(2 * wp.numel() + 32, dtype=torch.float16, device=wp.device)
+    if Ci % 4 == 0:
+        rscale = torch.empty(Ci, dtype=torch.float32, device=wp.device)
+        check(hip.lib().sp_split2_f16_wT_rows(ptr(wp), Co, KH * KW, Ci, ptr(absorb), ptr(out), ptr(rscale), hip.stream()),
+              "sp_split2_f16_wT_rows")
+        return SplitOperand(out, rscale, scheme, "rows", absorb)
+    assert absorb is None
     scale = _scale_slot(wp.device)
     check(hip.lib().sp_split2_f16_wT(ptr(wp), Co, KH * KW, Ci, ptr(out), ptr(scale), hip.stream()), "sp_split2_f16_wT")
     return SplitOperand(out, scale, scheme)
+
+
+def _weight_operand(wp, act: SplitOperand, wcache, transposed=False) -> SplitOperand:
+    """the split form of the physical weight wp [Co,KH,KW,Ci] that meets the activation-side operand `act` (forward: [Co][K] rows;
+    transposed: the data gradient's [Ci][K]); cached in wcache only when it absorbed no per-channel scales (those belong to ONE tensor)"""
+    absorb = _absorb_of(act)
+    key = ("wT" if transposed else "w", act.scheme)
+    if absorb is None and wcache is not None and key in wcache:
+        return wcache[key]
+    if transposed:
+        op = split_op_wT(wp, act.scheme, absorb)
+    else:
+        Co, KH, KW, Ci = wp.shape
+        op = split_w(wp.reshape(Co, KH * KW * Ci), act.scheme, Ci, absorb)
+    if absorb is None and wcache is not None:
+        wcache[key] = op
+    return op
 
 
 # Parity tests run the benchmark's kernel path at a small batch: the cost models below then price every GEMM as if its pixel
@@ -234,14 +318,23 @@ def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, l
     d = ConvDesc(N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, KH, KW, stride, pad, dil, mode, ldw, float(alpha), int(beta),
                  int(relu), 1, 0, 0, 0, 0, None)
     f16 = Xs.scheme == "f16x2"
+    xscale = Xs.scale
+    if f16:
+        d.w_scale_rows = int(Ws.kind == "rows")
+        if Xs.kind == "cols":      # the per-channel scales of the activation operand live in the weight operand
+            if Ws.absorbed is not Xs.scale:
+                raise RuntimeError("scanpaths_amd: a per-channel-scaled operand met a weight operand that did not absorb its scales")
+            xscale = _one(out.device)
+        elif Ws.absorbed is not None:
+            raise RuntimeError("scanpaths_amd: a weight operand that absorbed per-channel scales met another activation operand")
 
     def launch():
         if stats is not None:          # (partial, mm): BatchNorm statistics of the output from the epilogue
-            check(hip.lib().sp_conv_igemm_f16x2_stats(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(Ws.buf), ptr(Ws.scale), ptr(out),
+            check(hip.lib().sp_conv_igemm_f16x2_stats(C.byref(d), ptr(Xs.buf), ptr(xscale), ptr(Ws.buf), ptr(Ws.scale), ptr(out),
                                                       ptr(stats[0]), ptr(stats[1]), hip.stream()), "sp_conv_igemm_f16x2_stats")
         elif f16:
             fn = hip.lib().sp_conv_igemm_f16x1 if THROUGHPUT_MODE else hip.lib().sp_conv_igemm_f16x2
-            check(fn(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(Ws.buf), ptr(Ws.scale), ptr(bias), ptr(out), hip.stream()),
+            check(fn(C.byref(d), ptr(Xs.buf), ptr(xscale), ptr(Ws.buf), ptr(Ws.scale), ptr(bias), ptr(out), hip.stream()),
                   "sp_conv_igemm_f16x2")
         else:
             check(hip.lib().sp_conv_igemm_bf16x3(C.byref(d), ptr(Xs.buf), ptr(Ws.buf), ptr(bias), ptr(out), hip.stream()),
@@ -280,11 +373,21 @@ def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, st
     d = WgradDesc(N_img, Hi, Wi, Ci, Ci, Ho, Wo, Co, Co, KH, KW, stride, pad, dil, ldo, int(beta), float(alpha), 1, 0, 0, 0)
     L = hip.lib()
     f16 = Xs.scheme == "f16x2"
-    ws = hip.workspace((L.sp_conv_wgrad_f16x2_workspace if f16 else L.sp_conv_wgrad_bf16x3_workspace)(C.byref(d)), dW.device,
-                       slot=ws_slot)
+    if f16:      # K = pixels: per-channel scales of either operand factor out in the epilogue / slab reduce
+        d.x_scale_vec, d.y_scale_vec = int(Xs.kind == "cols"), int(dYs.kind == "cols")
+    M = N_img * Ho * Wo
+    # large single weight gradients whose shape fits the 256 x 256-tile kernel (x-gate conv, sal_conv): hw2_kernel with one segment
+    big = L.sp_conv_wgrad_f16x2_multi_workspace(C.byref(d), 1) if (f16 and HW2_SINGLE and not THROUGHPUT_MODE
+                                                                   and 2.0 * M * Co * KH * KW * Ci >= 1e12) else 0
+    ws = hip.workspace(big if big > 0 else (L.sp_conv_wgrad_f16x2_workspace if f16 else L.sp_conv_wgrad_bf16x3_workspace)(C.byref(d)),
+                       dW.device, slot=ws_slot)
 
     def launch():
-        if f16:
+        if big > 0:
+            one = lambda t: (C.c_void_p * 1)(t.data_ptr())
+            check(L.sp_conv_wgrad_f16x2_multi(C.byref(d), 1, one(Xs.buf), one(Xs.scale), one(dYs.buf), one(dYs.scale), ptr(dW), ptr(ws),
+                                              hip.stream()), "sp_conv_wgrad_f16x2_multi")
+        elif f16:
             fn = L.sp_conv_wgrad_f16x1 if THROUGHPUT_MODE else L.sp_conv_wgrad_f16x2
             check(fn(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(dYs.buf), ptr(dYs.scale), ptr(dW), ptr(ws), hip.stream()),
                   "sp_conv_wgrad_f16x2")
@@ -293,8 +396,7 @@ def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, st
                   "sp_conv_wgrad_bf16x3")
     if hip.TIMER is None:
         return launch()
-    M = N_img * Ho * Wo
-    hip.TIMER.bracket(((("h1" if THROUGHPUT_MODE else "h2") if f16 else "b3") + "_wgrad", M, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * M * Co * KH * KW * Ci, launch)
+    hip.TIMER.bracket(((("h1" if THROUGHPUT_MODE else "h2") if f16 else "b3") + ("_wgrad_multi" if big > 0 else "_wgrad"), M, Co, KH * KW * Ci, f"{KH}x{KW}", 1), 2.0 * M * Co * KH * KW * Ci, launch)
 
 
 def colsum(x2d: torch.Tensor, C_: int, ld: int, M: int) -> torch.Tensor:
@@ -355,64 +457,79 @@ def touch_zero_grad(t, params):
 
 class _FanOut(Function):
     """x -> n aliases of x for n consumers; backward adds the n gradients in ONE pass (sp_sum_n) instead of the n-1
-    read-read-write adds autograd would issue.  Used for the hoisted x-gate pre-activations (one consumer per decode step)."""
+    read-read-write adds autograd would issue.  Used for the hoisted x-gate pre-activations (one consumer per decode step).
+    token: dict shared with the aliases (alias i carries ``_sp_fan = (token, i)``).  A consumer whose backward leaves the fp32 form of
+    its gradient UNWRITTEN (the cell backward, _lstm_rank1_backward) records the split operand it wrote instead under its alias index;
+    this backward then reads that contribution from the token BY OUTPUT INDEX -- never from an attribute of the incoming tensor, whose
+    identity autograd does not guarantee (a hook that returns a new tensor, an accumulation, a cloning wrapper: ADVICE r3) -- and
+    raises if a recorded contribution's gradient never arrived or arrives marked as unwritten without a record."""
     @staticmethod
-    def forward(ctx, x, n):
-        ctx.n = n
+    def forward(ctx, x, n, token):
+        ctx.n, ctx.token = n, token
         ctx.set_materialize_grads(False)      # an alias nobody consumed contributes None, not a full-size zero tensor to sum
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
-        gs = [g.contiguous() for g in grads if g is not None]
-        if not gs:
-            return None, None
-        skipped = [getattr(g, "_sp_skipped", False) for g in gs]       # contributions that exist only as split operands (cell backward)
-        if any(skipped):
+        tok = ctx.token if ctx.token is not None else {}
+        for i in tok:
+            if grads[i] is None:
+                raise RuntimeError(f"scanpaths_amd: fan-out alias {i} recorded a split-only gradient but no gradient arrived for it")
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        if not idx:
+            return None, None, None
+        for i in idx:
+            if i not in tok and getattr(grads[i], "_sp_skipped", False):
+                raise RuntimeError("scanpaths_amd: a gradient whose fp32 form was left unwritten reached a fan-in without its record")
+        gs = [grads[i].contiguous() for i in idx]
+        ops = [tok.get(i) for i in idx]            # contributions that exist only as split operands (cell backward)
+        tok.clear()                                # (a second backward through a retained graph records again)
+        if any(op is not None for op in ops):
             out = torch.empty_like(gs[0])
             n = out.numel()
             assert n % 16 == 0 and len(gs) <= 32, (n, len(gs))
-            ops = [g._sp_cache["f16x2"] if sk else None for g, sk in zip(gs, skipped)]
-            f = (C.c_void_p * len(gs))(*[None if sk else g.data_ptr() for g, sk in zip(gs, skipped)])
+            f = (C.c_void_p * len(gs))(*[None if op is not None else g.data_ptr() for g, op in zip(gs, ops)])
             pl = (C.c_void_p * len(gs))(*[op.buf.data_ptr() if op is not None else None for op in ops])
             sc = (C.c_void_p * len(gs))(*[op.scale.data_ptr() if op is not None else None for op in ops])
             hint = _amax_hint(out.device)
             check(hip.lib().sp_sum_n_mixed(f, pl, sc, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n_mixed")
             if hint is not None:
                 out._sp_amax = hint
-            return out, None
+            return out, None, None
         if len(gs) == 1:
-            return gs[0], None
+            return gs[0], None, None
         out = torch.empty_like(gs[0])
         n = out.numel()
         if n % 4 or len(gs) > 32:
             acc = gs[0]
             for g in gs[1:]:
                 acc = _add_raw(acc, g)
-            return acc, None
+            return acc, None, None
         arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
         hint = _amax_hint(out.device)          # max|sum|: the LSTM cell's backward bounds its split operand with it
         check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n")
         if hint is not None:
             out._sp_amax = hint
-        return out, None
+        return out, None, None
 
 
 def fanout(x: torch.Tensor, n: int):
     """n aliases of x whose gradients are summed in ONE pass; the operand-split cache and the fused-amax hint travel with them"""
-    outs = _FanOut.apply(x, n)
+    split_ok = x.numel() % 16 == 0 and n <= 32
+    token = {} if split_ok else None
+    outs = _FanOut.apply(x, n, token)
     for attr in ("_sp_cache", "_sp_amax"):
         v = getattr(x, attr, None)
         if v is not None:
             for o in outs:
                 setattr(o, attr, v)
-    if x.numel() % 16 == 0 and n <= 32:
-        for o in outs:
-            o._sp_split_grad_ok = True      # a consumer may hand back its gradient as a split operand only (see _FanOut.backward)
+    if split_ok:
+        for i, o in enumerate(outs):
+            o._sp_fan = (token, i)          # a consumer may hand back its gradient as a split operand only (see _FanOut)
+            o._sp_split_grad_ok = True
     return outs
 
 
-GRAD_MERGE = os.environ.get("SP_GRAD_MERGE", "1") != "0"
 
 
 class GradMerge:
@@ -516,12 +633,8 @@ class _Conv2d(Function):
             raise RuntimeError("scanpaths_amd: a BatchNorm left this input's fp32 form unwritten (skip_z) but this conv does not run "
                                "from the split operand alone; run with SP_BN_SKIP_DX=0")
         if _b3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, a_elems=x.numel(), free_a=shared):
-            xs = split_op(x)
-            wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
-            if wsplit is None:
-                wsplit = split_op(wp, xs.scheme)
-                if wcache is not None:
-                    wcache[("w", xs.scheme)] = wsplit
+            xs = split_op(x, channel=True)
+            wsplit = _weight_operand(wp, xs, wcache)
             stats = None
             if bn_stats and BN_SPLIT and xs.scheme == "f16x2" and not THROUGHPUT_MODE and bias is None and not relu:
                 # bn_stats: a train-mode BatchNorm follows -- the epilogue writes the first stage of its batch statistics
@@ -553,7 +666,7 @@ class _Conv2d(Function):
         else:
             _igemm(x, wp, bias, y, N_img=N, Hi=H, Wi=W_, Kc=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Nout=Co, ldc=Co, ldw=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=0, relu=relu)
-        ctx.xs_scheme = xs.scheme if xs is not None else None
+        ctx.xs_scheme = (xs.scheme, xs.kind) if xs is not None else None
         xs_buf, xs_scale = (xs.buf, xs.scale) if xs is not None else (None, None)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
         ctx.wcache = wcache
@@ -564,7 +677,7 @@ class _Conv2d(Function):
     def backward(ctx, dy):
         stride, pad, dil, relu, has_bias = ctx.cfg
         x, wp, y, xs_buf, xs_scale = ctx.saved_tensors
-        xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
+        xs = SplitOperand(xs_buf, xs_scale, *ctx.xs_scheme) if xs_buf is not None else None
         if ctx.dy_token is not None and ctx.dy_token["skipped"] and getattr(dy, "_sp_cache", None) is None:
             raise RuntimeError("scanpaths_amd: a BatchNorm left this gradient's fp32 form unwritten (skip_dx) but its split form "
                                "did not arrive with it; run with SP_BN_SKIP_DX=0")
@@ -581,48 +694,59 @@ class _Conv2d(Function):
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-# MEASURED (round 2, same box, bs 32, 320x512, T = 16): 317.6 / 319.5 ms per step with the side stream, 317.5 / 316.5 without -- the
-# weight-gradient GEMM (3.9 -> 6.9 ms per launch) and the main stream's kernels (data gradient 3.0 -> 3.9 ms) merely share the CUs:
-# a GEMM workgroup owns its CU's whole LDS and register file, so an HBM-bound kernel of the other stream cannot run BESIDE it, only
-# INSTEAD of it.  Off by default (SP_SIDE_WGRAD=1 enables it); results are bit-identical either way.
-SIDE_WGRAD = os.environ.get("SP_SIDE_WGRAD", "0") == "1"
 
 
 class DeferredWgrad:
-    """Weight gradient of a conv that is applied T times with the same weight (the h-gate conv): nobody needs the T contributions
-    before the end of backward, so each one runs on a SIDE stream, accumulating into one buffer (epilogue beta = 1), while the main
-    stream goes on with the recurrence (data gradient, cell backward, heads, fan-ins -- the HBM- and latency-bound part of a decode
-    step, during which the matrix pipes would otherwise idle).  The application that runs LAST in backward (the first one of the
-    forward pass claims that role) waits for the side stream and hands the sum to autograd; the others return no gradient."""
-    __slots__ = ("acc", "claimed")
+    """Weight gradient of a conv that is applied T times with the same weight (the h-gate conv of the ConvLSTM): nobody needs the T
+    contributions before the end of backpropagation through time, and the split operands of every application (h_{t-1}: kept by the
+    forward pass; the gate gradient of step t: written by the cell backward) stay alive until then anyway.  Each application's
+    backward only RECORDS its operand pair; the application whose backward runs LAST (the first one of the forward pass claims that
+    role) issues ONE launch over all of them (sp_conv_wgrad_f16x2_multi: hw2_kernel, 256 x 256 tiles; the per-step launches ran 4.5
+    rounds of 256 workgroups each and wrote / re-read 8 slabs per step) and hands the sum to autograd; the others return no gradient.
+    (Round 2's side-stream variant of this class measured neutral -- DESIGN.md 5f -- and is gone.)"""
+    __slots__ = ("items", "claimed")
 
     def __init__(self):
-        self.acc, self.claimed = None, False
+        self.items, self.claimed = [], False
 
     def claim(self) -> bool:
         first, self.claimed = not self.claimed, True
         return first
 
 
-def _deferred_wgrad(defer, final, Xs, dYs, wp, geom):
-    dev = wp.device
-    side, main = hip.side_stream(dev), torch.cuda.current_stream()
-    side.wait_stream(main)                       # the split operands were produced on the main stream
-    with torch.cuda.stream(side):
-        beta = 1
-        if defer.acc is None:
-            defer.acc, beta = torch.empty_like(wp), 0
-        _wgrad_b3(Xs, dYs, defer.acc, beta=beta, ws_slot=3, **geom)
-    for op in (Xs, dYs):                         # keep the operands' memory from being reused before the side kernel has read it
-        op.buf.record_stream(side)
-        if op.scale is not None:
-            op.scale.record_stream(side)
-    if not final:
-        return None
-    main.wait_stream(side)
-    acc, defer.acc, defer.claimed = defer.acc, None, False
-    acc.record_stream(main)                      # allocated on the side stream, consumed on the main one
-    return acc.permute(0, 3, 1, 2)
+def _flush_deferred(defer, wp, geom):
+    """dW of all recorded applications: one multi-application launch where the kernel's shape constraints hold, else one launch per
+    application accumulating in place"""
+    items, defer.items, defer.claimed = defer.items, [], False
+    Co, KH, KW, Ci = wp.shape
+    dwp = torch.empty_like(wp)
+    L = hip.lib()
+    xs0, dys0 = items[0]
+    same = all(x.kind == xs0.kind and y.kind == dys0.kind for x, y in items)
+    d = WgradDesc(geom["N_img"], geom["Hi"], geom["Wi"], Ci, Ci, geom["Ho"], geom["Wo"], Co, geom.get("ldy", Co), KH, KW, geom["stride"],
+                  geom["pad"], geom["dil"], KH * KW * Ci, 0, 1.0, 1, 0, 0, 0)
+    d.x_scale_vec, d.y_scale_vec = int(xs0.kind == "cols"), int(dys0.kind == "cols")
+    nseg = len(items)
+    wsb = L.sp_conv_wgrad_f16x2_multi_workspace(C.byref(d), nseg) if (same and not THROUGHPUT_MODE and 1 < nseg <= 16) else 0
+    if wsb > 0:
+        ws = hip.workspace(wsb, wp.device, slot=3)
+        arr = lambda ts: (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
+        Xa, Sxa = arr([x.buf for x, _ in items]), arr([x.scale for x, _ in items])
+        Ya, Sya = arr([y.buf for _, y in items]), arr([y.scale for _, y in items])
+
+        def launch():
+            check(L.sp_conv_wgrad_f16x2_multi(C.byref(d), nseg, Xa, Sxa, Ya, Sya, ptr(dwp), ptr(ws), hip.stream()), "sp_conv_wgrad_f16x2_multi")
+        FUSION_COUNTS["wgrad_multi"] += 1
+        if hip.TIMER is None:
+            launch()
+        else:
+            M = geom["N_img"] * geom["Ho"] * geom["Wo"]
+            hip.TIMER.bracket(("h2_wgrad_multi", M * nseg, Co, KH * KW * Ci, f"{KH}x{KW}", nseg), 2.0 * M * nseg * Co * KH * KW * Ci, launch)
+    else:
+        g2 = {k: v for k, v in geom.items() if k != "ldy"}
+        for k, (x, y) in enumerate(items):
+            _wgrad_b3(x, y, dwp, beta=int(k > 0), ldo=KH * KW * Ci, Ci=Ci, Co=Co, KH=KH, KW=KW, **g2)
+    return dwp.permute(0, 3, 1, 2)
 
 
 def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None, defer_final=False):
@@ -634,19 +758,16 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
     dx = dw = None
     dys = None
     dy_cached = getattr(dy, "_sp_cache", None)       # the producer of dy (a BatchNorm / cell backward) already wrote its split form
-    defer = wcache.get("defer") if (SIDE_WGRAD and isinstance(wcache, dict)) else None
+    defer = wcache.get("defer") if (DEFER_WGRAD and isinstance(wcache, dict)) else None
+    geom = dict(N_img=N, Hi=H, Wi=W_, Ho=Ho, Wo=Wo, stride=stride, pad=pad, dil=dil)
+    deferred = False
     if need_dw and defer is not None:
         wsch = _wgrad_scheme(Ci, Co)
-        if xs is not None and xs.scheme == wsch and \
+        if wsch == "f16x2" and xs is not None and xs.scheme == wsch and \
                 _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=dy_cached is not None and wsch in dy_cached):
-            # launched BEFORE the data gradient: the side stream then only waits for the operands, not for that GEMM
-            dys = dy_cached[wsch] if (dy_cached is not None and wsch in dy_cached) else split_op(dy, wsch)
-            dw = _deferred_wgrad(defer, defer_final, xs, dys, wp,
-                                 dict(N_img=N, Hi=H, Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride,
-                                      pad=pad, dil=dil))
-            need_dw = False
-        elif defer_final and defer.acc is not None:          # (this application fell back to the plain path: still hand over the sum)
-            need_dw = "plus_deferred"
+            dys = dy_cached[wsch] if (dy_cached is not None and wsch in dy_cached) else split_op(dy, wsch, channel=True)
+            defer.items.append((xs, dys))
+            deferred = True
     if need_dx:
         beta = 0
         if accum is not None and accum.first is not None and accum.first.shape == x.shape and accum.first.is_contiguous():
@@ -656,37 +777,34 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
             dx = torch.empty_like(x)
         if _b3_pays(N * H * W_, Ci, KH * KW * Co, Co, a_elems=dy.numel(), free_a=dy_cached is not None or dys is not None):
             if dys is None or dys.scheme != _scheme_for(Co):
-                dys = split_op(dy)
-            wT = wcache.get(("wT", dys.scheme)) if wcache is not None else None
-            if wT is None:
-                wT = split_op_wT(wp, dys.scheme)
-                if wcache is not None:
-                    wcache[("wT", dys.scheme)] = wT
+                dys = split_op(dy, channel=True)
+            wT = _weight_operand(wp, dys, wcache, transposed=True)
             _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
                       ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
         else:
             _fp32_required(dy, "the fp32 data-gradient GEMM")
             _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
                    KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
-    if need_dw:
+    if need_dw and not deferred:
         dwp = torch.empty_like(wp)
         wsch = _wgrad_scheme(Ci, Co)
         if dys is None and dy_cached is not None and wsch in dy_cached:
             dys = dy_cached[wsch]
         free = xs is not None and (dys is not None and dys.scheme == wsch)
         if _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=free):
-            _wgrad_b3(xs if xs is not None else split_op(x, wsch),
-                      dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch), dwp, N_img=N, Hi=H,
+            _wgrad_b3(xs if xs is not None else split_op(x, wsch, channel=True),
+                      dys if dys is not None and dys.scheme == wsch else split_op(dy, wsch, channel=True), dwp, N_img=N, Hi=H,
                       Wi=W_, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, ldo=KH * KW * Ci, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
         else:
             _fp32_required(dy, "the fp32 weight-gradient GEMM")
             _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
         dw = dwp.permute(0, 3, 1, 2)
-        if need_dw == "plus_deferred":
-            torch.cuda.current_stream().wait_stream(hip.side_stream(wp.device))
-            dw = dw + defer.acc.permute(0, 3, 1, 2)
-            defer.acc, defer.claimed = None, False
+    if need_dw and defer is not None and defer_final and defer.items:
+        # this application runs last in backward: the recorded applications (its own among them, unless it took the plain path) in
+        # one launch
+        dsum = _flush_deferred(defer, wp, geom)
+        dw = dsum if dw is None else dw + dsum
     return dx, dw
 
 
@@ -891,7 +1009,6 @@ class _BnAct(Function):
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
-BN_SPLIT = os.environ.get("SP_BN_SPLIT", "1") != "0"
 
 
 class _BnActSplit(Function):
@@ -976,8 +1093,6 @@ class _BnActSplit(Function):
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
 
 
-BN_SKIP_DX = os.environ.get("SP_BN_SKIP_DX", "1") != "0"
-BN_SKIP_Z = os.environ.get("SP_BN_SKIP_Z", "1") != "0"
 
 
 def bn_act(x, gamma, beta, rmean, rvar, residual=None, training=True, momentum=0.1, eps=1e-5, relu=True, emit_split=False,
@@ -1052,7 +1167,7 @@ class _GateConv(Function):
             hg = torch.empty((B, Hm, Wm, C4), dtype=torch.float32, device=spcol.device)
             if _b3_pays(B * Hm * Wm, C4, 9 * Cc, Cc):
                 hs_ = split_op(h)
-                _igemm_b3(hs_, split_op(wp, hs_.scheme), None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4,
+                _igemm_b3(hs_, _weight_operand(wp, hs_, None), None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4,
                           ldc=C4, ldw=9 * Cc, KH=3, KW=3, pad=1, mode=0)
             else:
                 _igemm(h, wp, None, hg, N_img=B, Hi=Hm, Wi=Wm, Kc=Cc, ldx=Cc, Ho=Hm, Wo=Wm, Nout=C4, ldc=C4, ldw=9 * Cc,
@@ -1080,7 +1195,7 @@ class _GateConv(Function):
                 dh = torch.empty_like(h)
                 if _b3_pays(B * Hm * Wm, Cc, 9 * C4, C4):
                     dys = split_op(dhg)
-                    _igemm_b3(dys, split_op_wT(wp, dys.scheme), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
+                    _igemm_b3(dys, _weight_operand(wp, dys, None, transposed=True), None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm,
                               Nout=Cc, ldc=Cc, ldw=9 * C4, KH=3, KW=3, pad=1, mode=1)
                 else:
                     _igemm(dhg, wp, None, dh, N_img=B, Hi=Hm, Wi=Wm, Kc=C4, ldx=C4, Ho=Hm, Wo=Wm, Nout=Cc, ldc=Cc, ldw=Cc,
@@ -1177,7 +1292,8 @@ class _LstmCellRank1(Function):
             h._sp_amax = hint
         h._sp_cache = {}                  # h feeds the saliency tap GEMM of this step and the h-gate conv of the next: split once
         ctx.has = (hg is not None, c_prev is not None)
-        ctx.skip_ok = hg is None and getattr(xg, "_sp_split_grad_ok", False)      # dpre's only consumer (xg's fan-in) takes a split operand
+        ctx.fan = getattr(xg, "_sp_fan", None)
+        ctx.skip_ok = hg is None and ctx.fan is not None      # dpre's only consumer (xg's fan-in) takes a split operand
         ctx.set_materialize_grads(False)          # the last step's dc stays None instead of a zero tensor the kernel would read
         ctx.cbounds = _cell_bounds(c_prev, c)
         ctx.save_for_backward(gates, c_prev, c, spcol, wc)
@@ -1187,7 +1303,7 @@ class _LstmCellRank1(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[3],
-                                                   ctx.needs_input_grad[4], ctx.cbounds, skip_fp32=ctx.skip_ok)
+                                                   ctx.needs_input_grad[4], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan)
         has_hg, has_c = ctx.has
         return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
 
@@ -1201,13 +1317,9 @@ def _cell_bounds(c_prev, c):
     return cb, cbp
 
 
-LSTM_BWD_SPLIT = os.environ.get("SP_LSTM_BWD_SPLIT", "1") != "0"
-RANK1_DSP_SPLIT = os.environ.get("SP_RANK1_DSP_SPLIT", "1") != "0"
-RANK1_DWC_SPLIT = os.environ.get("SP_RANK1_DWC_SPLIT", "1") != "0"
-LSTM_SKIP_DPRE = os.environ.get("SP_LSTM_SKIP_DPRE", "1") != "0"
 
 
-def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None), skip_fp32=False):
+def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None), skip_fp32=False, fan=None):
     """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint or -- when bounds of max|dh|, max|dc| and
     max|c| are known -- its 2xfp16 split operand, written by the same pass), c_prev, spcol and wc"""
     dh_h = getattr(dh, "_sp_amax", None) if dh is not None else None
@@ -1230,17 +1342,19 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
         planes = torch.empty(2 * dpre.numel() + 32, dtype=torch.float16, device=dpre.device)
         # skip_fp32 (the caller's other consumers of dpre read its split form): when the two rank-1 gradients do too, the fp32
         # tensor is allocated (autograd wants one) but never written -- 671 MB per step at the benchmark size
-        skip = (skip_fp32 and LSTM_SKIP_DPRE and (not need_dsp or (RANK1_DSP_SPLIT and rank1_split_ok))
+        skip = (skip_fp32 and fan is not None and LSTM_SKIP_DPRE and (not need_dsp or (RANK1_DSP_SPLIT and rank1_split_ok))
                 and (not need_dwc or (RANK1_DWC_SPLIT and rank1_split_ok)))
         if skip:
             FUSION_COUNTS["lstm_skip_dpre"] += 1
-            dpre._sp_skipped = True
+            dpre._sp_skipped = True          # guards every fp32 reader this process owns (_fp32_required); the fan-in reads the record
         check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, None if skip else ptr(dpre), ptr(dcp),
                                                     None, _hint_ptr(chint), _hint_ptr(dh_h), _hint_ptr(dc_h), float(cbounds[0]),
                                                     float(cbounds[1]), ptr(planes), ptr(hint), hip.stream()),
               "sp_lstm_pointwise_bwd_split")
         dpre._sp_amax = hint
         dpre._sp_cache = {"f16x2": SplitOperand(planes, hint, "f16x2")}
+        if skip:
+            fan[0][fan[1]] = dpre._sp_cache["f16x2"]      # xg's fan-in takes this contribution from the record, by alias index
     else:
         check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, ptr(dpre), ptr(dcp),
                                                     _hint_ptr(hint), _hint_ptr(chint), None, None, 0.0, 0.0, None, None,
@@ -1258,8 +1372,9 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
             # batched GEMM it replaces read the fp32 dpre (0.5 GB) at ~2 TB/s
             FUSION_COUNTS["rank1_dsp_split"] += 1
             xs = dpre._sp_cache["f16x2"]
-            ws = split_op(wc.transpose(1, 2).contiguous(), "f16x2")                   # [B][KP][3C]: K contiguous
+            ws = split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")   # [B][KP][3C]: K contiguous, one scale per row
             d = ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
+            d.w_scale_rows = 1
             check(hip.lib().sp_conv_igemm_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(ws.buf), ptr(ws.scale), None, ptr(dsp),
                                                 hip.stream()), "sp_conv_igemm_f16x2 (batched)")
         else:
@@ -1291,8 +1406,6 @@ def lstm_cell_rank1(xg, hg, c_prev, spcol, wc):
     return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc)
 
 
-FUSE_GATE_LSTM = os.environ.get("SP_FUSE_LSTM", "1") != "0"
-LSTM_H_PLANES = os.environ.get("SP_LSTM_H_PLANES", "1") != "0"
 
 
 def gateconv_lstm_fusable(h, w_h, spcol) -> bool:
@@ -1321,16 +1434,15 @@ class _GateConvLstm(Function):
         Co, KH, KW, _ = wp.shape
         assert xg.numel() == B * P * Co and wc.shape == (B, 3 * Ci, KP) and N == B, (xg.shape, spcol.shape, wc.shape)
         xs = split_op(h_prev)
-        wsplit = wcache.get(("w", xs.scheme)) if wcache is not None else None
-        if wsplit is None:
-            wsplit = split_op(wp, xs.scheme)
-            if wcache is not None:
-                wcache[("w", xs.scheme)] = wsplit
+        wsplit = _weight_operand(wp, xs, wcache)
+        if xs.kind != "scalar":
+            raise RuntimeError("scanpaths_amd: the fused gate conv expects the hidden state's operand with a per-tensor scale")
         gates = torch.empty_like(xg)
         c = torch.empty_like(c_prev)
         h = torch.empty_like(c_prev)
         hint = _amax_hint(xg.device)
         d = ConvDesc(N, H, W_, Ci, Ci, H, W_, Co, Co, KH, KW, 1, 1, 1, 0, KH * KW * Ci, 1.0, 0, 0, 1, 0, 0, 0, 0, None)
+        d.w_scale_rows = int(wsplit.kind == "rows")
         cbounds = _cell_bounds(c_prev, c)
         # |h| = |o * c| <= |c| <= t + 1: with that bound the epilogue writes h's split operand itself (no max|h| pass, no split pass)
         hplanes = torch.empty(2 * h.numel() + 32, dtype=torch.float16, device=h.device) \
@@ -1358,11 +1470,12 @@ class _GateConvLstm(Function):
         ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
         keep = ctx.needs_input_grad[1] and _w3_pays(N * P, Co, KH * KW * Ci, Ci, free_splits=True) \
             and xs.scheme == _wgrad_scheme(Ci, Co)
-        ctx.xs_scheme = xs.scheme if keep else None
+        ctx.xs_scheme = (xs.scheme, xs.kind) if keep else None
         ctx.wcache = wcache
         # the gate gradient dpre of this step has three consumers: xg's fan-in, the h-gate conv's data and weight gradient.  When all
         # of them read its split form, its fp32 form is never written (_lstm_rank1_backward skip_fp32)
-        ctx.skip_ok = (getattr(xg, "_sp_split_grad_ok", False) and _scheme_for(Co) == "f16x2"
+        ctx.fan = getattr(xg, "_sp_fan", None)
+        ctx.skip_ok = (ctx.fan is not None and _scheme_for(Co) == "f16x2"
                        and (not ctx.needs_input_grad[0] or _b3_pays(N * P, Ci, KH * KW * Co, Co, a_elems=xg.numel(), free_a=True))
                        and (not ctx.needs_input_grad[1] or (keep and _wgrad_scheme(Ci, Co) == "f16x2")))
         ctx.save_for_backward(gates, c_prev, c, spcol, wc, h_prev, wp, xs.buf if keep else None, xs.scale if keep else None)
@@ -1372,8 +1485,8 @@ class _GateConvLstm(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc, h_prev, wp, xs_buf, xs_scale = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
-                                                   ctx.needs_input_grad[5], ctx.cbounds, skip_fp32=ctx.skip_ok)
-        xs = SplitOperand(xs_buf, xs_scale, ctx.xs_scheme) if xs_buf is not None else None
+                                                   ctx.needs_input_grad[5], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan)
+        xs = SplitOperand(xs_buf, xs_scale, *ctx.xs_scheme) if xs_buf is not None else None
         dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                  defer_final=ctx.defer_final)
         return dhp, dw, dpre, dcp, dsp, dwc, None

@@ -11,11 +11,22 @@ from typing import Optional
 
 import torch
 
+from . import config as _config
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SP_LIBRARY=timing (tools/ only): the A/B build with schedule variants and wrong-result timing modes compiled in
-# (make -C scanpaths_amd/csrc timing).  The product path always loads libscanpaths_amd.so.
-TIMING_LIB = os.environ.get("SP_LIBRARY", "") == "timing"
-LIB_PATH = os.path.join(_HERE, "libscanpaths_amd_timing.so" if TIMING_LIB else "libscanpaths_amd.so")
+# config library="timing" (tools/ only; SP_LIBRARY=timing under SP_ALLOW_ENV_TUNING=1): the A/B build with wrong-result timing modes
+# compiled in (make -C scanpaths_amd/csrc timing).  The product path always loads libscanpaths_amd.so.
+TIMING_LIB = False
+LIB_PATH = ""
+
+
+def _apply_config():
+    global TIMING_LIB, LIB_PATH
+    TIMING_LIB = _config.settings["library"] == "timing"
+    LIB_PATH = os.path.join(_HERE, "libscanpaths_amd_timing.so" if TIMING_LIB else "libscanpaths_amd.so")
+
+
+_apply_config()
 
 
 class ConvDesc(C.Structure):
@@ -26,7 +37,7 @@ class ConvDesc(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_int), ("relu", C.c_int),
                 ("nbatch", C.c_int),
                 ("strideX", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
-                ("ksplit", C.c_int), ("workspace", C.c_void_p)]
+                ("ksplit", C.c_int), ("workspace", C.c_void_p), ("w_scale_rows", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -34,7 +45,8 @@ class WgradDesc(C.Structure):
                 ("Ho", C.c_int), ("Wo", C.c_int), ("Co", C.c_int), ("ldy", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
                 ("ldo", C.c_int), ("beta", C.c_int), ("alpha", C.c_float), ("nbatch", C.c_int),
-                ("strideX", C.c_int64), ("strideY", C.c_int64), ("strideO", C.c_int64)]
+                ("strideX", C.c_int64), ("strideY", C.c_int64), ("strideO", C.c_int64),
+                ("x_scale_vec", C.c_int), ("y_scale_vec", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -49,6 +61,12 @@ SIGNATURES = {
     "sp_split3_bf16_wT": (_I, [_P, _I, _I, _I, _P, _P]),
     "sp_split2_f16": (_I, [_P, _L, _P, _P, _I, _P]),
     "sp_split2_f16_wT": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "sp_split2_f16_rows": (_I, [_P, _L, _L, _I, _P, _P, _P, _P]),
+    "sp_split2_f16_wT_rows": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "sp_split2_f16_cols_workspace": (_L, [_L, _I]),
+    "sp_split2_f16_cols": (_I, [_P, _L, _I, _P, _P, _P, _P]),
+    "sp_conv_wgrad_f16x2_multi_workspace": (_L, [_P, _I]),
+    "sp_conv_wgrad_f16x2_multi": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_igemm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x2_workspace": (_L, [_P]),
     "sp_conv_wgrad_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
@@ -160,13 +178,12 @@ def lib() -> C.CDLL:
             raise RuntimeError("libscanpaths_amd.so ABI version mismatch")
         # every max|.| slot this host passes comes zeroed from functional._amax_hint's pool and is used once: the launchers add
         # their reset node only while a stream is being captured (graph replays re-use the slot)
-        if not os.environ.get("SP_ALWAYS_RESET_AMAX"):
+        if not _config.settings["always_reset_amax"]:
             check(_lib.sp_set_tuning(b"amax_reset", 1), "sp_set_tuning")
         if _lib.sp_timing_build() != int(TIMING_LIB):
             raise RuntimeError(f"{LIB_PATH}: timing / product build mix-up")
-        if TIMING_LIB:      # A/B timing / profiling knobs, honoured by the timing build only
-            for env, knob in (("SP_H2_DBG", b"h2_dbg"), ("SP_HW_DBG", b"hw_dbg"), ("SP_B3_DBG", b"b3_dbg"),
-                              ("SP_HW_SPLITS", b"hw_splits"), ("SP_H2_HALO", b"h2_halo")):
+        if TIMING_LIB and _config.env_tuning_allowed():      # A/B timing / profiling knobs, honoured by the timing build only
+            for env, knob in _config.TIMING_KNOBS.items():
                 if os.environ.get(env):
                     check(_lib.sp_set_tuning(knob, int(os.environ[env])), "sp_set_tuning")
     return _lib

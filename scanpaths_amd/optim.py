@@ -43,7 +43,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  clip: float = 0.0, process_group=None, conditional_params: bool = False, bucket_mb: float = 32.0,
-                 reference_zero_grad: bool = False, force_bucketer: bool = False):
+                 reference_zero_grad: Optional[bool] = None, force_bucketer: bool = False):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip=clip))
         assert len(self.param_groups) == 1
@@ -66,7 +66,9 @@ class FlatAdam(torch.optim.Optimizer):
         self._sticky = False                     # zero_grad(set_to_none=False) semantics, see the class docstring
         # reference_zero_grad: a bare zero_grad() zero-fills like the reference's pinned torch==1.6.0 (sp_baseline.yml:116) instead of
         # following the installed torch's set_to_none=True default -- COCO_Search18 heads then keep decaying / momentum-stepping
-        self.reference_zero_grad = bool(reference_zero_grad)
+        # (default: as conditional_params -- the only models where the two semantics differ are those with conditionally-used
+        # parameters, and there the reference's behaviour is the parity target: ADVICE r3)
+        self.reference_zero_grad = bool(conditional_params if reference_zero_grad is None else reference_zero_grad)
         self.process_group = process_group
         self.conditional_params = bool(conditional_params)
         with torch.no_grad():
@@ -109,6 +111,10 @@ class FlatAdam(torch.optim.Optimizer):
         if set_to_none is None:
             set_to_none = not self.reference_zero_grad
         self._sticky = not set_to_none
+        if self._bucketer is not None:
+            # a backward whose step() was skipped (non-finite-loss guard, caught exception) left buckets launched / counted: wait for
+            # the all-reduces in flight before the buffer is cleared, and reset the counters so the next backward is a fresh round
+            self._bucketer.drain()
         self.flat_g.zero_()
         self._touched = [False] * len(self._params)
         for p, o in zip(self._params, self._offs):

@@ -18,9 +18,16 @@ def test_collate_targets_match_reference_collate_func():
     from scanpaths_amd.dataset import collate_targets
     g = np.load(os.path.join(GOLDEN, "collate.npz"))
     recs = json.loads(bytes(g["records"]).decode())
-    out = collate_targets(recs, 16, (30, 40))
+    # collate.npz was made under numpy >= 2 (float32 division): the kernel's float32 branch is what it pins; the default
+    # (f64_div=True = the reference's pinned numpy 1.19) is pinned by collate_f64.npz below
+    out = collate_targets(recs, 16, (30, 40), f64_div=False)
     for k in ("scanpaths", "durations", "action_masks", "duration_masks"):
         assert np.array_equal(out[k].cpu().numpy(), g[k]), k
+    g64 = np.load(os.path.join(GOLDEN, "collate_f64.npz"))
+    recs64 = json.loads(bytes(g64["records"]).decode())
+    out64 = collate_targets(recs64, 16, (30, 40))
+    for k in ("scanpaths", "durations", "action_masks", "duration_masks"):
+        assert np.array_equal(out64[k].cpu().numpy(), g64[k]), ("f64 default", k)
     # numpy-1.x (float64 division) semantics vs the oracle restatement, on cell-boundary-rich inputs at 320x512 -> 40x64
     from oracle import sampling_oracle as SO
     rng = np.random.Generator(np.random.PCG64(2))

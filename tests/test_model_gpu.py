@@ -69,6 +69,65 @@ def _record(rows):
         pass
 
 
+MAX_KINKED = 2          # parameters per case whose gradient may carry a ReLU-kink event (see _param_grad_check)
+SMALL_NORM = 1e-6       # parameters whose gradient norm is below SMALL_NORM x the largest norm of the model are held to that floor
+
+
+def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
+    """Per-parameter gradient bar (VERDICT r3 "what's weak" #1): every parameter is held to ITS OWN norm,
+        ||got_k - ref64_k||  <=  max(10 * ||ref32_k - ref64_k||,  1e-4 * max(||ref64_k||, SMALL_NORM * top)),
+    not to the largest gradient norm of the model -- Adam normalises per element, so a relative error of a small-norm parameter is
+    exactly what the update sees (round 3's bar, relative to `top`, let performance_sal_layer.True.weight be wrong by 5.7 % of itself).
+    named_got: {name: tensor or None}; g64 / g32: {name: tensor} (entries may be samples of the gradient: then `got` is sampled alike
+    by the caller).  ReLU-kink rule (profiles/r03_grad_error_concentration.log): a parameter may exceed its bar if, after removing its
+    two worst OUTPUT channels, the rest meets the bar and the whole stays within 5e-3 of the norm -- at most MAX_KINKED parameters.
+    Returns (rows, kinked, worst ratio to the oracle's own fp32 error, its parameter)."""
+    top = max(float(torch.as_tensor(v).double().norm()) for v in g64.values())
+    rows, kinked, worst, worst_name = [], [], 0.0, ""
+    for k, ref in g64.items():
+        ref = torch.as_tensor(ref).double()
+        got = named_got.get(k)
+        got = torch.zeros_like(ref) if got is None else torch.as_tensor(got).detach().cpu().double().reshape(ref.shape)
+        d = got - ref
+        e, floor, nrm = float(d.norm()), float((torch.as_tensor(g32[k]).double() - ref).norm()), float(ref.norm())
+        bar = max(10 * floor, 1e-4 * max(nrm, SMALL_NORM * top))
+        row = {"case": case, "backend": backend, "param": k, "err": e, "oracle32_err": floor, "norm": nrm, "bar": bar,
+               "err_over_norm": e / max(nrm, 1e-300), "err_over_oracle32": e / max(floor, 1e-300), "kinked": False}
+        if e > bar and d.dim() > 1 and d.shape[0] >= 64:
+            ch = d.flatten(1).pow(2).sum(1)
+            rest = float((ch.sum() - ch.topk(2).values.sum()).clamp(min=0).sqrt())
+            if rest <= bar and e <= 5e-3 * nrm:
+                row["kinked"], row["err_without_two_channels"] = True, rest
+                kinked.append((k, e / nrm, rest / nrm))
+                e = rest
+        row["failed"] = bool(e > bar)
+        rows.append(row)
+        if floor > 1e-12 * top and e / floor > worst:
+            worst, worst_name = e / floor, k
+    _record_grads(rows)
+    bad = [r for r in rows if r["failed"]]
+    assert not bad, [(r["param"], f"err {r['err']:.3e} bar {r['bar']:.3e} norm {r['norm']:.3e} oracle32 {r['oracle32_err']:.3e}") for r in bad[:6]]
+    assert len(kinked) <= MAX_KINKED, kinked
+    return rows, kinked, worst, worst_name
+
+
+def _record_grads(rows):
+    """per-parameter gradient errors -> gpurun_out/parity/r04_grad_errors.json (committed copy: profiles/)"""
+    import json
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "parity")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "r04_grad_errors.json")
+        old = json.load(open(path)) if os.path.exists(path) else []
+        keyf = lambda r: (r["case"], r["backend"], r["param"])
+        have = {keyf(r): r for r in old}
+        for r in rows:
+            have[keyf(r)] = r
+        json.dump(sorted(have.values(), key=keyf), open(path, "w"), indent=0)
+    except OSError:
+        pass
+
+
 def _call(model, meta, b):
     img = b["images"].to(DEV)
     if meta["task"] == "AiR":
@@ -273,6 +332,8 @@ def test_train_step_matches_reference(name):
     nerr = np.abs(gn - gref).max()
     report.append(f"{name}: grad-norm err {nerr:.2e} (ref32 floor {nfloor:.2e}, total norm {tot:.2f})")
     assert nerr <= max(1e-4 * tot, 10 * nfloor), report[-1]
+    # per-parameter bar on the parameter's OWN norm (full gradients where the golden holds them, else its 512-entry sample)
+    got_g, ref_g, r32_g = {}, {}, {}
     for k in g:
         if k.startswith("ref64/grad/") or k.startswith("ref64/gradsample/"):
             full = k.startswith("ref64/grad/")
@@ -282,10 +343,10 @@ def test_train_step_matches_reference(name):
                 gg = torch.zeros_like(params[pname])
             if not full:
                 gg = gg.flatten()[::max(1, gg.numel() // 512)][:512]
-            ref = g[k]
-            f32 = max_err(g[k.replace("ref64", "ref32")], ref)
-            e = max_err(gg, ref)
-            assert e <= max(1e-4 * max(1.0, float(np.abs(ref).max())), 10 * f32, 1e-5 * tot), (pname, e, f32)
+            got_g[pname], ref_g[pname], r32_g[pname] = gg, g[k], g[k.replace("ref64", "ref32")]
+    _, kinked, worst, worst_name = _param_grad_check(name, got_g, ref_g, r32_g)
+    report.append(f"{name}: {len(ref_g)} parameter gradients within max(10 x ref32 error, 1e-4 x own norm); worst err / ref32 err "
+                  f"{worst:.2f} ({worst_name}); kink-affected {kinked}")
     tn = opt.step()
     checked_after = total_after = 0
     assert abs(float(tn) - g["ref64/total_norm"][0]) <= max(1e-4 * tot, 10 * abs(g["ref32/total_norm"][0] - g["ref64/total_norm"][0]))
@@ -365,18 +426,9 @@ def test_air_320x512_train_gradients_match_oracle():
     g64, l64 = grads[torch.float64]
     g32, l32 = grads[torch.float32]
     assert abs(float(loss) - l64) <= max(1e-4, 10 * abs(l32 - l64)), (float(loss), l64, l32)
-    norms = {k: float(v.norm()) for k, v in g64.items()}
-    top = max(norms.values())
-    worst = 0.0
-    for k, p in model.named_parameters():
-        if k not in g64:
-            continue
-        got = p.grad.detach().cpu().double() if p.grad is not None else torch.zeros_like(g64[k])
-        e = float((got - g64[k]).norm())
-        floor = float((g32[k].double() - g64[k]).norm())
-        assert e <= max(1e-4 * top, 10 * floor), (k, e, floor, norms[k])
-        worst = max(worst, e / max(floor, 1e-30) if floor > 1e-12 * top else 0.0)
-    print(f"320x512 train: loss hip {float(loss):.6f} oracle64 {l64:.6f}; worst grad err / oracle32 err = {worst:.2f}")
+    got_g = {k: p.grad for k, p in model.named_parameters() if k in g64}
+    _, kinked, worst, worst_name = _param_grad_check("air_320x512_train_T2", got_g, g64, g32)
+    print(f"320x512 train: loss hip {float(loss):.6f} oracle64 {l64:.6f}; worst grad err / oracle32 err = {worst:.2f} ({worst_name}); kink-affected {kinked}")
 
 
 def test_air_320x512_matches_oracle():
@@ -477,32 +529,11 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     l64, l32 = losses["ref64/"], losses["ref32/"]
     assert abs(float(loss) - l64) <= max(1e-4, 10 * abs(l32 - l64)), (float(loss), l64, l32)
     g64, g32 = grads["ref64/"], grads["ref32/"]
-    top = max(float(v.norm()) for v in g64.values())
-    worst, worst_name, kinked = 0.0, "", []
-    for k, p in model.named_parameters():
-        if k not in g64:
-            continue
-        got = p.grad.detach().cpu().double() if p.grad is not None else torch.zeros_like(g64[k])
-        d = got - g64[k]
-        e, floor, nrm = float(d.norm()), float((g32[k] - g64[k]).norm()), float(g64[k].norm())
-        bar = max(1e-4 * top, 10 * floor)
-        if e > bar and d.shape[0] >= 64:
-            # ReLU-kink events: a pre-activation of the layer this parameter feeds that lies within the fp32 noise of zero gets the
-            # other mask in one implementation than in the other; the gradient then differs in ONE output channel by a whole
-            # element's contribution (~ norm / sqrt(active elements)) while every other channel agrees.  Measured on this very case
-            # (profiles/r03_grad_error_concentration.log): sal_conv.weight, 98.2 % of the squared error in output channel 434 --
-            # identically on the 2xfp16 and the 3xbf16 back-end -- and the error of the remaining 510 channels BELOW the fp32
-            # oracle's own; the oracle's fp32 run shows the same signature against its fp64 run (95 % in two channels).  So: at
-            # most two output channels may be kink-affected, the rest must meet the bar, and the whole stays within 5e-3 of the norm.
-            ch = d.flatten(1).pow(2).sum(1) if d.dim() > 1 else d.pow(2)
-            rest = float((ch.sum() - ch.topk(2).values.sum()).clamp(min=0).sqrt())
-            assert rest <= bar and e <= 5e-3 * nrm, (k, e, rest, floor, nrm)
-            kinked.append((k, e / nrm, rest / nrm))
-            e = rest
-        assert e <= bar, (k, e, floor, nrm)
-        if floor > 1e-12 * top and e / floor > worst:
-            worst, worst_name = e / floor, k
-    assert len(kinked) <= 4, kinked
+    # every parameter gradient against ITS OWN norm (10 x the oracle's fp32 error or 1e-4 of the norm), at most MAX_KINKED parameters
+    # with a ReLU-kink event (measured on this very case, profiles/r03_grad_error_concentration.log: sal_conv.weight, 98.2 % of the
+    # squared error in output channel 434 on every back-end, the other 510 channels below the fp32 oracle's own error)
+    got_g = {k: p.grad for k, p in model.named_parameters() if k in g64}
+    _, kinked, worst, worst_name = _param_grad_check("bench_path_320x512_train_T16", got_g, g64, g32)
     rows.append({"case": "bench_path_320x512_train_T16", "backend": "f16x2", "key": "loss", "step": -1, "err": abs(float(loss) - l64),
                  "ref32_noise": abs(l32 - l64), "scale": abs(l64), "bar": max(1e-4, 10 * abs(l32 - l64)),
                  "worst_grad_err_over_oracle32": worst, "worst_grad_param": worst_name, "fusion_counts": got_counts,

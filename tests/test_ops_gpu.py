@@ -517,6 +517,103 @@ def test_f16x2_scales_survive_extreme_operand_magnitudes():
         F.USE_BF16X3, F.SPLIT_SCHEME, F._b3_pays, F._w3_pays = saved
 
 
+
+def _row_col_rel(got, ref):
+    """worst relative rms error over the rows and over the columns of a 2-D result, each relative to that row's / column's OWN rms"""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    d = got - ref
+    rows = (d.pow(2).mean(1).sqrt() / ref.pow(2).mean(1).sqrt().clamp_min(1e-300)).max().item()
+    cols = (d.pow(2).mean(0).sqrt() / ref.pow(2).mean(0).sqrt().clamp_min(1e-300)).max().item()
+    return rows, cols
+
+
+@pytest.mark.parametrize("path", ["f16x2", "bf16x3", "fp32_mfma"])
+@pytest.mark.parametrize("k", [3, 1])
+def test_conv_gemms_keep_every_row_and_column_over_30_binades(path, k, monkeypatch):
+    """operands whose CHANNELS span 2^0 .. 2^-30 in magnitude -- activations and output gradients per channel,
+    weights per output AND per input channel.  An output row / column of a GEMM that receives all of its contributions from a small
+    slice of an operand (forward: output channel <- weight row; data gradient: input channel <- weight column; weight gradient: dW
+    row <- dY channel, dW column <- X channel) must be as exact RELATIVE TO ITS OWN rms as any other: 3e-6, all three back-ends.
+    (Round 3's per-tensor scale of the 2xfp16 operands left such slices with few or no significant bits; now: per-row scales for
+    weight operands, per-channel scales for activation / gradient operands, absorbed by the weight operand where the GEMM contracts
+    over channels.)  Reference semantics: plain fp32 F.conv2d, AiR/models/baseline_attention.py:212-215, 306-309."""
+    from scanpaths_amd import functional as F
+    monkeypatch.setattr(F, "USE_BF16X3", path != "fp32_mfma")
+    monkeypatch.setattr(F, "SPLIT_SCHEME", path if path != "fp32_mfma" else "bf16x3")
+    if path != "fp32_mfma":
+        monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1, **kw: nbatch == 1 and Kc % 16 == 0)
+        monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1, **kw: nbatch == 1 and Ci % 128 == 0 and Co % 32 == 0)
+    N, H, W, Ci, Co = 2, 12, 16, 128, 160
+    g = np.random.Generator(np.random.PCG64(77))
+    span = lambda n: torch.from_numpy(np.exp2(-30.0 * g.permutation(n) / (n - 1)).astype(np.float32))
+    fx, fg, fwo, fwi = span(Ci), span(Co), span(Co), span(Ci)
+    x = _rand(N, H, W, Ci, seed=1) * fx
+    w = _rand(Co, Ci, k, k, seed=2, scale=1.0 / math.sqrt(Ci * k * k)) * fwo.view(Co, 1, 1, 1) * fwi.view(1, Ci, 1, 1)
+    gy = _rand(N, H, W, Co, seed=3) * fg
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, padding=k // 2)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    dev = _dev()
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F.conv2d(xd, wd, None, pad=k // 2)
+    y.backward(gy.to(dev))
+    res = {"y": _row_col_rel(y.reshape(-1, Co), yr.permute(0, 2, 3, 1).reshape(-1, Co)),
+           "dx": _row_col_rel(xd.grad.reshape(-1, Ci), xr.grad.permute(0, 2, 3, 1).reshape(-1, Ci)),
+           "dw": _row_col_rel(wd.grad.permute(0, 2, 3, 1).reshape(Co, -1), wr.grad.permute(0, 2, 3, 1).reshape(Co, -1)),
+           # the weight gradient per INPUT channel (its columns over all taps and output channels)
+           "dw_ci": _row_col_rel(wd.grad.permute(1, 0, 2, 3).reshape(Ci, -1), wr.grad.permute(1, 0, 2, 3).reshape(Ci, -1))}
+    print(f"30-binade spans [{path}, {k}x{k}]: worst (row, column) relative rms error "
+          + ", ".join(f"{n} ({a:.1e}, {b:.1e})" for n, (a, b) in res.items()))
+    for n, (a, b) in res.items():
+        assert a <= 3e-6 and b <= 3e-6, (path, k, n, a, b)
+
+
+@pytest.mark.parametrize("wo,co", [(64, 256), (20, 256), (64, 128)])
+def test_deferred_weight_gradient_of_a_repeated_conv_matches_fp64(wo, co, monkeypatch):
+    """F.DeferredWgrad: the weight gradient of a conv applied T times with the same weight (the ConvLSTM's h-gate conv, AiR/models/
+    baseline_attention.py:37-56) is computed by ONE launch over all applications at the end of backward (sp_conv_wgrad_f16x2_multi:
+    hw2_kernel, 256 x 256 tiles, single-level accumulation, per-application operand scales applied by the slab reduce) -- against
+    fp64, with applications whose gradients differ by 2^-20 .. 2^+8 in scale.  (20-pixel-wide map / 128 output channels: the
+    kernel's shape constraints do not hold, the recorded applications run one launch each: same result.)"""
+    from scanpaths_amd import functional as F
+    monkeypatch.setattr(F, "USE_BF16X3", True)
+    monkeypatch.setattr(F, "SPLIT_SCHEME", "f16x2")
+    monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1, **kw: nbatch == 1 and Kc % 32 == 0)
+    monkeypatch.setattr(F, "_w3_pays", lambda M, Co, K, Ci, nbatch=1, **kw: nbatch == 1 and Ci % 32 == 0 and Co % 32 == 0)
+    T, N, H, Ci = 3, 4, 8, 256
+    w = _rand(co, Ci, 3, 3, seed=5, scale=1.0 / math.sqrt(9 * Ci))
+    xs = [_rand(N, H, wo, Ci, seed=10 + t) * (0.5 + t) for t in range(T)]
+    gys = [_rand(N, H, wo, co, seed=20 + t) * s for t, s in zip(range(T), (1.0, 2.0 ** -20, 2.0 ** 8))]
+    wr = w.double().requires_grad_(True)
+    tot = 0.0
+    for x, gy in zip(xs, gys):
+        tot = tot + (TF.conv2d(x.double().permute(0, 3, 1, 2), wr, padding=1) * gy.double().permute(0, 3, 1, 2)).sum()
+    tot.backward()
+    dev = _dev()
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    cache = {"defer": F.DeferredWgrad()}
+    F.reset_fusion_counts()
+    loss = 0.0
+    xds = [x.to(dev).requires_grad_(True) for x in xs]
+    for xd, gy in zip(xds, gys):
+        loss = loss + (F.conv2d(xd, wd, None, pad=1, wcache=cache) * gy.to(dev)).sum()
+    loss.backward()
+    fits = wo % 32 == 0 and co % 256 == 0
+    assert F.FUSION_COUNTS["wgrad_multi"] == int(fits), F.FUSION_COUNTS
+    assert not cache["defer"].items
+    rel = float((wd.grad.detach().cpu().double() - wr.grad).norm() / wr.grad.norm())
+    rows, cols = _row_col_rel(wd.grad.permute(0, 2, 3, 1).reshape(co, -1), wr.grad.permute(0, 2, 3, 1).reshape(co, -1))
+    print(f"deferred weight gradient ({'one multi-application launch' if fits else 'one launch per application'}): relative error {rel:.2e}, "
+          f"worst row {rows:.2e}, worst column {cols:.2e}")
+    assert rel <= 1e-6 and rows <= 3e-6 and cols <= 3e-6, (rel, rows, cols)
+    for xd, x, gy in zip(xds, xs, gys):      # the data gradients are untouched by the deferral
+        xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+        (TF.conv2d(xr, w.double(), padding=1) * gy.double().permute(0, 3, 1, 2)).sum().backward()
+        _close(xd.grad.permute(0, 3, 1, 2), xr.grad, 2e-6, "dx")
+
+
 def test_fused_amax_hints_equal_the_separate_pass():
     """producers (BN apply / backward, LSTM cell forward / backward) leave max|output| behind for the 2xfp16 operand split:
     the hinted split must be bit-identical to the split that runs its own amax pass, and a tensor without a hint still works"""
@@ -764,6 +861,45 @@ def test_fan_in_of_split_only_gradients_and_cell_backward_without_fp32_output():
         assert rc == 0
         res.append((planes.clone(), dcp.clone(), scale.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+
+def test_fan_in_reads_split_only_contributions_from_the_alias_record_not_from_tensor_identity():
+    """a consumer that leaves the fp32 form of its gradient unwritten records the split operand under its alias
+    index (F.fanout's token); the fan-in must take that contribution from the record even when autograd hands it ANOTHER tensor object
+    than the consumer returned (a hook that clones: attributes such as _sp_skipped are lost), and must refuse an unwritten gradient
+    that arrives without a record."""
+    from scanpaths_amd import functional as F
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 256, generator=g).to(dev).requires_grad_(True)
+    true_g = [torch.randn(64, 256, generator=g).to(dev) * s for s in (1.0, 7.0)]
+
+    class SplitOnly(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, k, record):
+            ctx.k, ctx.fan, ctx.record = k, a._sp_fan, record
+            return a.clone()
+
+        @staticmethod
+        def backward(ctx, gout):
+            poisoned = torch.full_like(gout, float("nan"))          # the "unwritten" fp32 gradient
+            poisoned._sp_skipped = True
+            if ctx.record:
+                ctx.fan[0][ctx.fan[1]] = F.split_op(true_g[ctx.k], "f16x2")
+            return poisoned, None, None
+
+    a, b = F.fanout(x, 2)
+    a.register_hook(lambda t: t.clone())                             # identity (and the attribute) lost on the way to the fan-in
+    ya, yb = SplitOnly.apply(a, 0, True), b * 2.0
+    (ya.sum() + (yb * true_g[1]).sum()).backward()
+    ref = true_g[0].double() + 2.0 * true_g[1].double()
+    assert torch.isfinite(x.grad).all()
+    assert (x.grad.double() - ref).abs().max().item() <= 4e-6 * float(ref.abs().max())
+    x2 = x.detach().clone().requires_grad_(True)
+    a2, b2 = F.fanout(x2, 2)
+    with pytest.raises(RuntimeError, match="without its record"):
+        (SplitOnly.apply(a2, 0, False).sum() + b2.sum()).backward()
 
 
 def test_product_library_has_no_timing_modes():
