@@ -376,10 +376,11 @@ def main():
         nprod = PRODUCTS.get(fam)
         peak = PEAK_F16_MFMA_TFLOPS if nprod else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_src = None, None
-        # the committed PMC passes were taken on the h-gate conv shape (tools/bench_hconv.py: M = 81920, N = 2048, K = 4608)
-        if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_PREFIX and \
-                (dom_key[1], dom_key[2], dom_key[3]) == (81920, 2048, 4608):
-            for fn in ("r03_pmc_hconv.json", "r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
+        # the committed PMC passes were taken on the h-gate conv shape (tools/bench_hconv_steps.py: M = 81920 pixels per application,
+        # N = 2048, K = 4608; the deferred weight gradient hw2_kernel covers all T - 1 applications in one launch)
+        hgate = (dom_key[2], dom_key[3]) == (2048, 4608) and dom_key[1] in (81920, 81920 * (args.T - 1))
+        if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_PREFIX and hgate:
+            for fn in ("r04_pmc_hconv.json", "r03_pmc_hconv.json", "r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
                     keys = [k for k in pmc if k.startswith(PMC_PREFIX[kind])]
@@ -403,9 +404,10 @@ def main():
             "frac": round(dom["tflops"] / peak, 4),
             "traffic": traffic,
             "traffic_note": (f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{traffic_src}); "
-                             "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.75 GB "
-                             "(weight gradient) / 1.05 GB (forward; the ConvLSTM-fused forward also reads the x-gates and writes gates, c, h "
-                             "and h's split operand: 2.9 GB)") if traffic else "no committed PMC pass for this kernel/shape",
+                             "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.88 GB per application "
+                             "(weight gradient: dY planes 671 MB + X planes 168 MB + dW 38 MB; the deferred hw2_kernel launch covers T - 1 "
+                             "applications: x (T - 1)) / 1.05 GB (forward; the ConvLSTM-fused forward also reads the x-gates and writes gates, "
+                             "c, h and h's split operand: 2.9 GB)") if traffic else "no committed PMC pass for this kernel/shape",
             "kernel": f"{KERNEL_NAMES.get(kind, kind)}: implicit GEMM M={M} N={N} K={K} ({dom_key[4]} taps) -- the timed GEMM "
                       "kind+shape with the largest total time",
             "achieved_note": "ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMM the reference computes) / HIP-event launch time on the "
@@ -415,9 +417,11 @@ def main():
             "mfma_products_per_fma": nprod,
             "mfma_pipe_frac": round(dom["tflops"] * nprod / peak, 4) if nprod else None,
             "mfma_pipe_note": "issued MFMA FLOPs / peak = frac x products per algorithmic FMA (matrix-pipe occupancy of the scheme)",
-            "practical_ceiling_note": "profiles/r03_wave_tile_probe.log: an idealised loop of the kernels' structure (same MFMAs, fragment reads, "
-                                      "LDS-DMA pieces; no epilogue, no address arithmetic) runs 2.3-2.5 ms per launch on constant and 3.3-3.55 ms on random "
-                                      "fp16 operands (DVFS under switching power); the shipped kernels run at 3.2-3.8 ms, i.e. at the ceiling of their structure",
+            "practical_ceiling_note": "profiles/r03_wave_tile_probe.log, profiles/r04_hw2_probe.log: idealised loops of the kernels' structures (same "
+                                      "MFMAs, fragment reads, LDS-DMA pieces; no epilogue, no address arithmetic) on random fp16 operands (DVFS under "
+                                      "switching power): 256x128 tile / 64x64 wave tiles 3.3-3.7 ms per application of the h-gate shape, 256x256 tile / "
+                                      "64x128 wave tiles (hw2_kernel, deferred launch) 3.0-3.2 ms; the shipped kernels run at 2.8 (hw2), 2.9-3.0 (data "
+                                      "gradient) and 3.6-3.8 ms (fused forward incl. the cell epilogue)",
             "timed_gemms": by_kind,
             "all_big_gemms_ms_per_step": round(total_timed_ms, 2),
             "all_big_gemms_tflops": round(sum(d["flops_per_launch"] * d["launches"] for d in summ.values())

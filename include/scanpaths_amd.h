@@ -450,6 +450,12 @@ int sp_scanmatch_align(const int* A, int n, const int* B, int m, const double* s
 int sp_scan_max_fixations(void);
 int sp_scan_sed_stde(const double* fix, int ncol, const int64_t* start, const int* count, const int* pairs, int npairs, int height,
                      int width, int ngrid, double max_dim, int* sed, double* stde, void* stream);
+/* MultiMatch (the five similarities the reference obtains per pair from multimatch_gaze.docomparison, AiR/utils/evaluation.py:7,44-45,213;
+ * multimatch_gaze==0.1.2 is not vendored: the published algorithm, restated on the host in utils/evaltools/multimatch.py, is this
+ * kernel's checker): fix [total][ncol >= 3] = (x, y, duration), scanpaths of at most sp_scan_max_fixations() fixations; out [npairs][5]
+ * = (vector, direction, length, position, duration), five NaNs for a pair with a scanpath of fewer than 3 fixations. */
+int sp_scan_multimatch(const double* fix, int ncol, const int64_t* start, const int* count, const int* pairs, int npairs,
+                       double screen_w, double screen_h, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Post-hoc sampling (models/sampling.py:16-77), SURVEY.md §8 row f1.

@@ -777,11 +777,16 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t
     __shared__ float sh4[4];
     float mx = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 acc = reinterpret_cast<const float4*>(l.p[0])[i];
+        // fp64 accumulation like every reduction of the path (free on an HBM-bound pass): a fan-in of T decode steps may cancel --
+        // the scalar gradient of object_head.drt_layer_1.bias came out 2e-4 of itself off on EVERY back-end with fp32 sums here
+        // (tests/diagnostics/drt_bias_probe.py), 50x the fp32 reference's own error
+        const float4 v0 = reinterpret_cast<const float4*>(l.p[0])[i];
+        double ax = v0.x, ay = v0.y, az = v0.z, aw = v0.w;
         for (int k = 1; k < l.n; ++k) {
             const float4 v = reinterpret_cast<const float4*>(l.p[k])[i];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            ax += (double)v.x; ay += (double)v.y; az += (double)v.z; aw += (double)v.w;
         }
+        const float4 acc = make_float4((float)ax, (float)ay, (float)az, (float)aw);
         reinterpret_cast<float4*>(o)[i] = acc;
         mx = amax4(mx, acc.x, acc.y, acc.z, acc.w);
     }
@@ -801,16 +806,16 @@ __global__ __launch_bounds__(256) void sum_n_mixed_kernel(SumListMixed l, float*
     float mx = 0.f;
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
-        float acc[16];
+        double acc[16];                      // fp64 accumulation over the (up to 32) contributions, see sum_n_kernel
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0;
         for (int k = 0; k < l.n; ++k) {
             if (l.f[k]) {
                 const float4* q = reinterpret_cast<const float4*>(l.f[k]) + i * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 v = q[j];
-                    acc[4 * j] += v.x; acc[4 * j + 1] += v.y; acc[4 * j + 2] += v.z; acc[4 * j + 3] += v.w;
+                    acc[4 * j] += (double)v.x; acc[4 * j + 1] += (double)v.y; acc[4 * j + 2] += (double)v.z; acc[4 * j + 3] += (double)v.w;
                 }
             } else {
                 const h8* q = reinterpret_cast<const h8*>(l.pl[k]) + i * 4;        // 64 bytes: plane 0 (2 x 8 halves), plane 1
@@ -818,16 +823,17 @@ __global__ __launch_bounds__(256) void sum_n_mixed_kernel(SumListMixed l, float*
                 const h8 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    acc[e] += ((float)a0[e] + (float)b0[e]) * inv;
-                    acc[8 + e] += ((float)a1[e] + (float)b1[e]) * inv;
+                    acc[e] += (double)(((float)a0[e] + (float)b0[e]) * inv);
+                    acc[8 + e] += (double)(((float)a1[e] + (float)b1[e]) * inv);
                 }
             }
         }
         float4* w = reinterpret_cast<float4*>(o) + i * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            w[j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-            mx = amax4(mx, acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            const float4 r4 = make_float4((float)acc[4 * j], (float)acc[4 * j + 1], (float)acc[4 * j + 2], (float)acc[4 * j + 3]);
+            w[j] = r4;
+            mx = amax4(mx, r4.x, r4.y, r4.z, r4.w);
         }
     }
     if (amax) block_amax_commit(mx, amax, sh4);

@@ -101,6 +101,20 @@ __device__ __forceinline__ void block_amax_commit(float m, unsigned* amax, float
         if (b > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, b);
     }
 }
+// ---- gate non-linearities of the ConvLSTM cell (decoder.hip, the fused cell epilogue of conv_f16x2.hip) ----
+// sigmoid(x) = rcp(1 + exp2(-x * log2 e)) on the hardware's 1-ulp v_exp_f32 / v_rcp_f32 (6 VALU instructions; `1.f / (1.f + expf(-x))`
+// compiles to 27, tanhf to 40, and the fused epilogue evaluates 3 + 1 of them for 64 elements per lane: ~15 us of its ~27 us per tile
+// were these).  Error: the argument product adds |x| * 2^-24 relative to exp(-x), which sigmoid damps by s(1 - s): <= 1.3e-8 absolute
+// over all x, below half an ulp of the result's range; with the rcp ~2 ulp in total.  tanh(x) = 1 - 2 * rcp(1 + exp2(2x log2 e)):
+// absolute error ~1e-7 (one ulp of 1.0; relative accuracy is lost for |x| << 1, where the cell only needs g = tanh(pre) to an
+// absolute 1e-7 next to c of order 1).  Saturates correctly: exp2 -> inf gives rcp 0.
+__device__ __forceinline__ float sp_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float sp_tanh(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // ---- 2xfp16 operand split (conv_f16x2.hip; shared with the producers that emit split operands directly) ----
 // power-of-two scale with amax * s in [8192, 16384)
 __device__ __forceinline__ float scale_of(unsigned amax_bits) {

@@ -15,6 +15,9 @@
 // 32 k = 128 bytes per row.  A 64-byte zero block follows the data (masked loader lanes); the scale lives in a device float.
 #include "common.h"
 #include <algorithm>
+#ifndef SP_XG_PRE
+#define SP_XG_PRE 8
+#endif
 #include <cstdlib>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -107,7 +110,7 @@ struct H2Args {
 // in acc4[i][0..3].  Epilogue: + x-gate term + rank-1 gate term (spcol x wc, staged in the now idle LDS), sigmoid/tanh, cell and
 // hidden state, max|h| -- the [M][4C] h-gate tensor (42 MB per decode step at the benchmark size) is never written or re-read.
 // Needs P % 256 == 0 (a 256-pixel tile lies inside one sample: one filter slice per workgroup), C % 32 == 0, KP <= 32.
-__device__ __forceinline__ float h2_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }      // = decoder.hip sigmoidf_
+__device__ __forceinline__ float h2_sigmoid(float x) { return sp_sigmoid(x); }      // = decoder.hip sigmoidf_ (common.h)
 // Chunk swizzle of the halo activation block.  A ds_read_b128 is served in lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (per
 // 32-lane half): of the 16 consecutive pixel slots b .. b+15 a group reads slots {0-3,12-15} at chunk c (k-group g4 even) and slots
 // {4-11} at chunk c ^ 1 (g4 odd), or the other way round.  The ring's swizzle  c ^ ((row >> 1) & 7)  is conflict-free only for b = 0
@@ -135,6 +138,14 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
     const int64_t m0 = (int64_t)tmi * HBM;
     const int n0 = LSTM ? tn * 32 : tn * HBN;          // LSTM: first CHANNEL of the tile
+    float lstm_sw[4] = {1.f, 1.f, 1.f, 1.f};           // LSTM build: the lane's four per-row weight scales (gate q, its channel), see the epilogue
+    if constexpr (LSTM) {
+        const int chl = n0 + (wave & 1) * 16 + (lane & 15);
+        if (p.sw_rows && chl < p.lC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lstm_sw[q] = p.sw[q * p.lC + chl];
+        }
+    }
     const int HoWo = p.Ho * p.Wo;
 
     // ---- loader mapping: LDS chunk g = t + 512 j -> row g/8, position g%8; source chunk = position ^ swizzle(row) ----
@@ -578,23 +589,48 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         float* sp_s = reinterpret_cast<float*>(smem);             // [256][KP]
         float* wc_s = sp_s + HBM * KP;                            // [3][32][WST]
         const int b = (int)(m0 / p.lP);
-        for (int i = t; i < HBM * KP; i += 512) sp_s[i] = (m0 + i / KP) < p.M ? p.l_spcol[m0 * KP + i] : 0.f;
-        for (int i = t; i < 96 * KP; i += 512) {
-            const int k = i % KP, qj = i / KP;                    // qj = gate * 32 + channel
-            const int ch = n0 + (qj & 31);
-            wc_s[qj * WST + k] = ch < C ? p.l_wc[((int64_t)b * 3 * C + (qj >> 5) * C + ch) * KP + k] : 0.f;
-        }
-        __syncthreads();
         const int cl = wn * 16 + l16, ch = n0 + cl;
-        float iswq[4];                                            // weight row of (gate q, channel ch) = q * C + ch
-#pragma unroll
-        for (int q = 0; q < 4; ++q) iswq[q] = (p.sw_rows && ch < C) ? 1.f / p.sw[q * C + ch] : isw;
+        constexpr int XG_PITCH = 132, HC_PITCH = 36;
+        // The epilogue's global reads are requested FIRST -- the x-gate tile (16 float4 per lane) and the lane's 16 previous cell values;
+        // the per-row weight scales were fetched before the K loop -- so that their latency runs under the staging of the rank-1 operands and the rank-1 loop
+        // below instead of being exposed behind them (three dependent global round trips per tile before: ~2-3 us each of the tile's
+        // ~25 us epilogue, with the matrix pipe of this CU idle).
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {                          // weight row of (gate q, channel ch) = q * C + ch: its own scale
+                const float iswq = (p.sw_rows && ch < C) ? 1.f / lstm_sw[q] : isw;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tot4[i][q][r] = ((tot4[i][q][r] + acc4[i][q][r]) * isx) * iswq[q];
+                for (int r = 0; r < 4; ++r) tot4[i][q][r] = ((tot4[i][q][r] + acc4[i][q][r]) * isx) * iswq;
+            }
+        __builtin_amdgcn_sched_barrier(0);                 // the loads below must not move up into the K loop's register budget
+        float4 v[16];
+        auto load_xg = [&](int k0, int k1) {
+#pragma unroll
+            for (int k = k0; k < k1; ++k) {
+                const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
+                const int64_t m = m0 + row;
+                v[k] = (m < p.M && n0 + c4 * 4 < C) ? *reinterpret_cast<const float4*>(p.l_xg + m * 4 * C + q * C + n0 + c4 * 4)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        constexpr int XG_PRE = SP_XG_PRE;                  // float4s of the x-gate tile requested ahead of the rank-1 phase
+        load_xg(0, XG_PRE);
+        float cpv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                cpv[i][r] = (p.l_cprev && ch < C && m < p.M) ? p.l_cprev[m * C + ch] : 0.f;
+            }
+        for (int i = t; i < HBM * KP; i += 512) sp_s[i] = (m0 + i / KP) < p.M ? p.l_spcol[m0 * KP + i] : 0.f;
+        for (int i = t; i < 96 * KP; i += 512) {
+            const int k = i % KP, qj = i / KP;                    // qj = gate * 32 + channel
+            const int chq = n0 + (qj & 31);
+            wc_s[qj * WST + k] = chq < C ? p.l_wc[((int64_t)b * 3 * C + (qj >> 5) * C + chq) * KP + k] : 0.f;
+        }
+        __syncthreads();
         for (int k = 0; k < KP; ++k) {
             const float w0 = wc_s[cl * WST + k], w1 = wc_s[(32 + cl) * WST + k], w2 = wc_s[(64 + cl) * WST + k];
 #pragma unroll
@@ -609,20 +645,17 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         }
         // The x-gate tile comes in and the activated gates leave through the LDS ring as float4 per lane: per (row, gate) the 32
         // channels of the workgroup are 128 contiguous bytes; read / written 4 bytes per lane straight from the MFMA layout they were
-        // 64-byte runs, and this epilogue (1.85 GB per launch) ran 0.47 ms with the matrix pipe idle.  xs [256 rows][4 gates][32 ch].
+        // 64-byte runs, and this epilogue (1.85 GB per launch) ran 0.47 ms with the matrix pipe idle.  xs [256 rows][4 gates][32 ch],
+        // row pitch XG_PITCH = 132 floats: the four row groups of a lane group (rows 4 apart) land 16 banks apart -- with the natural
+        // pitch of 128 floats they shared their banks (4-way conflicts on 12 accesses per element: 13.4 M SQ_LDS_BANK_CONFLICT cycles per
+        // launch in round 3's counters); the float4 side stays 16-byte aligned (528-byte rows).
+        load_xg(XG_PRE, 16);
         __syncthreads();                                   // sp_s / wc_s are dead
         float* xs = reinterpret_cast<float*>(smem);
-        {
-            float4 v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
-                const int64_t m = m0 + row;
-                v[k] = (m < p.M && n0 + c4 * 4 < C) ? *reinterpret_cast<const float4*>(p.l_xg + m * 4 * C + q * C + n0 + c4 * 4)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) reinterpret_cast<float4*>(xs)[t + 512 * k] = v[k];
+        for (int k = 0; k < 16; ++k) {
+            const int e = t + 512 * k;
+            *reinterpret_cast<float4*>(xs + (e >> 5) * XG_PITCH + (e & 31) * 4) = v[k];
         }
         __syncthreads();
         float hmx = 0.f;
@@ -636,13 +669,12 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 hv[i][r] = 0.f;
                 cv[i][r] = 0.f;
                 if (ch >= C || m >= p.M) continue;
-                float* px = xs + row * 128 + cl;
+                float* px = xs + row * XG_PITCH + cl;
                 const float gi = h2_sigmoid(tot4[i][0][r] + px[0]);
                 const float gf = h2_sigmoid(tot4[i][1][r] + px[32]);
                 const float go = h2_sigmoid(tot4[i][2][r] + px[64]);
-                const float gg = tanhf(tot4[i][3][r] + px[96]);
-                const float cp = p.l_cprev ? p.l_cprev[m * C + ch] : 0.f;
-                const float cn = gf * cp + gi * gg;
+                const float gg = sp_tanh(tot4[i][3][r] + px[96]);
+                const float cn = gf * cpv[i][r] + gi * gg;
                 const float hn = go * cn;
                 px[0] = gi;
                 px[32] = gf;
@@ -658,20 +690,22 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
             const int64_t m = m0 + row;
             if (m < p.M && n0 + c4 * 4 < C)
-                *reinterpret_cast<float4*>(p.l_gates + m * 4 * C + q * C + n0 + c4 * 4) = reinterpret_cast<const float4*>(xs)[e];
+                *reinterpret_cast<float4*>(p.l_gates + m * 4 * C + q * C + n0 + c4 * 4) =
+                    *reinterpret_cast<const float4*>(xs + row * XG_PITCH + (e & 31) * 4);
         }
-        // h and c leave the same way ([256 rows][32 channels] each: 128-byte runs), and h also as the split operand of its consumers
-        // (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <= t + 1, so the operand scale needs no max|h| pass
+        // h and c leave the same way ([256 rows][32 channels] each: 128-byte runs, row pitch HC_PITCH = 36 floats for the same reason),
+        // and h also as the split operand of its consumers (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <=
+        // t + 1, so the operand scale needs no max|h| pass
         __syncthreads();
         float* hs = xs;
-        float* cs2 = xs + HBM * 32;
+        float* cs2 = xs + HBM * HC_PITCH;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * 64 + i * 16 + 4 * g4 + r;
-                hs[row * 32 + cl] = hv[i][r];
-                cs2[row * 32 + cl] = cv[i][r];
+                hs[row * HC_PITCH + cl] = hv[i][r];
+                cs2[row * HC_PITCH + cl] = cv[i][r];
             }
         __syncthreads();
         const float hsc = p.l_hplanes ? scale_of(__float_as_uint(p.l_hbound)) : 1.f;
@@ -680,10 +714,10 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const int e = t + 512 * k, row = e >> 3, c4 = e & 7;
             const int64_t m = m0 + row;
             const bool live = m < p.M && n0 + c4 * 4 < C;
-            const float4 h4 = reinterpret_cast<const float4*>(hs)[e];
+            const float4 h4 = *reinterpret_cast<const float4*>(hs + row * HC_PITCH + c4 * 4);
             if (live) {
                 *reinterpret_cast<float4*>(p.l_h + m * C + n0 + c4 * 4) = h4;
-                *reinterpret_cast<float4*>(p.l_c + m * C + n0 + c4 * 4) = reinterpret_cast<const float4*>(cs2)[e];
+                *reinterpret_cast<float4*>(p.l_c + m * C + n0 + c4 * 4) = *reinterpret_cast<const float4*>(cs2 + row * HC_PITCH + c4 * 4);
             }
             if (p.l_hplanes) {
                 ushort4 pa, pb;
@@ -1686,7 +1720,12 @@ __global__ __launch_bounds__(256) void colamax_final_kernel(const float* partial
     if (c >= C) return;
     float m = 0.f;
     for (int b = 0; b < nblk; ++b) m = fmaxf(m, partial[(int64_t)b * C + c]);
-    col_scale[c] = scale_of(__float_as_uint(m));
+    // An all-zero channel (a dead ReLU channel, the gradient columns of a head no sample selected) gets a HUGE scale, not 1: its planes
+    // are zero either way, but the weight operand that absorbs the vector divides its entries for this channel by the scale -- with
+    // scale 1 those entries (which multiply zeros) would be 2^13 .. 2^24 times larger than the entries that matter and set the
+    // weight row's scale, i.e. take the significant bits away from every useful entry of the row (found as a 5e-4 error of the
+    // LSTM bias gradients on the bench path: tests/diagnostics/head_grad_probe.py).
+    col_scale[c] = m > 0.f ? scale_of(__float_as_uint(m)) : 0x1p100f;
 }
 
 // x [rows][C] (C % 16 == 0) -> planes of x[r][c] * col_scale[c]

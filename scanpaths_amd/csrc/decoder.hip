@@ -8,7 +8,7 @@ namespace {
 
 inline int ew_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n, 256), 2048)); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return sp_sigmoid(x); }      // common.h: the fused cell epilogue uses the same pair
 
 // ------------------------------------------------------------------------------------------------
 // ConvLSTM cell pointwise (:44-54): gates gate-major [i|f|o|g] x C.
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* xg, const fl
         gi.k = sigmoidf_(pi.k);                   \
         gf.k = sigmoidf_(pf.k);                   \
         go.k = sigmoidf_(po.k);                   \
-        gg.k = tanhf(pg.k);                       \
+        gg.k = sp_tanh(pg.k);                       \
         cn.k = gf.k * cp.k + gi.k * gg.k;         \
         hn.k = go.k * cn.k;
         CELL(x) CELL(y) CELL(z) CELL(w)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void lstm_rank1_fwd_kernel(const float* __rest
                 gi[e] = sigmoidf_(pi[e]);
                 gf[e] = sigmoidf_(pf[e]);
                 go[e] = sigmoidf_(po[e]);
-                gg[e] = tanhf(pg[e]);
+                gg[e] = sp_tanh(pg[e]);
                 cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
                 hn[e] = go[e] * cn[e];
             }
@@ -593,6 +593,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, in
 }
 
 // amap (pre-softmax action map) is needed in backward when softmax != 0; pass it as `amap` ([nh][B][P]).
+// block-wide fp64 sum for blockDim.x == 256 (the bias gradients below are sums with heavy cancellation over sites / pixels)
+__device__ __forceinline__ double block_sum_256_d(double v, double* sh4d) {
+    v = wave_sum_d(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh4d[w] = v;
+    __syncthreads();
+    return sh4d[0] + sh4d[1] + sh4d[2] + sh4d[3];
+}
+
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, const float* damap, const float* dmu,
                                                        const float* dsigma2, const float* logits, const float* amap,
                                                        const float* sigma2,
@@ -601,6 +611,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
                                                        float* dw2_partial, float* db2_partial, int dh, int dw, float* ddpre,
                                                        int zc) {
     __shared__ float sh4[4];
+    __shared__ double sh4d[4];
     __shared__ float sdd[MAXS];
     const int hd = blockIdx.y, b = blockIdx.x, nh = gridDim.y;
     const int P = Hm * Wm, S = dh * dw;
@@ -618,40 +629,40 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
     // duration branch gradients
     const float dt0 = dmu[hd * B + b];
     const float dt1 = dsigma2[hd * B + b] * sigma2[hd * B + b];
-    float sumdd = 0.f;
+    double sumdd = 0.0;                  // fp64: per-site terms of either sign (drt_layer_1.bias, round 4 per-parameter bars)
     for (int s = threadIdx.x; s < S; s += 256) {
         const float dv = drt[((int64_t)hd * B + b) * S + s];
         const float dd = dv > 0.f ? dt0 * w2[s] + dt1 * w2[S + s] : 0.f;
         sdd[s] = dd;
         if (ddpre) ddpre[((int64_t)hd * B + b) * S + s] = dd;
-        sumdd += dd;
+        sumdd += (double)dd;
         float* pw = dw2_partial + (((int64_t)b * nh + hd) * 2) * S;
         pw[s] = dt0 * dv;
         pw[S + s] = dt1 * dv;
     }
-    sumdd = block_sum_256(sumdd, sh4);   // also a barrier: sdd visible
+    sumdd = block_sum_256_d(sumdd, sh4d);   // also a barrier: sdd visible
     if (threadIdx.x == 0) {
         db2_partial[((int64_t)b * nh + hd) * 2 + 0] = dt0;
         db2_partial[((int64_t)b * nh + hd) * 2 + 1] = dt1;
         dcb[0] = d0;
-        dcb[IDX_BD] = sumdd;
+        dcb[IDX_BD] = (float)sumdd;
     }
     // composed-bias gradient of the taps: sum over sites where the tap is in range
     if (threadIdx.x < NTAP) {
         const int ky = threadIdx.x / 7, kx = threadIdx.x % 7;
-        float s = 0.f;
+        double s = 0.0;
         if (!ddpre)
         for (int sy = 0; sy < dh; ++sy) {
             if ((unsigned)(5 * sy - 2 + ky) >= (unsigned)Hm) continue;
             for (int sx = 0; sx < dw; ++sx)
-                if ((unsigned)(5 * sx - 2 + kx) < (unsigned)Wm) s += sdd[sy * dw + sx];
+                if ((unsigned)(5 * sx - 2 + kx) < (unsigned)Wm) s += (double)sdd[sy * dw + sx];
         }
-        dcb[2 + threadIdx.x] = s;
+        dcb[2 + threadIdx.x] = (float)s;
     } else if (threadIdx.x > IDX_BD && threadIdx.x < HC) {
         dcb[threadIdx.x] = 0.f;
     }
     // dZ, coalesced over the HC columns of this head
-    float s1 = 0.f;
+    double s1 = 0.0;                     // fp64: sal_layer_3.bias = a sum over all pixels of the masked map gradient
     const float invP = 1.f / (float)P;
     for (int64_t i = threadIdx.x; i < (int64_t)P * zc; i += 256) {
         const int p = (int)(i / zc), j = (int)(i % zc);
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
             float g = softmax ? lg[1 + p] * (dl[1 + p] - dot) : dl[1 + p];
             if (damap) g += damap[((int64_t)hd * B + b) * P + p];
             v = am[p] > 0.f ? g : 0.f;
-            s1 += v;
+            s1 += (double)v;
         } else if (j < 2 + NTAP && !ddpre) {
             const int tap = j - 2, ky = tap / 7, kx = tap % 7;
             const int py = p / Wm, px = p % Wm;
@@ -674,8 +685,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
         }
         dz[(int64_t)p * ldz + j] = v;
     }
-    s1 = block_sum_256(s1, sh4);
-    if (threadIdx.x == 0) dcb[1] = s1;
+    s1 = block_sum_256_d(s1, sh4d);
+    if (threadIdx.x == 0) dcb[1] = (float)s1;
 }
 
 }  // namespace

@@ -104,10 +104,10 @@ __global__ __launch_bounds__(128) void compose11_bwd_kernel(const float* __restr
         O4[(row * 25 + u) * C4 + c4] = acc;
     }
     if (u == 0 && threadIdx.x == 0) {
-        float s = 0.f;
+        double s = 0.0;
         for (int cls = 0; cls < ncls; ++cls)
-            if (((ay.mask[cls / ax.ncls] >> ky) & 1u) && ((ax.mask[cls % ax.ncls] >> kx) & 1u)) s += dcbsum[hd * ncls + cls];
-        dcb[row] = s;
+            if (((ay.mask[cls / ax.ncls] >> ky) & 1u) && ((ax.mask[cls % ax.ncls] >> kx) & 1u)) s += (double)dcbsum[hd * ncls + cls];
+        dcb[row] = (float)s;
     }
 }
 
@@ -370,16 +370,16 @@ __global__ __launch_bounds__(256) void drt_slab_reduce_kernel(const float* __res
 __global__ __launch_bounds__(64) void drt_dcbsum_kernel(const float* __restrict__ dD, const int* __restrict__ hmap, int B,
                                                         int nsel, AxisCls ay, AxisCls ax, float* __restrict__ dcbsum) {
     const int cls = blockIdx.x, k = blockIdx.y, ncls = gridDim.x, S = ay.n * ax.n;
-    float acc = 0.f;
+    double acc = 0.0;                    // fp64 like every reduction of the path: the terms cancel
     for (int bi = threadIdx.x; bi < B * nsel; bi += 64) {
         if (hmap[bi] != k) continue;
         const int b = bi / nsel, i = bi % nsel;
         const float* g = dD + ((int64_t)i * B + b) * S;
         for (int s = 0; s < S; ++s)
-            if (ay.cls[s / ax.n] * ax.ncls + ax.cls[s % ax.n] == cls) acc += g[s];
+            if (ay.cls[s / ax.n] * ax.ncls + ax.cls[s % ax.n] == cls) acc += (double)g[s];
     }
-    acc = wave_sum(acc);
-    if (threadIdx.x == 0) dcbsum[k * ncls + cls] = acc;
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) dcbsum[k * ncls + cls] = (float)acc;
 }
 
 static inline int ew_grid(int64_t n) {

@@ -378,12 +378,13 @@ def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, st
     M = N_img * Ho * Wo
     # large single weight gradients whose shape fits the 256 x 256-tile kernel (x-gate conv, sal_conv): hw2_kernel with one segment
     big = L.sp_conv_wgrad_f16x2_multi_workspace(C.byref(d), 1) if (f16 and HW2_SINGLE and not THROUGHPUT_MODE
-                                                                   and 2.0 * M * Co * KH * KW * Ci >= 1e12) else 0
+                                                                   and 2.0 * M * COST_M_SCALE * Co * KH * KW * Ci >= 1e12) else 0
     ws = hip.workspace(big if big > 0 else (L.sp_conv_wgrad_f16x2_workspace if f16 else L.sp_conv_wgrad_bf16x3_workspace)(C.byref(d)),
                        dW.device, slot=ws_slot)
 
     def launch():
         if big > 0:
+            FUSION_COUNTS["wgrad_multi"] += 1
             one = lambda t: (C.c_void_p * 1)(t.data_ptr())
             check(L.sp_conv_wgrad_f16x2_multi(C.byref(d), 1, one(Xs.buf), one(Xs.scale), one(dYs.buf), one(dYs.scale), ptr(dW), ptr(ws),
                                               hip.stream()), "sp_conv_wgrad_f16x2_multi")

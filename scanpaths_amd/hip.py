@@ -141,6 +141,7 @@ SIGNATURES = {
     "sp_scanmatch_align": (_I, [_P, _I, _P, _I, _P, _I, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
     "sp_scan_max_fixations": (_I, []),
     "sp_scan_sed_stde": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, C.c_double, _P, _P, _P]),
+    "sp_scan_multimatch": (_I, [_P, _I, _P, _P, _P, _I, C.c_double, C.c_double, _P, _P]),
     "sp_sample_actions": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_uint64, _P, _P, _P, _P]),
     "sp_generate_scanpath": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sp_beam_search": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),

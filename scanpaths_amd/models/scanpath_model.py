@@ -329,8 +329,10 @@ class ScanpathModel(nn.Module):
         vfs = list(F.fanout(vf, n_vf)) if vf.requires_grad and n_vf <= 32 else [vf] * n_vf
         Xg = F.conv2d(vfs.pop(), Wx, bias, pad=1)
         Wh = self._cat_phys([L.input_h.weight, L.forget_h.weight, L.output_h.weight, L.memory_h.weight])
-        Wr = [torch.cat([getattr(L, g + s).weight.permute(0, 2, 3, 1) for g in ("input", "forget", "output")], 0)
-              .reshape(3 * 512 * 9, 512) for s in self.streams]
+        # contracted-filter weights of the rank-1 gate terms, one [3*512*9, 512] matrix per stream, stacked: the S contractions of a decode
+        # step are ONE batched GEMM (forward, data and weight gradient: 3 x (S - 1) launches per step less)
+        Wr = torch.stack([torch.cat([getattr(L, g + s).weight.permute(0, 2, 3, 1) for g in ("input", "forget", "output")], 0)
+                          .reshape(3 * 512 * 9, 512) for s in self.streams], 0)
         KP = (9 * S + 3) // 4 * 4
         mvf = F.channel_mean(vfs.pop()).view(B * P)
         u_sem, u_spa = self._attention_vectors()
@@ -372,7 +374,7 @@ class ScanpathModel(nn.Module):
         spw, spb = rep(self.spatial_embed.weight, T), rep(self.spatial_embed.bias, T)
         sew, seb = rep(self.semantic_embed.weight, T), rep(self.semantic_embed.bias, T)
         mvfs, u_spas, u_sems = rep(mvf, T), rep(u_spa, T), rep(u_sem, T)
-        Wrs = [rep(w, T) for w in Wr]
+        Wrs = rep(Wr, T)
         Wsals, W11s, cbsums, cbs, w2s, b2s = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T), rep(w2, T), rep(b2, T)
 
         def push(amaps, k):       # amaps [S,B,P]; memory update number k (:277-296 / :317-336)
@@ -399,9 +401,8 @@ class ScanpathModel(nn.Module):
             wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight-gradient GEMMs run on a side stream, summed in place
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t in range(T):
-            se = se_mem.view(S, B, Cc).unbind(0)      # (unbind: ONE stack in backward instead of a zero-fill + copy per stream and an add)
-            parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk").view(B, 3 * 512, 9) for s in range(S)]
-            wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
+            wcs = F.gemm(se_mem.view(S, B, Cc), Wrs.pop(), None, "nk").unbind(0)        # S x [B, 3*512*9] (unbind: ONE stack in backward)
+            wc = torch.cat([w_.view(B, 3 * 512, 9) for w_ in wcs] + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
             if F.gateconv_lstm_fusable(h, Wh, spcol):       # the cell as the epilogue of the h-gate conv: no h-gate tensor
                 h, c = F.gateconv_lstm(h, Wh, Xg_t[t], c, spcol, wc, wh_cache)

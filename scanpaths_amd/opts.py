@@ -57,6 +57,11 @@ def parse_opt(task="AiR", argv=None):
         if args.cfg is not None:
             with open(args.cfg) as f:
                 cfg = yaml.safe_load(f) or {}
+            if isinstance(cfg, dict) and "_BASE_" in cfg:
+                # the reference's loader (utils/config.py:15-144 load_yaml_with_base) merges the named base file first; that config code
+                # is not rebuilt here -- refuse instead of silently training with the base's values missing
+                raise ValueError(f"{args.cfg}: '_BASE_' inheritance is not supported by scanpaths_amd.opts; flatten the file "
+                                 f"(base {cfg['_BASE_']!r} merged first, then this file's keys)")
         it = iter(args.set_cfgs)
         for k, v in zip(it, it):
             cfg[k] = yaml.safe_load(v)

@@ -7,7 +7,11 @@ vector differences -> cheapest monotone alignment path from the first to the las
 cost = the entered cell) -> medians of the vector, direction, length, position and duration differences along the path ->
 normalisation to [0, 1].  Scanpaths with fewer than 3 fixations give five NaNs (the rule that makes the reference drop a pair).
 PARITY: **unpinned** -- no fixture of the original package exists in the reference; utils/evaluation.py uses the installed
-``multimatch_gaze`` instead whenever it is importable.  Host-side numpy: a pair is a <= 16 x 16 dynamic programme."""
+``multimatch_gaze`` instead whenever it is importable.
+
+Two forms: ``docomparison`` (host numpy, one pair; the reference's call signature) and ``multimatch_pairs`` (round 4: ALL pairs of a
+validation call in one launch of ``sp_scan_multimatch``, one thread per pair -- the triple python loop per pair was the wall-clock of
+validation once ScanMatch / SED / STDE ran on the device).  The host form is the device kernel's checker (tests/test_scanmatch_gpu.py)."""
 from __future__ import annotations
 
 import math
@@ -68,3 +72,32 @@ def docomparison(fixation_vectors1, fixation_vectors2, screensize, grouping=Fals
     un = [float(np.median(v)) for v in (vec, ang, ln, pos, dur)]
     diag = math.sqrt(screensize[0] ** 2 + screensize[1] ** 2)
     return [1 - un[0] / (2 * diag), 1 - un[1] / math.pi, 1 - un[2] / diag, 1 - un[3] / diag, 1 - un[4]]
+
+
+def multimatch_pairs(scanpaths, pairs, screensize):
+    """MultiMatch of many pairs on the device.  scanpaths: list of fixation records / arrays (x, y, duration); pairs: [npairs, 2]
+    indices into scanpaths (first, second argument of docomparison); screensize [width, height].  Returns float64 [npairs, 5]
+    (numpy), five NaNs for a pair with a scanpath of fewer than 3 fixations."""
+    import torch
+
+    from ... import hip
+    from ...hip import check, ptr
+    pr = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    if pr.shape[0] == 0:
+        return np.zeros((0, 5))
+    L = hip.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    arrs = [np.array([list(_) for _ in list(a)], dtype=np.float64).reshape(-1, 3) for a in scanpaths]
+    counts = [a.shape[0] for a in arrs]
+    if max(counts) > L.sp_scan_max_fixations():
+        raise ValueError(f"scanpath of {max(counts)} fixations exceeds the kernel limit {L.sp_scan_max_fixations()}")
+    count = torch.tensor(counts, dtype=torch.int32)
+    start = (torch.cumsum(count.to(torch.int64), 0) - count.to(torch.int64)).to(dev)
+    cat = np.concatenate(arrs, 0) if sum(counts) else np.zeros((1, 3))
+    fix = torch.from_numpy(np.ascontiguousarray(cat)).to(dev)
+    prd = torch.from_numpy(np.ascontiguousarray(pr)).to(dev)
+    count_d = count.to(dev)
+    out = torch.empty((pr.shape[0], 5), dtype=torch.float64, device=dev)
+    check(L.sp_scan_multimatch(ptr(fix), 3, ptr(start), ptr(count_d), ptr(prd), pr.shape[0], float(screensize[0]), float(screensize[1]),
+                               ptr(out), hip.stream()), "sp_scan_multimatch")
+    return out.cpu().numpy()

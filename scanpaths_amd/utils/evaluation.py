@@ -120,12 +120,28 @@ def gtpairs_eval_scanmatch_performance_related(gt_fix_vectors, ScanMatchwithDura
 # with-duration score first, :323-324 label them the other way round).
 # ====================================================================================================================
 def _default_multimatch():
+    """the installed multimatch_gaze (the reference's dependency) if the user has it; else None = the batched device restatement
+    (utils/evaltools/multimatch.multimatch_pairs: every pair of the call in one launch)"""
     try:
-        import multimatch_gaze as mm        # the reference's dependency, if the user has it
+        import multimatch_gaze as mm
         return mm.docomparison
     except Exception:
-        from .evaltools.multimatch import docomparison
-        return docomparison
+        return None
+
+
+def _multimatch_rows(mm, candidates):
+    """candidates: list of (fixation vectors 1, fixation vectors 2) -> list of 5-value rows (NaNs where MultiMatch cannot score).
+    mm None: one device launch for all candidates; else the per-pair callable (the reference's loop)."""
+    if not candidates:
+        return []
+    if mm is not None:
+        return [list(mm(a, b, screensize=[320, 240])) for a, b in candidates]
+    from .evaltools.multimatch import multimatch_pairs
+    paths, pairs = [], []
+    for a, b in candidates:
+        paths.extend([a, b])
+        pairs.append((len(paths) - 2, len(paths) - 1))
+    return [list(r) for r in multimatch_pairs(paths, pairs, [320, 240])]
 
 
 def _rows_for_pairs(paths, pairs, sm_wd, sm_wod, mm_rows):
@@ -176,20 +192,21 @@ def evaluation_performance_related(gt_fix_vectors, predict_fix_vectors, all_perf
     """(utils/evaluation.py:188-359)  -> cur_metrics, cur_metrics_std, scores_of_each_images"""
     mm = multimatch or _default_multimatch()
     sm_wd, sm_wod = _make_scanmatch()
+    cand = [(gt_fix_vectors[index][inner], predict_fix_vectors[index], index, inner)
+            for index in range(len(gt_fix_vectors)) for inner in range(len(gt_fix_vectors[index]))]
+    mm_all = _multimatch_rows(mm, [(a, b) for a, b, _, _ in cand])
     paths, pairs, mm_rows, owner = [], [], [], []
-    for index in range(len(gt_fix_vectors)):
-        pred = predict_fix_vectors[index]
-        pi = len(paths)
-        paths.append(_as_ms(pred))
-        for inner_index in range(len(gt_fix_vectors[index])):
-            gt = gt_fix_vectors[index][inner_index]
-            rlt = list(mm(gt, pred, screensize=[320, 240]))
-            if np.any(np.isnan(np.asarray(rlt, dtype=np.float64))):
-                continue                                                    # (:215-217) pairs MultiMatch cannot score are dropped
-            paths.append(_as_ms(gt))
-            pairs.append((len(paths) - 1, pi))
-            mm_rows.append(rlt)
-            owner.append((index, inner_index))
+    pred_slot = {}
+    for (gt, pred, index, inner_index), rlt in zip(cand, mm_all):
+        if index not in pred_slot:
+            pred_slot[index] = len(paths)
+            paths.append(_as_ms(pred))
+        if np.any(np.isnan(np.asarray(rlt, dtype=np.float64))):
+            continue                                                    # (:215-217) pairs MultiMatch cannot score are dropped
+        paths.append(_as_ms(gt))
+        pairs.append((len(paths) - 1, pred_slot[index]))
+        mm_rows.append(rlt)
+        owner.append((index, inner_index))
     rows = _rows_for_pairs(paths, pairs, sm_wd, sm_wod, mm_rows)
     collect_all, collect_right, collect_wrong, scores_of_each_images = [], [], [], []
     k = 0
@@ -218,7 +235,7 @@ def human_evaluation(dataloader, multimatch=None):
     "fix_vectors", "performances", "question_ids"  -> human_metrics, human_metrics_std, scores_of_each_images_dict"""
     mm = multimatch or _default_multimatch()
     sm_wd, sm_wod = _make_scanmatch()
-    paths, pairs, mm_rows, owner, images, gt_qid_name = [], [], [], [], [], []
+    paths, images, gt_qid_name, cand = [], [], [], []
     for batch in dataloader:
         gt_qid_name.extend(batch["question_ids"])
         for fix_vectors, performances in zip(batch["fix_vectors"], batch["performances"]):
@@ -229,14 +246,16 @@ def human_evaluation(dataloader, multimatch=None):
                 paths.append(_as_ms(fv))
             for index_1 in range(len(fix_vectors)):
                 for index_2 in range(len(fix_vectors)):
-                    if index_2 == index_1:
-                        continue
-                    rlt = list(mm(fix_vectors[index_1], fix_vectors[index_2], screensize=[320, 240]))
-                    if np.any(np.isnan(np.asarray(rlt, dtype=np.float64))):
-                        continue
-                    pairs.append((base + index_1, base + index_2))
-                    mm_rows.append(rlt)
-                    owner.append((img, index_1, index_2))
+                    if index_2 != index_1:
+                        cand.append((fix_vectors[index_1], fix_vectors[index_2], base + index_1, base + index_2, (img, index_1, index_2)))
+    mm_all = _multimatch_rows(mm, [(a, b) for a, b, _, _, _ in cand])
+    pairs, mm_rows, owner = [], [], []
+    for (_, _, p1, p2, own), rlt in zip(cand, mm_all):
+        if np.any(np.isnan(np.asarray(rlt, dtype=np.float64))):
+            continue
+        pairs.append((p1, p2))
+        mm_rows.append(rlt)
+        owner.append(own)
     rows = _rows_for_pairs(paths, pairs, sm_wd, sm_wod, mm_rows)
     collect_all, collect_right, collect_wrong, good_scores, poor_scores = [], [], [], [], []
     k = 0

@@ -95,6 +95,10 @@ CONFIGS = {
     "no_fuse": ("bench path, FUSE_GATE_LSTM off", dict(COST_M_SCALE=16.0, FUSE_GATE_LSTM=False)),
     "no_hplanes": ("bench path, LSTM_H_PLANES off", dict(COST_M_SCALE=16.0, LSTM_H_PLANES=False)),
     "no_amax_hint": ("bench path, FUSED_AMAX off", dict(COST_M_SCALE=16.0, FUSED_AMAX=False)),
+    "no_defer": ("bench path, DEFER_WGRAD off", dict(COST_M_SCALE=16.0, DEFER_WGRAD=False)),
+    "no_channel_scales": ("bench path, CHANNEL_SCALES off", dict(COST_M_SCALE=16.0, CHANNEL_SCALES=False)),
+    "no_rank1_split": ("bench path, RANK1_DSP_SPLIT / RANK1_DWC_SPLIT off", dict(COST_M_SCALE=16.0, RANK1_DSP_SPLIT=False, RANK1_DWC_SPLIT=False)),
+    "no_skip_dpre": ("bench path, LSTM_SKIP_DPRE off", dict(COST_M_SCALE=16.0, LSTM_SKIP_DPRE=False)),
     "bf16x3": ("bf16x3 back-end", dict(COST_M_SCALE=16.0, SPLIT_SCHEME="bf16x3")),
     "fp32": ("fp32 MFMA back-end", dict(USE_BF16X3=False)),
 }

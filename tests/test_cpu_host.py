@@ -109,6 +109,38 @@ def test_opts_flag_surface():
     assert parse_opt("AiR", ["--ablate_attention_info", "False"]).ablate_attention_info is True   # type=bool quirk kept
     assert parse_opt("AiR", ["--set_cfgs", "lr", "0.01"]).lr == 0.01                              # set_cfgs > defaults
     assert parse_opt("AiR", ["--set_cfgs", "lr", "0.01", "--lr", "0.5"]).lr == 0.5                 # explicit CLI > set_cfgs (:70)
+    # --cfg: plain YAML is merged; a file that relies on the reference's _BASE_ inheritance (utils/config.py:15-144) is refused loudly
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        plain, based = os.path.join(d, "a.yaml"), os.path.join(d, "b.yaml")
+        open(plain, "w").write("lr: 0.003\nbatch: 8\n")
+        open(based, "w").write("_BASE_: a.yaml\nlr: 0.004\n")
+        a = parse_opt("AiR", ["--cfg", plain])
+        assert a.lr == 0.003 and a.batch == 8
+        with pytest.raises(ValueError, match="_BASE_"):
+            parse_opt("AiR", ["--cfg", based])
+
+
+def test_config_switchboard_ignores_stray_environment_variables():
+    """SP_* tuning variables are honoured only under SP_ALLOW_ENV_TUNING=1; the throughput mode and the timing library
+    announce themselves; bench.py can list the non-default switches"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import scanpaths_amd.functional as F, scanpaths_amd.config as c;"
+            "print(F.SPLIT_SCHEME, F.THROUGHPUT_MODE, F.BN_SPLIT, c.non_default())")
+    run = lambda env: subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, **env}, capture_output=True, text=True)
+    base = {k: "" for k in ("SP_ALLOW_ENV_TUNING", "SP_SPLIT_SCHEME", "SP_BN_SPLIT", "SP_LIBRARY")}
+    r = run({**base, "SP_SPLIT_SCHEME": "f16x1", "SP_BN_SPLIT": "0"})
+    assert r.stdout.split()[:3] == ["f16x2", "False", "True"] and "IGNORING" in r.stderr, (r.stdout, r.stderr)
+    r = run({**base, "SP_ALLOW_ENV_TUNING": "1", "SP_SPLIT_SCHEME": "f16x1", "SP_BN_SPLIT": "0"})
+    assert r.stdout.split()[:3] == ["f16x2", "True", "False"] and "THROUGHPUT MODE" in r.stderr, (r.stdout, r.stderr)
+    assert "'split_scheme': 'f16x1'" in r.stdout and "'bn_split': False" in r.stdout
+    from scanpaths_amd import config
+    with pytest.raises(KeyError):
+        config.set(no_such_switch=1)
+    with pytest.raises(ValueError):
+        config.set(split_scheme="fp8")
 
 
 def test_sampling_refuses_cpu():

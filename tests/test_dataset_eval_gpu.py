@@ -142,6 +142,59 @@ def test_evaluation_performance_related_matches_literal_restatement():
     assert scores[2] == list(np.zeros(9))
 
 
+
+def test_multimatch_on_the_device_matches_the_host_restatement():
+    """sp_scan_multimatch (one thread per pair, all pairs of a validation call in one launch: AiR/utils/evaluation.py:44-45,213 calls
+    multimatch_gaze.docomparison per pair) against utils/evaltools/multimatch.docomparison, its checker: lengths 1 .. 24 (fewer than 3
+    fixations -> five NaNs on both sides), coordinates on an 8-pixel lattice (equal alignment costs: the tie rule right > down >
+    diagonal must agree), repeated fixations (zero-length saccades), equal durations.  Same alignment path -> vector / length /
+    position / duration values to 1e-13 (python's ** 2 is pow()), direction to 1e-12 (atan2's last bit).  Then the two validation
+    entry points with the device default against the same call with the host callable."""
+    from scanpaths_amd.utils.evaltools.multimatch import docomparison, multimatch_pairs
+    from scanpaths_amd.utils.evaluation import evaluation_performance_related
+    rng = np.random.Generator(np.random.PCG64(31))
+
+    def fv(n, lattice):
+        a = np.zeros(n, dtype=_FV)
+        if lattice:
+            a["start_x"], a["start_y"] = rng.integers(0, 40, n) * 8.0, rng.integers(0, 30, n) * 8.0
+            a["duration"] = rng.integers(1, 4, n) * 0.1
+        else:
+            a["start_x"], a["start_y"], a["duration"] = rng.uniform(0, 320, n), rng.uniform(0, 240, n), rng.uniform(0.05, 0.9, n)
+        return a
+    paths = [fv(int(rng.integers(1, 25)), bool(k % 2)) for k in range(60)]
+    paths[5] = paths[4].copy()                                        # identical scanpaths: all differences zero
+    paths[7]["start_x"][:], paths[7]["start_y"][:] = 100.0, 50.0       # one location: zero-length saccades
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, len(paths), (400, 2))] + [(4, 5), (7, 7), (7, 8)]
+    got = multimatch_pairs(paths, pairs, [320, 240])
+    worst = np.zeros(5)
+    nnan = 0
+    for (a, b), g in zip(pairs, got):
+        with np.errstate(all="ignore"):
+            ref = np.asarray(docomparison(paths[a], paths[b], screensize=[320, 240]), dtype=np.float64)
+        assert np.array_equal(np.isnan(ref), np.isnan(g)), (a, b, ref, g)
+        if np.isnan(ref).any():
+            nnan += 1
+            continue
+        worst = np.maximum(worst, np.abs(ref - g))
+    print(f"MultiMatch device vs host restatement over {len(pairs)} pairs ({nnan} unscorable): worst |diff| per value {worst}")
+    assert nnan > 10 and (worst[[0, 2, 3, 4]] <= 1e-13).all() and worst[1] <= 1e-12, worst
+    n_img = 6
+    gt = [[_fv(int(rng.integers(2, 12)), rng) for _ in range(int(rng.integers(2, 6)))] for _ in range(n_img)]
+    perf = [[bool(rng.random() < 0.5) for _ in g] for g in gt]
+    perf[0], perf[1] = [True] * len(perf[0]), [False] * len(perf[1])
+    pred = [_fv(int(rng.integers(3, 14)), rng) for _ in range(n_img)]
+    alloc = [True, False, True, True, False, True]
+    dev_out = evaluation_performance_related(gt, pred, perf, alloc)                              # default: device MultiMatch
+    host_out = evaluation_performance_related(gt, pred, perf, alloc, multimatch=docomparison)
+    for cat in ("all", "right_answer", "wrong_answer"):
+        for grp in ("MultiMatch", "ScanMatch", "VAME"):
+            for key, v in host_out[0][cat][grp].items():
+                assert abs(float(dev_out[0][cat][grp][key]) - float(v)) <= 1e-6, (cat, grp, key)
+    for a, b in zip(dev_out[2], host_out[2]):
+        assert np.allclose(a, b, rtol=0, atol=1e-9)
+
+
 def test_run_test_loop_order_and_single_copy():
     """the reference's test loop (AiR/test.py:111-193) on the device: record order (per trial: N good, then N poor), counts,
     finite metrics; fixation vectors equal what generate_scanpath returns for the same draws"""

@@ -205,5 +205,17 @@ def test_second_backward_before_step_raises_instead_of_drifting():
         for i in (3, 2, 1, 0):                                               # after finish() the next step starts clean
             bk.mark_ready(i)
         bk.finish()
+        # a double report inside a bucket that has NOT been launched yet is detected as well (it used to decrement the counter
+        # again and launch the bucket one report early) ...
+        bk.mark_ready(3)
+        with pytest.raises(RuntimeError, match="twice"):
+            bk.mark_ready(3)
+        # ... and a backward whose step() was skipped (non-finite-loss guard, caught exception) is recoverable: drain() -- what
+        # FlatAdam.zero_grad() calls -- waits for what is in flight and starts a fresh round
+        bk.drain()
+        assert bk.pending == bk.members and not bk.handles and not any(bk.reported)
+        for i in (3, 2, 1, 0):
+            bk.mark_ready(i)
+        bk.finish()
     finally:
         dist.destroy_process_group()

