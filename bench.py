@@ -37,11 +37,15 @@ KERNEL_NAMES = {
     "h2_fwd": "h2_kernel<fwd> (2xfp16 split, 3 MFMA products)", "h2_dgrad": "h2_kernel<dgrad> (2xfp16 split, 3 MFMA products)",
     "h2_wgrad": "hw_kernel (2xfp16 split weight gradient, 3 MFMA products)",
     "h2_wgrad_multi": "hw2_kernel (2xfp16 split weight gradient of ALL applications of the h-gate conv in one launch, 3 MFMA products)",
+    "h2_wgrad_multi_rows": "hw2_kernel (2xfp16 split weight gradient of ALL applications of the h-gate conv in one launch, 3 MFMA products; "
+                           "samples behind their last masked-in step skipped)",
+    "h2_dgrad_rows": "h2_kernel<dgrad> (2xfp16 split, 3 MFMA products; zero tiles for samples behind their last masked-in step)",
     "h1_fwd": "h2_kernel<fwd, 1 plane> (fp16 in / fp32 acc, 1 product)", "h1_dgrad": "h2_kernel<dgrad, 1 plane>",
     "h1_wgrad": "hw_kernel<1 plane>",
     "b3_fwd": "b3_kernel<fwd> (3xbf16 split, 6 MFMA products)", "b3_dgrad": "b3_kernel<dgrad>", "b3_wgrad": "w3_kernel",
     "igemm_fwd": "igemm_kernel<fwd> (fp32 MFMA)", "igemm_dgrad": "igemm_kernel<dgrad> (fp32 MFMA)", "wgrad": "wgrad_kernel (fp32 MFMA)"}
-PMC_PREFIX = {"h2_fwd": "h2_kernel<0,", "h2_dgrad": "h2_kernel<1,", "h2_wgrad": "hw_kernel", "h2_wgrad_multi": "hw2_kernel"}      # kernel-name prefixes in profiles/*_pmc_hconv.json
+PMC_PREFIX = {"h2_fwd": "h2_kernel<0,", "h2_dgrad": "h2_kernel<1,", "h2_wgrad": "hw_kernel", "h2_wgrad_multi": "hw2_kernel",
+              "h2_dgrad_rows": "h2_kernel<1,", "h2_wgrad_multi_rows": "hw2_kernel"}      # kernel-name prefixes in profiles/*_pmc_hconv.json
 # the forward launches of the h-gate shape are (15 of 16) the ConvLSTM-fused variant: its own PMC entry (7th template argument true)
 PMC_FUSED_FWD = ", true, true, true"
 
@@ -112,6 +116,9 @@ def parse():
     ap.add_argument("--T", type=int, default=16)
     ap.add_argument("--arch", type=str, default="resnet50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-backward", action="store_true",
+                    help="do not skip the (sample, decode step) pairs behind a sample's last masked-in step in the backward pass (their gradients "
+                         "are exactly zero; default: skipped, results identical -- the line reports the dense time of the same process too)")
     ap.add_argument("--force-bucketer", action="store_true",
                     help="1-GPU half of the scaling evidence: run the data-parallel machinery in an RCCL world of ONE (post-accumulate hooks, "
                          "32 MB buckets, async all-reduce on RCCL's stream) and report its cost next to the plain step (JSON key 'ddp')")
@@ -293,6 +300,7 @@ def main():
     model = build_model(args, dev)
     b = {k: v.to(dev) for k, v in make_batch(task, args.batch, args.height, args.width, args.T, seed=0, rank=rank).items()}
 
+    sparse_bwd = [not args.dense_backward]       # (a cell: the dense leg below flips it for the same step function)
     if args.mode == "train":
         model.train()
         if world > 1:
@@ -312,7 +320,7 @@ def main():
                 mask_sums = global_mask_normaliser(torch.cat([F.device_sum(b["action_masks"]),
                                                               F.device_sum(b["duration_masks"])]))
             loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0,
-                                         mask_sums)
+                                         mask_sums, skip_masked_backward=sparse_bwd[0])
             loss.backward()
             opt.step()
             return loss
@@ -352,6 +360,31 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
+    sparsity = None
+    if args.mode == "train" and world == 1 and sparse_bwd[0]:
+        # the same step with the dense backward pass (what the reference computes), same process, after the timed region
+        sparse_bwd[0] = False
+        step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dense_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        sparse_bwd[0] = True
+        am, dm = b["action_masks"], b["duration_masks"]
+        Tn = am.shape[1]
+        last = (((am > 0) | (dm > 0)).int() * torch.arange(1, Tn + 1, device=am.device, dtype=torch.int32)).amax(1) - 1
+        frac = float((last.view(-1, 1) >= torch.arange(1, Tn, device=am.device).view(1, -1)).float().mean())
+        sparsity = {"skip_masked_backward": True, "dense_backward_ms_per_step": round(dense_ms, 2),
+                    "dense_backward_images_per_s": round(args.batch * 1e3 / dense_ms, 3),
+                    "active_fraction_of_sample_steps": round(frac, 4),
+                    "note": "the loss multiplies by action_masks / duration_masks (AiR/models/loss.py:10-14,27-32): behind a sample's last "
+                            "masked-in step every gradient of the decoder's recurrence is EXACTLY zero; the cell backward, the h-gate conv's data "
+                            "gradient and its deferred weight gradient skip those (sample, step) pairs instead of multiplying zeros -- gradients "
+                            "bit-identical to the dense backward (tests/test_model_gpu.py::test_masked_step_sparsity...); forward, loss, "
+                            "clip and Adam are unchanged; synthetic scanpath lengths are uniform in 1..T (SURVEY.md 8d); `--dense-backward` "
+                            "times the dense form as the headline instead"}
     ddp_info = None
     if args.force_bucketer:
         ddp_info = bucketer_overhead(opt, step, sync, args.steps, dt / args.steps * 1e3)
@@ -367,6 +400,18 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
     summ = timer.summary()
+    # launches that skip samples behind their last masked-in step ("_rows" keys) EXECUTE only the active fraction of the dense FLOPs
+    # their key was priced with: the roofline below counts the executed ones
+    if args.mode == "train":
+        am_, dm_ = b["action_masks"], b["duration_masks"]
+        Tn_ = am_.shape[1]
+        last_ = (((am_ > 0) | (dm_ > 0)).int() * torch.arange(1, Tn_ + 1, device=am_.device, dtype=torch.int32)).amax(1) - 1
+        act_frac = float((last_.view(-1, 1) >= torch.arange(1, Tn_, device=am_.device).view(1, -1)).float().mean())
+        for k_, d_ in summ.items():
+            if k_[0].endswith("_rows"):
+                d_["flops_per_launch"] *= act_frac
+                d_["tflops"] *= act_frac
+                d_["executed_fraction"] = round(act_frac, 4)
     # ---- roofline of the dominant kernel = the timed GEMM kind + shape with the largest total time -------------
     roofline = None
     if summ:
@@ -396,6 +441,7 @@ def main():
         for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:6]:
             f = k[0].split("_")[0]
             by_kind.append({"kernel": KERNEL_NAMES.get(k[0], k[0]), "M": k[1], "N": k[2], "K": k[3],
+                            **({"executed_fraction_of_dense_flops": d["executed_fraction"]} if "executed_fraction" in d else {}),
                             "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
                             "ms_per_step": round(d["ms"] / args.steps, 2), "tflops": round(d["tflops"], 1),
                             "frac_of_2500": round(d["tflops"] / PEAK_F16_MFMA_TFLOPS, 4) if PRODUCTS.get(f) else None})
@@ -460,6 +506,10 @@ def main():
                       # only under SP_ALLOW_ENV_TUNING=1): {} for the headline line
                       "non_default_switches": sp_config.non_default()},
            "roofline": roofline}
+    if sparsity is not None:
+        out["backward_sparsity"] = sparsity
+    elif args.mode == "train":
+        out["backward_sparsity"] = {"skip_masked_backward": bool(sparse_bwd[0])}
     if ddp_info is not None:
         out["ddp"] = ddp_info
         out["metric"] = metric + " [--force-bucketer: RCCL world of one, NOT the headline line]"

@@ -72,6 +72,14 @@ typedef struct sp_conv_desc {
     /* 2xfp16 kernels only (sp_conv_igemm_f16x2*, sp_gateconv_lstm_f16x2): w_scale is a VECTOR with one power-of-two scale per weight
      * row = output column (nbatch * Nout entries; sp_split2_f16_rows / sp_split2_f16_wT_rows) instead of one device scalar */
     int w_scale_rows;
+    /* 2xfp16 data gradient (mode 1, nbatch 1) only -- ROW SPARSITY of a gradient implied by the loss masks: row_last[img] (device, one int per
+     * sample, nullable) = the last decode step at which sample img receives any loss gradient; a call made for decode step row_step >
+     * row_last[img] knows every row of that sample's output gradient to be exactly zero and writes (beta 0) / leaves (beta 1) its output
+     * tiles without reading the operands (tiles inside one sample: Ho * Wo % 256 == 0; else the call is dense).  Also honoured by the
+     * batched forward form (mode 0, nbatch > 1: one item per sample).  The reference computes
+     * these zeros densely (AiR/train.py:190-202: the loss multiplies by action_masks / duration_masks, AiR/models/loss.py:10-14,27-32). */
+    const int* row_last;
+    int row_step;
 } sp_conv_desc;
 
 int sp_conv_igemm(const sp_conv_desc* d, const float* X, const float* W, const float* bias, float* out, void* stream);
@@ -105,6 +113,10 @@ typedef struct sp_wgrad_desc {
     /* 2xfp16 kernels only: x_scale / y_scale are per-CHANNEL vectors ([Ci] / [Co]; sp_split2_f16_cols) instead of device scalars;
      * K = pixels, so a power-of-two scale per channel of either operand factors out of the contraction exactly (nbatch must be 1) */
     int x_scale_vec, y_scale_vec;
+    /* 2xfp16 batched form (nbatch > 1, one item per sample) only: row sparsity as in sp_conv_desc -- items with row_last[item] < row_step
+     * have an all-zero dY: their result is written as zeros (beta 0) / left alone (beta 1) without any work; NULL: dense */
+    const int* row_last;
+    int row_step;
 } sp_wgrad_desc;
 
 int64_t sp_conv_wgrad_workspace(const sp_wgrad_desc* d);
@@ -162,8 +174,11 @@ int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, const float*
  * fixed order with each application's own scales.  Shape constraints: stride 1, Wo % 32 == 0, Co % 256 == 0, KH*KW*Ci % 256 == 0;
  * the workspace query returns 0 and the launch SP_EINVAL when they do not hold (issue one sp_conv_wgrad_f16x2 per application then). */
 int64_t sp_conv_wgrad_f16x2_multi_workspace(const sp_wgrad_desc* d, int nseg);
+/* row_last / seg_steps (both or neither; seg_steps is a HOST array of nseg ints): application g belongs to decode step seg_steps[g]; the
+ * pixels of a sample with row_last[img] < seg_steps[g] carry an exactly-zero output gradient (sp_conv_desc.row_last) and are skipped. */
 int sp_conv_wgrad_f16x2_multi(const sp_wgrad_desc* d, int nseg, const void* const* Xsplits, const float* const* x_scales,
-                              const void* const* dYsplits, const float* const* y_scales, float* dW, void* workspace, void* stream);
+                              const void* const* dYsplits, const float* const* y_scales, float* dW, void* workspace,
+                              const int* row_last, const int* seg_steps, void* stream);
 /* forward conv whose epilogue also writes the first reduction stage of the BatchNorm behind it (per 256-row tile and output column:
  * sum, sum of squares in fp64; min, max in fp32): st_partial [tiles][2][Nout], st_mm [tiles][2][Nout], tiles = sp_conv_stats_tiles(d).
  * No bias / relu / beta.  models/resnet.py:57-93 (conv -> bn). */
@@ -309,6 +324,12 @@ int sp_lstm_pointwise_bwd_split(const float* dh, const float* dc, const float* g
                                 int64_t rows, int C, float* dpre, float* dc_prev, unsigned* dpre_amax, unsigned* dcp_amax,
                                 const unsigned* dh_amax, const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
                                 float* dpre_scale, void* stream);
+/* the same with the row sparsity of sp_conv_desc.row_last: samples (rows_per_sample consecutive rows each) with row_last[sample] < row_step
+ * get zero outputs without reading the inputs */
+int sp_lstm_pointwise_bwd_rows(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* c_out,
+                               int64_t rows, int C, float* dpre, float* dc_prev, unsigned* dpre_amax, unsigned* dcp_amax,
+                               const unsigned* dh_amax, const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
+                               float* dpre_scale, const int* row_last, int row_step, int rows_per_sample, void* stream);
 
 /* 3x3 zero-padded im2col of single-channel maps [R][H][W] into columns [koff,koff+9) of col[r][p][ldk], and adjoint.
  * Feeds the rank-1 gate convolutions conv3x3(W, spatial (x) semantic) (baseline_attention.py:40-50) and the

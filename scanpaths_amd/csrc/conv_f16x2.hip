@@ -16,7 +16,7 @@
 #include "common.h"
 #include <algorithm>
 #ifndef SP_XG_PRE
-#define SP_XG_PRE 8
+#define SP_XG_PRE 0      // float4s of the x-gate tile requested ahead of the rank-1 phase of the fused cell epilogue: 8 measured neutral (see there)
 #endif
 #include <cstdlib>
 
@@ -79,6 +79,11 @@ struct H2Args {
     // of bn_pool.hip's first reduction stage -- the BatchNorm behind this conv starts at its second stage
     double* st_partial;
     float* st_mm;
+    // Row sparsity of a gradient (data gradient, MODE 1): row_last[img] = last decode step at which sample img receives any loss gradient
+    // (from the loss masks); at step row_step > row_last[img] every row of that sample is exactly zero, so a tile that lies inside such
+    // a sample (Ho * Wo % 256 == 0) is zero: written as zeros (or left alone under beta) without touching the operands.
+    const int* row_last;
+    int row_step;
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
@@ -138,6 +143,30 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
     const int64_t m0 = (int64_t)tmi * HBM;
     const int n0 = LSTM ? tn * 32 : tn * HBN;          // LSTM: first CHANNEL of the tile
+    if constexpr (!LSTM) {
+        if (p.row_last != nullptr) {                   // (scalar: the whole workgroup takes the same way, before any barrier)
+            // data gradient: the tile's sample; batched forward GEMM (one item per sample, whole tiles per item): the tile's item
+            const int howo = MODE == 1 ? p.Ho * p.Wo : p.rows_per_batch;
+            const int img = (int)(m0 / howo);
+            if (howo % HBM == 0 && m0 < p.M && p.row_last[img] < p.row_step) {
+                if (!p.beta) {
+                    for (int i = t; i < HBM * (HBN / 4); i += 512) {
+                        const int row = i / (HBN / 4), n = n0 + (i % (HBN / 4)) * 4;
+                        const int64_t m = m0 + row;
+                        if (m >= p.M) continue;
+                        float* dst = p.C + m * p.ldc + n;
+                        if ((p.ldc & 3) == 0 && n + 3 < p.Nout && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
+                            *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        } else {
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.Nout) dst[e] = 0.f;
+                        }
+                    }
+                }
+                return;
+            }
+        }
+    }
     float lstm_sw[4] = {1.f, 1.f, 1.f, 1.f};           // LSTM build: the lane's four per-row weight scales (gate q, its channel), see the epilogue
     if constexpr (LSTM) {
         const int chl = n0 + (wave & 1) * 16 + (lane & 15);
@@ -590,7 +619,11 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         float* wc_s = sp_s + HBM * KP;                            // [3][32][WST]
         const int b = (int)(m0 / p.lP);
         const int cl = wn * 16 + l16, ch = n0 + cl;
+#ifdef SP_LIBM_GATES
+        constexpr int XG_PITCH = 128, HC_PITCH = 32;
+#else
         constexpr int XG_PITCH = 132, HC_PITCH = 36;
+#endif
         // The epilogue's global reads are requested FIRST -- the x-gate tile (16 float4 per lane) and the lane's 16 previous cell values;
         // the per-row weight scales were fetched before the K loop -- so that their latency runs under the staging of the rank-1 operands and the rank-1 loop
         // below instead of being exposed behind them (three dependent global round trips per tile before: ~2-3 us each of the tile's
@@ -614,7 +647,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        constexpr int XG_PRE = SP_XG_PRE;                  // float4s of the x-gate tile requested ahead of the rank-1 phase
+        // same-box A/B (make timing TIMING_EXTRA=-DSP_XG_PRE=8 against 0, three interleaved rounds): 311.3 vs 311.1 ms per step, fused launch
+        // 3.84 vs 3.83 ms -- neutral, and 8 costs 23 VGPRs (254 of 256; 12 spill): the default requests the tile after the rank-1 phase
+        constexpr int XG_PRE = SP_XG_PRE;
         load_xg(0, XG_PRE);
         float cpv[4][4];
 #pragma unroll
@@ -875,6 +910,8 @@ struct HWArgs {
     float alpha;
     int beta;
     uint32_t x_bytes, y_bytes;
+    const int* row_last;   // batched form (one item per sample): items with row_last[item] < row_step have an all-zero dY -> zero result, no work
+    int row_step;
 };
 
 constexpr int HWA_ROW = 1024, HWB_ROW = 512;
@@ -930,6 +967,16 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     }
     const float sx_dev = p.sx_vec ? 1.f : p.sx[0], sy_dev = p.sy_vec ? 1.f : p.sy[0];      // requested first, used by the epilogue (see h2_kernel)
     const int co0 = tmi * 256, n0 = tn * 128;
+    if (p.batched && p.row_last != nullptr && p.row_last[split] < p.row_step) {      // (scalar) this sample's dY is exactly zero
+        if (!p.beta) {
+            float* o = p.out + (int64_t)split * p.slab_stride;
+            for (int i = t; i < 256 * 128; i += 512) {
+                const int co = co0 + i / 128, n = n0 + i % 128;
+                if (co < p.Co && n < p.Nvalid) o[(int64_t)co * p.ldo + n] = 0.f;
+            }
+        }
+        return;
+    }
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
     const int64_t m_end = min(p.M, m_begin + p.rows_per_split);
     const int nkt = (int)((m_end - m_begin + 31) / 32);
@@ -1350,6 +1397,10 @@ struct HW2Args {
     int M;                         // pixels per segment
     int64_t slab_stride;
     uint32_t x_bytes;
+    // Row sparsity of the output gradient (see H2Args): segment g is decode step seg_step[g]; the pixels of a sample with
+    // row_last[img] < seg_step[g] carry an exactly-zero dY and are skipped by the K loop (whole samples: Ho * Wo % 32 == 0).
+    const int* row_last;
+    int seg_step[HW_MAXSEG];
 };
 constexpr int HW2_ROW = 1024, HW2_OP = 32 * HW2_ROW, HW2_STAGE = 2 * HW2_OP;      // 65536 per stage
 constexpr int HW2_LDS = 8 * 32 * 132 * 4;                                        // 135168: the epilogue's staging > the 2-stage ring
@@ -1370,7 +1421,23 @@ __global__ __launch_bounds__(512, 2) void hw2_kernel(HW2Args p) {
     const int co0 = tmi * 256, n0 = tn * 256;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nkt = (m_end - m_begin) >> 5;
+    const int PP = p.Ho * p.Wo;                                   // pixels per sample
+    // samples of this pixel range whose dY rows are exactly zero at this decode step are skipped (bit b of `skip` = sample b_first + b)
+    const int b_first = m_begin / PP;
+    uint32_t skip = 0;
+    int nkt = (m_end - m_begin) >> 5;
+    if (p.row_last != nullptr) {
+        const int step = p.seg_step[seg];
+        const int b_last = (m_end - 1) / PP;
+        if (b_last - b_first < 32) {
+            nkt = 0;
+            for (int b = b_first; b <= b_last; ++b) {
+                const int lo = max(m_begin, b * PP), hi = min(m_end, (b + 1) * PP);
+                if (p.row_last[b] < step) skip |= 1u << (b - b_first);
+                else nkt += (hi - lo) >> 5;
+            }
+        }
+    }
 
     // loader: LDS piece (wave + 8 j) = pixel row r = wave + 8 j of the K-tile, lane = 16-byte chunk position 0..63 of its 1 KB
     uint32_t a_voff[4], b_rel[4];
@@ -1394,6 +1461,15 @@ __global__ __launch_bounds__(512, 2) void hw2_kernel(HW2Args p) {
     int ld_y = (m_begin - ld_b * p.Ho * p.Wo) / p.Wo;
     int ld_x0 = m_begin - (ld_b * p.Ho + ld_y) * p.Wo;
     int ld_m = m_begin;
+    auto skip_samples = [&]() {          // move the loader to the first pixel of the next sample that is not skipped (scalar)
+        while (skip && ld_m < m_end && ((skip >> (ld_b - b_first)) & 1u)) {
+            ++ld_b;
+            ld_y = 0;
+            ld_x0 = 0;
+            ld_m = ld_b * PP;
+        }
+    };
+    skip_samples();
     auto issue_tile = [&](int stage) {
         unsigned char* st = smem + stage * HW2_STAGE;
         const unsigned char* baseA = Yp + (int64_t)ld_m * (4 * (int64_t)p.ldy);                          // scalar
@@ -1413,6 +1489,7 @@ __global__ __launch_bounds__(512, 2) void hw2_kernel(HW2Args p) {
             if (++ld_y == p.Ho) {
                 ld_y = 0;
                 ++ld_b;
+                skip_samples();
             }
         }
     };
@@ -1715,17 +1792,26 @@ __global__ __launch_bounds__(256) void colamax_partial_kernel(const float* x, in
         }
     }
 }
+// stage 2: 32 columns per block, 8 row groups of the partial rows per column (one thread per column walked 512 partial rows
+// serially: 120 us per launch), combined in LDS
 __global__ __launch_bounds__(256) void colamax_final_kernel(const float* partial, int nblk, int C, float* col_scale) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
     float m = 0.f;
-    for (int b = 0; b < nblk; ++b) m = fmaxf(m, partial[(int64_t)b * C + c]);
-    // An all-zero channel (a dead ReLU channel, the gradient columns of a head no sample selected) gets a HUGE scale, not 1: its planes
-    // are zero either way, but the weight operand that absorbs the vector divides its entries for this channel by the scale -- with
-    // scale 1 those entries (which multiply zeros) would be 2^13 .. 2^24 times larger than the entries that matter and set the
-    // weight row's scale, i.e. take the significant bits away from every useful entry of the row (found as a 5e-4 error of the
-    // LSTM bias gradients on the bench path: tests/diagnostics/head_grad_probe.py).
-    col_scale[c] = m > 0.f ? scale_of(__float_as_uint(m)) : 0x1p100f;
+    if (c < C)
+        for (int b = rg; b < nblk; b += 8) m = fmaxf(m, partial[(int64_t)b * C + c]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) m = fmaxf(m, sh[k * 32 + (threadIdx.x & 31)]);
+        // An all-zero channel (a dead ReLU channel, the gradient columns of a head no sample selected) gets a HUGE scale, not 1: its
+        // planes are zero either way, but the weight operand that absorbs the vector divides its entries for this channel by the scale
+        // -- with scale 1 those entries (which multiply zeros) would be 2^13 .. 2^24 times larger than the entries that matter and set
+        // the weight row's scale, i.e. take the significant bits away from every useful entry of the row (found as a 5e-4 error of the
+        // LSTM bias gradients on the bench path: tests/diagnostics/head_grad_probe.py).
+        col_scale[c] = m > 0.f ? scale_of(__float_as_uint(m)) : 0x1p100f;
+    }
 }
 
 // x [rows][C] (C % 16 == 0) -> planes of x[r][c] * col_scale[c]
@@ -1861,7 +1947,7 @@ extern "C" int sp_split2_f16_cols(const float* x, int64_t rows, int C_, void* ou
     const int nblk = colamax_blocks(rows, C_);
     hipLaunchKernelGGL(colamax_partial_kernel, dim3(nblk), dim3(256), 0, s, x, rows, C_, (float*)scratch);
     SP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colamax_final_kernel, dim3((unsigned)sp_cdiv(C_, 256)), dim3(256), 0, s, (const float*)scratch, nblk, C_, col_scale);
+    hipLaunchKernelGGL(colamax_final_kernel, dim3((unsigned)sp_cdiv(C_, 32)), dim3(256), 0, s, (const float*)scratch, nblk, C_, col_scale);
     SP_LAUNCH_CHECK();
     const int64_t n4 = rows * (C_ / 4);
     const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>(sp_cdiv(n4, 256), 4096));
@@ -1894,6 +1980,8 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     H2Args a{};
     a.X = (const uint16_t*)Xs; a.W = (const uint16_t*)Ws; a.bias = bias; a.C = out;
     a.sx = x_scale; a.sw = w_scale; a.sw_rows = d->w_scale_rows ? 1 : 0;
+    // row sparsity: the data gradient of a conv (tiles inside one sample) or a batched forward GEMM with one item per sample
+    a.row_last = ((d->mode == 1 && d->nbatch == 1) || (d->mode == 0 && d->nbatch > 1)) ? d->row_last : nullptr; a.row_step = d->row_step;
     a.M = rows_b * d->nbatch;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->ldc;
@@ -2037,6 +2125,7 @@ static int conv_wgrad_f16(const sp_wgrad_desc* d, const void* Xsplit, const floa
     a.sx = x_scale; a.sy = y_scale;
     a.sx_vec = d->x_scale_vec ? 1 : 0; a.sy_vec = d->y_scale_vec ? 1 : 0;
     if (batched && (a.sx_vec || a.sy_vec)) return SP_EINVAL;      // per-channel scales: one vector per GEMM
+    a.row_last = batched ? d->row_last : nullptr; a.row_step = d->row_step;
     a.M = rows_b * d->nbatch;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.ldy = d->ldy;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
@@ -2113,10 +2202,14 @@ extern "C" int64_t sp_conv_wgrad_f16x2_multi_workspace(const sp_wgrad_desc* d, i
 }
 extern "C" int sp_conv_wgrad_f16x2_multi(const sp_wgrad_desc* d, int nseg, const void* const* Xsplits, const float* const* x_scales,
                                          const void* const* dYsplits, const float* const* y_scales, float* dW, void* workspace,
-                                         void* stream) {
+                                         const int* row_last, const int* seg_steps, void* stream) {
     if (!d || !Xsplits || !x_scales || !dYsplits || !y_scales || !dW || !workspace) return SP_ENULL;
     if (!hw2_applies(d, nseg)) return SP_EINVAL;
+    if ((row_last != nullptr) != (seg_steps != nullptr)) return SP_ENULL;      // both or neither
     HW2Args a{};
+    a.row_last = row_last;
+    if (seg_steps)
+        for (int g = 0; g < nseg; ++g) a.seg_step[g] = seg_steps[g];
     HWScales sc{};
     for (int g = 0; g < nseg; ++g) {
         if (!Xsplits[g] || !dYsplits[g] || !x_scales[g] || !y_scales[g]) return SP_ENULL;

@@ -305,7 +305,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const fl
                                                        const float* c_prev, const float* c_out, int64_t rows, int C,
                                                        float* dpre, float* dc_prev, unsigned* dpre_amax, unsigned* dcp_amax,
                                                        const unsigned* dh_amax, const unsigned* dc_amax, float c_bound,
-                                                       float cprev_bound, uint16_t* planes, float* dpre_scale) {
+                                                       float cprev_bound, uint16_t* planes, float* dpre_scale,
+                                                       const int* row_last, int row_step, int row_P) {
+    // row_last (nullable): samples with row_last[r / row_P] < row_step receive no loss gradient at this decode step or any later one
+    // (loss masks): dh and dc are exactly zero there and so is every output -- written as zeros without reading the five inputs
     __shared__ float sh4[4];
     float dmx = 0.f, cmx = 0.f;
     const int C4 = C / 4;
@@ -325,7 +328,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* dh, const fl
         const int64_t r = live ? idx / C4 : 0;
         const int c = live ? (int)(idx - r * C4) * 4 : 0;
         float4 di = make_float4(0.f, 0.f, 0.f, 0.f), df = di, dov = di, dg = di;
-        if (live) {
+        const bool active = !row_last || row_last[r / row_P] >= row_step;
+        if (live && !active) {
+            if (dpre) {
+                float* pd = dpre + r * 4 * C + c;
+                *reinterpret_cast<float4*>(pd) = di;
+                *reinterpret_cast<float4*>(pd + C) = di;
+                *reinterpret_cast<float4*>(pd + 2 * C) = di;
+                *reinterpret_cast<float4*>(pd + 3 * C) = di;
+            }
+            *reinterpret_cast<float4*>(dc_prev + r * C + c) = di;
+        }
+        if (live && active) {
             const float* pgt = gates + r * 4 * C + c;
             const float4 gi = *reinterpret_cast<const float4*>(pgt), gf = *reinterpret_cast<const float4*>(pgt + C);
             const float4 go = *reinterpret_cast<const float4*>(pgt + 2 * C), gg = *reinterpret_cast<const float4*>(pgt + 3 * C);
@@ -768,21 +782,31 @@ extern "C" int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const flo
                                        0.f, 0.f, nullptr, nullptr, stream);
 }
 
+extern "C" int sp_lstm_pointwise_bwd_rows(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                                          const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
+                                          unsigned* dpre_amax, unsigned* dcp_amax, const unsigned* dh_amax,
+                                          const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
+                                          float* dpre_scale, const int* row_last, int row_step, int rows_per_sample, void* stream) {
+    if (!gates || !c_out || (!dpre && !planes) || !dc_prev) return SP_ENULL;      // dpre may be NULL when the split form is written
+    if (C % 4) return SP_EINVAL;
+    if (planes && (!dpre_scale || C % 256 || ((uintptr_t)planes & 15) || (dh && !dh_amax) || (dc && !dc_amax))) return SP_EINVAL;
+    if (row_last && (rows_per_sample < 1 || rows % rows_per_sample)) return SP_EINVAL;
+    SP_RESET_AMAX(dpre_amax, stream);
+    SP_RESET_AMAX(dcp_amax, stream);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
+                       c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax, dcp_amax, dh_amax, dc_amax, c_bound, cprev_bound,
+                       (uint16_t*)planes, dpre_scale, row_last, row_step, row_last ? rows_per_sample : 1);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 extern "C" int sp_lstm_pointwise_bwd_split(const float* dh, const float* dc, const float* gates, const float* c_prev,
                                            const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
                                            unsigned* dpre_amax, unsigned* dcp_amax, const unsigned* dh_amax,
                                            const unsigned* dc_amax, float c_bound, float cprev_bound, void* planes,
                                            float* dpre_scale, void* stream) {
-    if (!gates || !c_out || (!dpre && !planes) || !dc_prev) return SP_ENULL;      // dpre may be NULL when the split form is written
-    if (C % 4) return SP_EINVAL;
-    if (planes && (!dpre_scale || C % 256 || ((uintptr_t)planes & 15) || (dh && !dh_amax) || (dc && !dc_amax))) return SP_EINVAL;
-    SP_RESET_AMAX(dpre_amax, stream);
-    SP_RESET_AMAX(dcp_amax, stream);
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
-                       c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax, dcp_amax, dh_amax, dc_amax, c_bound, cprev_bound,
-                       (uint16_t*)planes, dpre_scale);
-    SP_LAUNCH_CHECK();
-    return SP_OK;
+    return sp_lstm_pointwise_bwd_rows(dh, dc, gates, c_prev, c_out, rows, C, dpre, dc_prev, dpre_amax, dcp_amax, dh_amax, dc_amax, c_bound,
+                                      cprev_bound, planes, dpre_scale, nullptr, 0, 1, stream);
 }
 
 extern "C" int sp_im2col3x3_1ch(const float* maps, int R, int H, int W, int koff, int ldk, float* col, void* stream) {

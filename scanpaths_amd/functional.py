@@ -85,7 +85,8 @@ def _apply_config():
     for name, key in (("GRAD_MERGE", "grad_merge"), ("BN_SPLIT", "bn_split"), ("BN_SKIP_DX", "bn_skip_dx"), ("BN_SKIP_Z", "bn_skip_z"),
                       ("LSTM_BWD_SPLIT", "lstm_bwd_split"), ("RANK1_DSP_SPLIT", "rank1_dsp_split"), ("RANK1_DWC_SPLIT", "rank1_dwc_split"),
                       ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
-                      ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single")):
+                      ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single"),
+                      ("ROW_SPARSITY", "row_sparsity")):
         g[name] = bool(c[key])
 
 
@@ -95,7 +96,39 @@ _apply_config()
 # how often each fused pass ran (tests assert that the benchmark's kernel path, not a fallback, is the one under test)
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
-                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0}
+                 "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
+                 "row_sparse_bwd": 0}
+
+
+# ---- row sparsity of the backward pass implied by the loss masks (scanpath_loss(skip_masked_backward=True)) ---------------------------
+# A sample whose scanpath ended at step L receives no loss gradient at any decode step t > L (the loss multiplies by action_masks /
+# duration_masks, AiR/models/loss.py:10-14,27-32; AiR/train.py:190-197), and nothing of sample b reaches another sample in the decoder:
+# the whole backward recurrence of (b, t > L_b) is EXACTLY zero.  The reference computes those zeros densely; here the loss leaves
+# `last[b]` (device int32, no host sync) in this context for the duration of ITS backward pass and the three kernels that carry the
+# recurrence's cost consult it: the cell backward writes zeros without reading, the h-gate conv's data gradient writes zero tiles without
+# multiplying, its deferred weight gradient skips those samples' pixels.  With scanpath lengths uniform in 1..T that is 44 % of the
+# (sample, step) pairs.  Only valid when the loss is the ONLY consumer of the model's outputs -- hence opt-in at the loss call.
+_ROWS = None
+
+
+class RowsCtx:
+    __slots__ = ("last", "B")
+
+    def __init__(self, last):
+        self.last, self.B = last, int(last.numel())
+
+
+def rows_ctx(step, nsamples):
+    """the active row-sparsity context if this op belongs to decode step `step` of a batch of nsamples samples, else None"""
+    rc = _ROWS
+    if rc is None or step is None or rc.B != nsamples or not ROW_SPARSITY:
+        return None
+    return rc
+
+
+def _clear_rows():
+    global _ROWS
+    _ROWS = None
 
 
 def reset_fusion_counts():
@@ -310,7 +343,7 @@ def _b3_pays(M, N, K, Kc, nbatch=1, a_elems=None, free_a=False):
 
 
 def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1, mode=0,
-              alpha=1.0, beta=0, relu=0, stats=None):
+              alpha=1.0, beta=0, relu=0, stats=None, rows=None):
     """implicit-GEMM conv / dgrad on split operands (SplitOperand, or a raw split-3 buffer)"""
     if not isinstance(Xs, SplitOperand):
         Xs, Ws = SplitOperand(Xs, None, "bf16x3"), SplitOperand(Ws, None, "bf16x3")
@@ -319,6 +352,8 @@ def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, l
                  int(relu), 1, 0, 0, 0, 0, None)
     f16 = Xs.scheme == "f16x2"
     xscale = Xs.scale
+    if f16 and rows is not None and mode == 1:      # (RowsCtx, step): zero tiles for samples without loss gradient at this decode step
+        d.row_last, d.row_step = rows[0].last.data_ptr(), int(rows[1])
     if f16:
         d.w_scale_rows = int(Ws.kind == "rows")
         if Xs.kind == "cols":      # the per-channel scales of the activation operand live in the weight operand
@@ -344,7 +379,8 @@ def _igemm_b3(Xs, Ws, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, l
     M = N_img * Ho * Wo
     K = KH * KW * Kc
     pre = ("h1" if THROUGHPUT_MODE else "h2") if f16 else "b3"
-    key = (pre + ("_fwd" if mode == 0 else "_dgrad"), M, Nout, K, f"{KH}x{KW}", 1)
+    sparse = f16 and rows is not None and mode == 1      # "_rows": the launch skips samples without loss gradient (bench.py scales its FLOPs)
+    key = (pre + ("_fwd" if mode == 0 else "_dgrad") + ("_rows" if sparse else ""), M, Nout, K, f"{KH}x{KW}", 1)
     hip.TIMER.bracket(key, 2.0 * M * Nout * K, launch)
 
 
@@ -387,7 +423,7 @@ def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, st
             FUSION_COUNTS["wgrad_multi"] += 1
             one = lambda t: (C.c_void_p * 1)(t.data_ptr())
             check(L.sp_conv_wgrad_f16x2_multi(C.byref(d), 1, one(Xs.buf), one(Xs.scale), one(dYs.buf), one(dYs.scale), ptr(dW), ptr(ws),
-                                              hip.stream()), "sp_conv_wgrad_f16x2_multi")
+                                              None, None, hip.stream()), "sp_conv_wgrad_f16x2_multi")
         elif f16:
             fn = L.sp_conv_wgrad_f16x1 if THROUGHPUT_MODE else L.sp_conv_wgrad_f16x2
             check(fn(C.byref(d), ptr(Xs.buf), ptr(Xs.scale), ptr(dYs.buf), ptr(dYs.scale), ptr(dW), ptr(ws), hip.stream()),
@@ -613,9 +649,10 @@ def _out_hw(H, W, KH, KW, stride, pad, dil):
 # ----------------------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None, bn_stats=False, grad_store=None, grad_accum=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, relu, wcache=None, bn_stats=False, grad_store=None, grad_accum=None, step=None):
         # grad_store / grad_accum: GradMerge of a block input -- leave the input gradient there / accumulate into what is there
-        ctx.grad_store, ctx.grad_accum = grad_store, grad_accum
+        # step: the decode step this application belongs to (row sparsity of its backward, see rows_ctx)
+        ctx.grad_store, ctx.grad_accum, ctx.step = grad_store, grad_accum, step
         defer = wcache.get("defer") if isinstance(wcache, dict) else None       # DeferredWgrad of a weight applied T times
         ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
         ctx.dy_token = None
@@ -688,11 +725,11 @@ class _Conv2d(Function):
             check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
             dy = dyr
         dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                accum=ctx.grad_accum, defer_final=ctx.defer_final)
+                                accum=ctx.grad_accum, defer_final=ctx.defer_final, step=ctx.step)
         if ctx.grad_store is not None and dx is not None:
             ctx.grad_store.first = dx
         db = _colsum_any(dy, wp.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 
@@ -722,8 +759,10 @@ def _flush_deferred(defer, wp, geom):
     Co, KH, KW, Ci = wp.shape
     dwp = torch.empty_like(wp)
     L = hip.lib()
-    xs0, dys0 = items[0]
-    same = all(x.kind == xs0.kind and y.kind == dys0.kind for x, y in items)
+    xs0, dys0, _ = items[0]
+    same = all(x.kind == xs0.kind and y.kind == dys0.kind for x, y, _ in items)
+    steps = [st for _, _, st in items]
+    rc = _ROWS if (all(st is not None for st in steps) and _ROWS is not None and _ROWS.B == geom["N_img"] and ROW_SPARSITY) else None
     d = WgradDesc(geom["N_img"], geom["Hi"], geom["Wi"], Ci, Ci, geom["Ho"], geom["Wo"], Co, geom.get("ldy", Co), KH, KW, geom["stride"],
                   geom["pad"], geom["dil"], KH * KW * Ci, 0, 1.0, 1, 0, 0, 0)
     d.x_scale_vec, d.y_scale_vec = int(xs0.kind == "cols"), int(dys0.kind == "cols")
@@ -732,25 +771,30 @@ def _flush_deferred(defer, wp, geom):
     if wsb > 0:
         ws = hip.workspace(wsb, wp.device, slot=3)
         arr = lambda ts: (C.c_void_p * nseg)(*[t.data_ptr() for t in ts])
-        Xa, Sxa = arr([x.buf for x, _ in items]), arr([x.scale for x, _ in items])
-        Ya, Sya = arr([y.buf for _, y in items]), arr([y.scale for _, y in items])
+        Xa, Sxa = arr([x.buf for x, _, _ in items]), arr([x.scale for x, _, _ in items])
+        Ya, Sya = arr([y.buf for _, y, _ in items]), arr([y.scale for _, y, _ in items])
+        seg_steps = (C.c_int * nseg)(*steps) if rc is not None else None
+        if rc is not None:
+            FUSION_COUNTS["row_sparse_bwd"] += 1
 
         def launch():
-            check(L.sp_conv_wgrad_f16x2_multi(C.byref(d), nseg, Xa, Sxa, Ya, Sya, ptr(dwp), ptr(ws), hip.stream()), "sp_conv_wgrad_f16x2_multi")
+            check(L.sp_conv_wgrad_f16x2_multi(C.byref(d), nseg, Xa, Sxa, Ya, Sya, ptr(dwp), ptr(ws), ptr(rc.last) if rc is not None else None,
+                                              seg_steps, hip.stream()), "sp_conv_wgrad_f16x2_multi")
         FUSION_COUNTS["wgrad_multi"] += 1
         if hip.TIMER is None:
             launch()
         else:
             M = geom["N_img"] * geom["Ho"] * geom["Wo"]
-            hip.TIMER.bracket(("h2_wgrad_multi", M * nseg, Co, KH * KW * Ci, f"{KH}x{KW}", nseg), 2.0 * M * nseg * Co * KH * KW * Ci, launch)
+            hip.TIMER.bracket(("h2_wgrad_multi" + ("_rows" if rc is not None else ""), M * nseg, Co, KH * KW * Ci, f"{KH}x{KW}", nseg),
+                              2.0 * M * nseg * Co * KH * KW * Ci, launch)
     else:
         g2 = {k: v for k, v in geom.items() if k != "ldy"}
-        for k, (x, y) in enumerate(items):
+        for k, (x, y, _) in enumerate(items):
             _wgrad_b3(x, y, dwp, beta=int(k > 0), ldo=KH * KW * Ci, Ci=Ci, Co=Co, KH=KH, KW=KW, **g2)
     return dwp.permute(0, 3, 1, 2)
 
 
-def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None, defer_final=False):
+def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None, defer_final=False, step=None):
     """data and weight gradient of y = conv(x, wp) (NHWC, physical weight [Co,KH,KW,Ci]); xs: the forward's split x or None;
     accum: GradMerge whose ``first`` (another consumer's gradient of x) the data gradient is added to in place"""
     N, H, W_, Ci = x.shape
@@ -761,13 +805,14 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
     dy_cached = getattr(dy, "_sp_cache", None)       # the producer of dy (a BatchNorm / cell backward) already wrote its split form
     defer = wcache.get("defer") if (DEFER_WGRAD and isinstance(wcache, dict)) else None
     geom = dict(N_img=N, Hi=H, Wi=W_, Ho=Ho, Wo=Wo, stride=stride, pad=pad, dil=dil)
+    rc = rows_ctx(step, N)          # samples whose gradient rows are exactly zero at this decode step (loss masks)
     deferred = False
     if need_dw and defer is not None:
         wsch = _wgrad_scheme(Ci, Co)
         if wsch == "f16x2" and xs is not None and xs.scheme == wsch and \
                 _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=dy_cached is not None and wsch in dy_cached):
             dys = dy_cached[wsch] if (dy_cached is not None and wsch in dy_cached) else split_op(dy, wsch, channel=True)
-            defer.items.append((xs, dys))
+            defer.items.append((xs, dys, step if rc is not None else None))
             deferred = True
     if need_dx:
         beta = 0
@@ -781,7 +826,8 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
                 dys = split_op(dy, channel=True)
             wT = _weight_operand(wp, dys, wcache, transposed=True)
             _igemm_b3(dys, wT, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci,
-                      ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
+                      ldc=Ci, ldw=KH * KW * Co, KH=KH, KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta,
+                      rows=(rc, step) if rc is not None else None)
         else:
             _fp32_required(dy, "the fp32 data-gradient GEMM")
             _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
@@ -828,8 +874,8 @@ def conv_runs_from_split(x_shape, w, stride=1, pad=0, dil=1, need_dw=True) -> bo
     return (not need_dw) or (_wgrad_scheme(Ci, Co) == "f16x2" and _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=True))
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None, bn_stats=False, grad_store=None, grad_accum=None):
-    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache, bn_stats, grad_store, grad_accum)
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, relu=False, wcache=None, bn_stats=False, grad_store=None, grad_accum=None, step=None):
+    return _Conv2d.apply(x, w, bias, stride, pad, dil, relu, wcache, bn_stats, grad_store, grad_accum, step)
 
 
 class _PadLast(Function):
@@ -878,11 +924,32 @@ def _rows(t):   # (nbatch, M, K, ld, batch_stride) of a 2-D / 3-D operand whose 
     return t.shape[0], t.shape[1], t.shape[2], t.stride(1), t.stride(0)
 
 
+class DeferredGemmWgrad:
+    """Weight gradient of a dense layer that is applied T times with the same weight (spatial_embed / semantic_embed and the contracted
+    filters of the rank-1 gate terms: once per memory update / decode step): dW = sum_t dC_t^T A_t is ONE GEMM over the concatenated
+    rows, K = T x rows, at the end of backward instead of T GEMMs with K = rows (32 .. 64) that each write the whole weight-sized
+    gradient (26 .. 56 MB) for a fan-in pass to re-read.  Each application's backward records (A_t, dC_t); the first application of
+    the forward pass -- the last to run in backward -- issues the GEMM, the others return no gradient (pass the weight itself to every
+    application, not fan-out aliases)."""
+    __slots__ = ("items", "claimed")
+
+    def __init__(self):
+        self.items, self.claimed = [], False
+
+    def claim(self) -> bool:
+        first, self.claimed = not self.claimed, True
+        return first
+
+
 class _Gemm(Function):
     """C = relu?(alpha * A @ op(B) + bias).  layout 'nk': B is [N,K] (C = A B^T); 'kn': B is [K,N].
-    A: [M,K] or [Bt,M,K]; B 2-D (shared) or 3-D (batched)."""
+    A: [M,K] or [Bt,M,K]; B 2-D (shared) or 3-D (batched).  defer: DeferredGemmWgrad of a weight applied several times ('nk' only)."""
     @staticmethod
-    def forward(ctx, a, b, bias, layout, alpha, relu):
+    def forward(ctx, a, b, bias, layout, alpha, relu, defer=None):
+        ctx.defer, ctx.defer_final = None, False
+        if defer is not None and ctx.needs_input_grad[1]:
+            assert layout == "nk" and (a.dim() == b.dim() or (a.dim() == 2 and b.dim() == 2)), (layout, a.shape, b.shape)
+            ctx.defer, ctx.defer_final = defer, defer.claim()
         a = a if a.stride(-1) == 1 else a.contiguous()
         b = b if b.is_contiguous() else b.contiguous()
         nb, M, K, lda, sA = _rows(a)
@@ -928,7 +995,18 @@ class _Gemm(Function):
             else:
                 _igemm(dc, b, None, da, N_img=M, Hi=1, Wi=1, Kc=Nn, ldx=Nn, Ho=1, Wo=1, Nout=K, ldc=K, ldw=Nn, mode=0,
                        alpha=alpha, nbatch=nb, sX=M * Nn, sW=sW, sC=M * K)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.defer is not None:
+            ctx.defer.items.append((a, dc))
+            if ctx.defer_final:          # this application runs last in backward: one GEMM over the rows of all recorded applications
+                items, ctx.defer.items, ctx.defer.claimed = ctx.defer.items, [], False
+                ac = torch.cat([x for x, _ in items], -2) if len(items) > 1 else items[0][0]
+                dcc = torch.cat([y for _, y in items], -2) if len(items) > 1 else items[0][1]
+                ac = ac if ac.stride(-1) == 1 else ac.contiguous()
+                nbc, Mc, _, ldac, sAc = _rows(ac)
+                db = torch.empty(b.shape, dtype=torch.float32, device=b.device)
+                _wgrad(ac, dcc, db, N_img=Mc, Hi=1, Wi=1, Ci=K, ldx=ldac, Ho=1, Wo=1, Co=Nn, ldy=Nn, ldo=K, alpha=alpha,
+                       nbatch=nbc, sX=sAc, sY=Mc * Nn, sO=(b.stride(0) if bb else 0))
+        elif ctx.needs_input_grad[1]:
             db = torch.empty(b.shape, dtype=torch.float32, device=b.device)
             if bb or nb == 1:
                 rows, nbt, sAa, sCc, sO = M, nb, sA, M * Nn, (b.stride(0) if bb else 0)
@@ -943,17 +1021,17 @@ class _Gemm(Function):
                        nbatch=nbt, sX=sCc, sY=sAa, sO=sO)
         if has_bias and ctx.needs_input_grad[2]:
             dbias = _colsum_any(dc, Nn)
-        return da, db, dbias, None, None, None
+        return da, db, dbias, None, None, None, None
 
 
-def gemm(a, b, bias=None, layout="nk", alpha=1.0, relu=False):
-    return _Gemm.apply(a, b, bias, layout, alpha, relu)
+def gemm(a, b, bias=None, layout="nk", alpha=1.0, relu=False, defer=None):
+    return _Gemm.apply(a, b, bias, layout, alpha, relu, defer)
 
 
-def linear(x, weight, bias):
-    """nn.Linear on the last dim (weight [out,in])."""
+def linear(x, weight, bias, defer=None):
+    """nn.Linear on the last dim (weight [out,in]); defer: DeferredGemmWgrad shared by the applications of this weight."""
     shp = x.shape
-    y = gemm(x.reshape(-1, shp[-1]), weight, bias, "nk")
+    y = gemm(x.reshape(-1, shp[-1]), weight, bias, "nk", defer=defer)
     return y.view(*shp[:-1], weight.shape[0])
 
 
@@ -1272,7 +1350,8 @@ class _LstmCellRank1(Function):
          pre[b,p,n] = xg + hg + sum_k spcol[b,p,k] * wc[b,n,k]   (n < 3C: the i/f/o gates)
     xg / hg [B,Hm,Wm,4C] (hg may be None at step 0), spcol [B,P,KP], wc [B,3C,KP]."""
     @staticmethod
-    def forward(ctx, xg, hg, c_prev, spcol, wc):
+    def forward(ctx, xg, hg, c_prev, spcol, wc, step=None):
+        ctx.step = step
         xg = xg.contiguous()
         hg = hg.contiguous() if hg is not None else None
         c_prev = c_prev.contiguous() if c_prev is not None else None
@@ -1304,9 +1383,9 @@ class _LstmCellRank1(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[3],
-                                                   ctx.needs_input_grad[4], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan)
+                                                   ctx.needs_input_grad[4], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan, step=ctx.step)
         has_hg, has_c = ctx.has
-        return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc
+        return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc, None
 
 
 def _cell_bounds(c_prev, c):
@@ -1320,7 +1399,8 @@ def _cell_bounds(c_prev, c):
 
 
 
-def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None), skip_fp32=False, fan=None):
+def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None), skip_fp32=False, fan=None,
+                         step=None):
     """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint or -- when bounds of max|dh|, max|dc| and
     max|c| are known -- its 2xfp16 split operand, written by the same pass), c_prev, spcol and wc"""
     dh_h = getattr(dh, "_sp_amax", None) if dh is not None else None
@@ -1336,6 +1416,7 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     dcp = torch.empty_like(c)
     hint, chint = _amax_hint(gates.device), _amax_hint(gates.device)
     rank1_split_ok = P % 256 == 0 and N3 % 32 == 0 and KP <= 32 and KP % 4 == 0 and not THROUGHPUT_MODE
+    rc = rows_ctx(step, B)          # samples without loss gradient at this decode step: zero outputs, inputs not read
     emit = (LSTM_BWD_SPLIT and hint is not None and Cc % 256 == 0 and cbounds[0] is not None and (dh is None or dh_h is not None)
             and (dc is None or dc_h is not None) and _scheme_for(C4) == "f16x2")
     if emit:
@@ -1348,10 +1429,11 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
         if skip:
             FUSION_COUNTS["lstm_skip_dpre"] += 1
             dpre._sp_skipped = True          # guards every fp32 reader this process owns (_fp32_required); the fan-in reads the record
-        check(hip.lib().sp_lstm_pointwise_bwd_split(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, None if skip else ptr(dpre), ptr(dcp),
-                                                    None, _hint_ptr(chint), _hint_ptr(dh_h), _hint_ptr(dc_h), float(cbounds[0]),
-                                                    float(cbounds[1]), ptr(planes), ptr(hint), hip.stream()),
-              "sp_lstm_pointwise_bwd_split")
+        check(hip.lib().sp_lstm_pointwise_bwd_rows(ptr(dh), ptr(dc), ptr(gates), ptr(c_prev), ptr(c), rows, Cc, None if skip else ptr(dpre), ptr(dcp),
+                                                   None, _hint_ptr(chint), _hint_ptr(dh_h), _hint_ptr(dc_h), float(cbounds[0]),
+                                                   float(cbounds[1]), ptr(planes), ptr(hint), ptr(rc.last) if rc is not None else None,
+                                                   int(step) if rc is not None else 0, P, hip.stream()),
+              "sp_lstm_pointwise_bwd_rows")
         dpre._sp_amax = hint
         dpre._sp_cache = {"f16x2": SplitOperand(planes, hint, "f16x2")}
         if skip:
@@ -1376,6 +1458,8 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
             ws = split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")   # [B][KP][3C]: K contiguous, one scale per row
             d = ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
             d.w_scale_rows = 1
+            if rc is not None:          # one item per sample: items without loss gradient at this step are zero tiles
+                d.row_last, d.row_step = rc.last.data_ptr(), int(step)
             check(hip.lib().sp_conv_igemm_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(ws.buf), ptr(ws.scale), None, ptr(dsp),
                                                 hip.stream()), "sp_conv_igemm_f16x2 (batched)")
         else:
@@ -1392,6 +1476,8 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
             ys = dpre._sp_cache["f16x2"]
             xs = split_op(torch.nn.functional.pad(spcol, (0, 32 - KP)), "f16x2")
             d = hip.WgradDesc(1, P // 64, 64, 32, 32, P // 64, 64, N3, C4, 1, 1, 1, 0, 1, KP, 0, 1.0, B, P * 32, P * C4, N3 * KP)
+            if rc is not None:
+                d.row_last, d.row_step = rc.last.data_ptr(), int(step)
             check(L.sp_conv_wgrad_f16x2(C.byref(d), ptr(xs.buf), ptr(xs.scale), ptr(ys.buf), ptr(ys.scale), ptr(dwc), None, hip.stream()),
                   "sp_conv_wgrad_f16x2 (batched)")
         elif KP <= 24:
@@ -1403,8 +1489,8 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     return dpre, dcp, dsp, dwc
 
 
-def lstm_cell_rank1(xg, hg, c_prev, spcol, wc):
-    return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc)
+def lstm_cell_rank1(xg, hg, c_prev, spcol, wc, step=None):
+    return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc, step)
 
 
 
@@ -1426,7 +1512,8 @@ class _GateConvLstm(Function):
     (sp_gateconv_lstm_f16x2), so the [B,Hm,Wm,4C] h-gate tensor is never materialised.  Backward = _LstmCellRank1's followed by
     _Conv2d's (same kernels as the unfused pair)."""
     @staticmethod
-    def forward(ctx, h_prev, w_h, xg, c_prev, spcol, wc, wcache):
+    def forward(ctx, h_prev, w_h, xg, c_prev, spcol, wc, wcache, step=None):
+        ctx.step = step
         h_prev, xg, c_prev = h_prev.contiguous(), xg.contiguous(), c_prev.contiguous()
         spcol, wc = spcol.contiguous(), wc.contiguous()
         N, H, W_, Ci = h_prev.shape
@@ -1486,15 +1573,15 @@ class _GateConvLstm(Function):
     def backward(ctx, dh, dc):
         gates, c_prev, c, spcol, wc, h_prev, wp, xs_buf, xs_scale = ctx.saved_tensors
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
-                                                   ctx.needs_input_grad[5], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan)
+                                                   ctx.needs_input_grad[5], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan, step=ctx.step)
         xs = SplitOperand(xs_buf, xs_scale, *ctx.xs_scheme) if xs_buf is not None else None
         dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                 defer_final=ctx.defer_final)
-        return dhp, dw, dpre, dcp, dsp, dwc, None
+                                 defer_final=ctx.defer_final, step=ctx.step)
+        return dhp, dw, dpre, dcp, dsp, dwc, None, None
 
 
-def gateconv_lstm(h_prev, w_h, xg, c_prev, spcol, wc, wcache=None):
-    return _GateConvLstm.apply(h_prev, w_h, xg, c_prev, spcol, wc, wcache)
+def gateconv_lstm(h_prev, w_h, xg, c_prev, spcol, wc, wcache=None, step=None):
+    return _GateConvLstm.apply(h_prev, w_h, xg, c_prev, spcol, wc, wcache, step)
 
 
 class _Im2col(Function):
@@ -1852,7 +1939,14 @@ def device_sum(x: torch.Tensor) -> torch.Tensor:
 
 class _ScanpathLoss(Function):
     @staticmethod
-    def forward(ctx, z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums):
+    def forward(ctx, z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums, skip_rows=False):
+        ctx.last = None
+        if skip_rows and ROW_SPARSITY:
+            # last[b] = the last decode step at which sample b has a loss term (device, no host sync); -1: none.  Published to the
+            # backward kernels of the decoder for the duration of this loss's backward pass (rows_ctx)
+            Tn = amask.shape[1]
+            act = ((amask > 0) | (dmask > 0)).to(torch.int32)
+            ctx.last = ((act * torch.arange(1, Tn + 1, dtype=torch.int32, device=amask.device)).amax(1) - 1).to(torch.int32).contiguous()
         z, mu, sigma2 = z.contiguous(), mu.contiguous(), sigma2.contiguous()
         gt, amask, dur, dmask = gt.contiguous(), amask.contiguous(), dur.contiguous(), dmask.contiguous()
         B, T, A = z.shape
@@ -1873,6 +1967,10 @@ class _ScanpathLoss(Function):
 
     @staticmethod
     def backward(ctx, g, _ga, _gd):
+        if ctx.last is not None:
+            global _ROWS
+            _ROWS = RowsCtx(ctx.last)
+            torch.autograd.Variable._execution_engine.queue_callback(_clear_rows)      # dropped when this backward pass ends
         dz, dmu, ds2 = ctx.saved_tensors
         g = g.reshape(1).contiguous().to(torch.float32)
         L = hip.lib()
@@ -1881,12 +1979,14 @@ class _ScanpathLoss(Function):
             o = torch.empty_like(t)
             check(L.sp_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), hip.stream()), "sp_scale_by")
             outs.append(o)
-        return outs[0], outs[1], outs[2], None, None, None, None, None, None
+        return outs[0], outs[1], outs[2], None, None, None, None, None, None, None
 
 
-def scanpath_loss(z, mu, sigma2, gt, amask, dur, dmask, lambda1=1.0, mask_sums=None):
+def scanpath_loss(z, mu, sigma2, gt, amask, dur, dmask, lambda1=1.0, mask_sums=None, skip_masked_backward=False):
     """loss, loss_actions, loss_duration (AiR/train.py:192-197).  mask_sums: device tensor
-    [sum(action_masks), sum(duration_masks)]; computed locally when None (single-process semantics)."""
+    [sum(action_masks), sum(duration_masks)]; computed locally when None (single-process semantics).
+    skip_masked_backward: the caller guarantees that this loss is the ONLY consumer of the model's outputs; the backward pass then
+    skips the (sample, step) pairs behind every sample's last masked-in step, whose gradients are exactly zero (see rows_ctx)."""
     if mask_sums is None:
         mask_sums = torch.cat([device_sum(amask), device_sum(dmask)])
-    return _ScanpathLoss.apply(z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums)
+    return _ScanpathLoss.apply(z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums, bool(skip_masked_backward))

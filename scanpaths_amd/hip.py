@@ -37,7 +37,8 @@ class ConvDesc(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_int), ("relu", C.c_int),
                 ("nbatch", C.c_int),
                 ("strideX", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
-                ("ksplit", C.c_int), ("workspace", C.c_void_p), ("w_scale_rows", C.c_int)]
+                ("ksplit", C.c_int), ("workspace", C.c_void_p), ("w_scale_rows", C.c_int),
+                ("row_last", C.c_void_p), ("row_step", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -46,7 +47,7 @@ class WgradDesc(C.Structure):
                 ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
                 ("ldo", C.c_int), ("beta", C.c_int), ("alpha", C.c_float), ("nbatch", C.c_int),
                 ("strideX", C.c_int64), ("strideY", C.c_int64), ("strideO", C.c_int64),
-                ("x_scale_vec", C.c_int), ("y_scale_vec", C.c_int)]
+                ("x_scale_vec", C.c_int), ("y_scale_vec", C.c_int), ("row_last", C.c_void_p), ("row_step", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -66,7 +67,7 @@ SIGNATURES = {
     "sp_split2_f16_cols_workspace": (_L, [_L, _I]),
     "sp_split2_f16_cols": (_I, [_P, _L, _I, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x2_multi_workspace": (_L, [_P, _I]),
-    "sp_conv_wgrad_f16x2_multi": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "sp_conv_wgrad_f16x2_multi": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_igemm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x2_workspace": (_L, [_P]),
     "sp_conv_wgrad_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
@@ -112,6 +113,7 @@ SIGNATURES = {
     "sp_sempool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "sp_lstm_pointwise_bwd_split": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
+    "sp_lstm_pointwise_bwd_rows": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
     "sp_im2col3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_col2im3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_listatt_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),

@@ -329,10 +329,11 @@ class ScanpathModel(nn.Module):
         vfs = list(F.fanout(vf, n_vf)) if vf.requires_grad and n_vf <= 32 else [vf] * n_vf
         Xg = F.conv2d(vfs.pop(), Wx, bias, pad=1)
         Wh = self._cat_phys([L.input_h.weight, L.forget_h.weight, L.output_h.weight, L.memory_h.weight])
-        # contracted-filter weights of the rank-1 gate terms, one [3*512*9, 512] matrix per stream, stacked: the S contractions of a decode
-        # step are ONE batched GEMM (forward, data and weight gradient: 3 x (S - 1) launches per step less)
-        Wr = torch.stack([torch.cat([getattr(L, g + s).weight.permute(0, 2, 3, 1) for g in ("input", "forget", "output")], 0)
-                          .reshape(3 * 512 * 9, 512) for s in self.streams], 0)
+        # contracted-filter weights of the rank-1 gate terms, one [3*512*9, 512] matrix per stream.  (Batching the S contractions of a
+        # decode step into one GEMM was tried: the batched fp32 kernel has no split-K, its data gradient -- M = 32 rows, K = 13 824 --
+        # then runs on 8 workgroups: 354 us instead of 2 x 25 us.)
+        Wr = [torch.cat([getattr(L, g + s).weight.permute(0, 2, 3, 1) for g in ("input", "forget", "output")], 0)
+              .reshape(3 * 512 * 9, 512) for s in self.streams]
         KP = (9 * S + 3) // 4 * 4
         mvf = F.channel_mean(vfs.pop()).view(B * P)
         u_sem, u_spa = self._attention_vectors()
@@ -371,10 +372,17 @@ class ScanpathModel(nn.Module):
             summed by ONE sp_sum_n pass instead of T small read-read-write adds that autograd would launch one by one"""
             return list(F.fanout(t, n)) if (t is not None and t.requires_grad and 1 < n <= 32) else [t] * n
 
-        spw, spb = rep(self.spatial_embed.weight, T), rep(self.spatial_embed.bias, T)
-        sew, seb = rep(self.semantic_embed.weight, T), rep(self.semantic_embed.bias, T)
+        # weights of dense layers applied once per memory update / decode step: their T weight gradients are ONE GEMM over the
+        # concatenated rows at the end of backward (F.DeferredGemmWgrad) -- the weight itself goes to every application
+        grad_on = torch.is_grad_enabled()
+        sp_defer = F.DeferredGemmWgrad() if (grad_on and self.spatial_embed.weight.requires_grad) else None
+        se_defer = F.DeferredGemmWgrad() if (grad_on and self.semantic_embed.weight.requires_grad) else None
+        wr_defer = [F.DeferredGemmWgrad() if (grad_on and w.requires_grad) else None for w in Wr]
+        spw = [self.spatial_embed.weight] * T if sp_defer is not None else rep(self.spatial_embed.weight, T)
+        sew = [self.semantic_embed.weight] * T if se_defer is not None else rep(self.semantic_embed.weight, T)
+        spb, seb = rep(self.spatial_embed.bias, T), rep(self.semantic_embed.bias, T)
         mvfs, u_spas, u_sems = rep(mvf, T), rep(u_spa, T), rep(u_sem, T)
-        Wrs = rep(Wr, T)
+        Wrs = [[w] * T if d is not None else rep(w, T) for w, d in zip(Wr, wr_defer)]
         Wsals, W11s, cbsums, cbs, w2s, b2s = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T), rep(w2, T), rep(b2, T)
 
         def push(amaps, k):       # amaps [S,B,P]; memory update number k (:277-296 / :317-336)
@@ -382,11 +390,11 @@ class ScanpathModel(nn.Module):
             # last step feeds nothing and is not run): T - k aliases -> ONE fan-in pass for its gradient instead of the
             # T - k - 1 small adds autograd issues for a tensor that sits in T - k stacks (~250 launches per step over both lists)
             spf = F.mul_relu(amaps, mvfs.pop())
-            sp_list.append(rep(F.linear(spf.view(S * B, P), spw.pop(), spb.pop()), T - k))
+            sp_list.append(rep(F.linear(spf.view(S * B, P), spw.pop(), spb.pop(), defer=sp_defer), T - k))
             vf3 = vfs.pop().view(B, P, Cc)
             pooled = F.semantic_pool(amaps, vf3) if (S <= 2 and Cc <= 512) else \
                 F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
-            se_list.append(rep(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop()), T - k))
+            se_list.append(rep(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop(), defer=se_defer), T - k))
             sp_mem = F.list_attention(torch.stack([a.pop() for a in sp_list], 0), u_spas.pop())        # [S*B,P]
             se_mem = F.list_attention(torch.stack([a.pop() for a in se_list], 0), u_sems.pop())        # [S*B,C]
             return sp_mem, se_mem
@@ -401,14 +409,15 @@ class ScanpathModel(nn.Module):
             wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight-gradient GEMMs run on a side stream, summed in place
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t in range(T):
-            wcs = F.gemm(se_mem.view(S, B, Cc), Wrs.pop(), None, "nk").unbind(0)        # S x [B, 3*512*9] (unbind: ONE stack in backward)
-            wc = torch.cat([w_.view(B, 3 * 512, 9) for w_ in wcs] + ([zpad] if zpad is not None else []), 2)
+            se = se_mem.view(S, B, Cc).unbind(0)      # (unbind: ONE stack in backward instead of a zero-fill + copy per stream and an add)
+            parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk", defer=wr_defer[s]).view(B, 3 * 512, 9) for s in range(S)]
+            wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
             if F.gateconv_lstm_fusable(h, Wh, spcol):       # the cell as the epilogue of the h-gate conv: no h-gate tensor
-                h, c = F.gateconv_lstm(h, Wh, Xg_t[t], c, spcol, wc, wh_cache)
+                h, c = F.gateconv_lstm(h, Wh, Xg_t[t], c, spcol, wc, wh_cache, step=t)
             else:
-                hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache) if h is not None else None        # step 0: h == 0
-                h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc)
+                hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache, step=t) if h is not None else None        # step 0: h == 0
+                h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc, step=t)
             # h has three consumers (two heads now, the h-gate conv of the next step): one fan-in pass for its gradient
             nuse = 3 if t + 1 < T else 2
             h_sal, h_drt, h = (tuple(F.fanout(h, nuse)) + (None,))[:3] if h.requires_grad else (h, h, h)

@@ -112,6 +112,14 @@ def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
         d = got - ref
         e, floor, nrm = float(d.norm()), float((torch.as_tensor(g32[k]).double() - ref).norm()), float(ref.norm())
         bar = max(10 * floor, 1e-4 * max(nrm, SMALL_NORM * top))
+        if ref.numel() < 64 and k.rsplit(".", 1)[0] + ".weight" in g64:
+            # A scalar / tiny bias gradient is a plain SUM of the upstream gradient over all sites, samples and steps; where that sum
+            # cancels (object_head.drt_layer_1.bias on air_tame_train_T16: 2.6e-3 left of per-step sums of order 0.1) the fp32 noise of
+            # the FORWARD values the terms are computed from (the reference's own fp32 run is 1e-5 of scale off its fp64 run there)
+            # enters undamped: 5.7e-7 on the fp32-MFMA back-end, 7.5e-7 on 2xfp16, 4.7e-7 on 3xbf16 (tests/diagnostics/drt_bias_probe.py;
+            # no ReLU flip, fp64 sums change nothing).  Its uncertainty scales with the upstream gradient, measured by the module's
+            # weight gradient, not with what is left after the cancellation.
+            bar = max(bar, 1e-6 * float(torch.as_tensor(g64[k.rsplit(".", 1)[0] + ".weight"]).double().norm()))
         row = {"case": case, "backend": backend, "param": k, "err": e, "oracle32_err": floor, "norm": nrm, "bar": bar,
                "err_over_norm": e / max(nrm, 1e-300), "err_over_oracle32": e / max(floor, 1e-300), "kinked": False}
         if e > bar and e <= 5e-3 * nrm:
@@ -483,7 +491,7 @@ def test_air_320x512_matches_oracle():
 
 BENCH_PATH_COUNTERS = ("gateconv_lstm", "gateconv_lstm_hplanes", "lstm_bwd_split", "bn_fwd_split", "bn_fwd_split_operand", "bn_skip_z",
                        "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split", "lstm_skip_dpre",
-                       "wgrad_multi")
+                       "wgrad_multi", "row_sparse_bwd")
 
 
 def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
@@ -509,7 +517,8 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     m32 = _build(meta, Hm, Wm).train()
     b32 = {k: v.to(DEV) for k, v in make_batch("AiR", 32, 320, 512, T, seed=seed).items()}
     pred = m32(b32["images"], b32["attention_maps"], b32["performances"])
-    supervised_loss(pred, b32["scanpaths"], b32["durations"], b32["action_masks"], b32["duration_masks"], 1.0)[0].backward()
+    supervised_loss(pred, b32["scanpaths"], b32["durations"], b32["action_masks"], b32["duration_masks"], 1.0,
+                    skip_masked_backward=True)[0].backward()          # as bench.py calls it (the masked-step sparsity of the backward)
     torch.cuda.synchronize()
     bench_counts = {k: F.FUSION_COUNTS[k] for k in BENCH_PATH_COUNTERS}
     del m32, b32, pred
@@ -518,6 +527,7 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     assert bench_counts["lstm_bwd_split"] == T and bench_counts["bn_skip_z"] > 0 and bench_counts["bn_skip_dx"] > 0, bench_counts
     assert bench_counts["rank1_dsp_split"] == T and bench_counts["rank1_dwc_split"] == T and bench_counts["lstm_skip_dpre"] == T, bench_counts
     assert bench_counts["wgrad_multi"] >= 1, bench_counts          # the T - 1 weight gradients of the h-gate conv in ONE launch (hw2_kernel)
+    assert bench_counts["row_sparse_bwd"] == 1, bench_counts       # ... which skips the samples behind their last masked-in step
 
     # ---- the oracle on the host: fp64 and fp32, train (loss + gradients) and eval -- two worker processes side by side ----------
     import concurrent.futures as cf
@@ -543,7 +553,8 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     model = _build(meta, Hm, Wm).train()
     F.reset_fusion_counts()
     pred = model(bd["images"], bd["attention_maps"], bd["performances"])
-    loss, _, _ = supervised_loss(pred, bd["scanpaths"], bd["durations"], bd["action_masks"], bd["duration_masks"], 1.0)
+    loss, _, _ = supervised_loss(pred, bd["scanpaths"], bd["durations"], bd["action_masks"], bd["duration_masks"], 1.0,
+                                 skip_masked_backward=True)
     loss.backward()
     torch.cuda.synchronize()
     got_counts = {k: F.FUSION_COUNTS[k] for k in BENCH_PATH_COUNTERS}
@@ -601,6 +612,54 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     bad = [r for r in rows if r.get("failed")]
     assert not bad, bad[:3]
     assert nargmax >= 0.3 * ntot, (nargmax, ntot)
+
+
+
+def test_masked_step_sparsity_of_the_backward_is_bit_identical_to_the_dense_backward(monkeypatch):
+    """supervised_loss(skip_masked_backward=True): behind a sample's last masked-in decode step every gradient of the decoder's
+    recurrence is exactly zero (the loss multiplies by action_masks / duration_masks, AiR/models/loss.py:10-14,27-32; AiR/train.py:190-197);
+    the cell backward (zeros without reading), the h-gate conv's data gradient (zero tiles without multiplying) and its deferred weight
+    gradient (those samples' pixels skipped, pixel ranges that cut samples) use that -- loss and EVERY parameter gradient must equal the
+    dense backward bit for bit, on the benchmark's kernel path (40x64 map, fused cell, deferred hw2 launch), with scanpaths that end at
+    the first step, in the middle, at the last step, and a sample without any loss term."""
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.synth import make_batch
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3 or F.THROUGHPUT_MODE:
+        pytest.skip("2xfp16 back-end not active")
+    T, NB, seed = 8, 5, 4
+    meta = dict(task="AiR", arch="resnet18", T=T, weight_seed=seed, weight_family="tame")
+    b = {k: v.to(DEV) for k, v in make_batch("AiR", NB, 320, 512, T, seed=seed).items()}
+    lengths = [1, 4, T, 2, 0]                                      # last loss step per sample: 0, 3, T - 1, 1, none
+    am, dm = torch.zeros(NB, T, device=DEV), torch.zeros(NB, T, device=DEV)
+    for i, L in enumerate(lengths):
+        am[i, :L] = 1
+        dm[i, :max(L - 1, 0)] = 1
+    b["action_masks"], b["duration_masks"] = am, dm
+    monkeypatch.setattr(F, "COST_M_SCALE", 32.0 / NB)
+    res = {}
+    for sparse in (False, True):
+        model = _build(meta, 40, 64).train()
+        F.reset_fusion_counts()
+        pred = model(b["images"], b["attention_maps"], b["performances"])
+        loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], am, dm, 1.0, skip_masked_backward=sparse)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert F._ROWS is None                                      # the context never outlives the backward pass
+        assert F.FUSION_COUNTS["row_sparse_bwd"] == int(sparse) and F.FUSION_COUNTS["wgrad_multi"] >= 1, F.FUSION_COUNTS
+        assert F.FUSION_COUNTS["gateconv_lstm"] == T - 1
+        res[sparse] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert res[True][0] == res[False][0]
+    assert res[True][1].keys() == res[False][1].keys()
+    diff = [k for k in res[True][1] if not torch.equal(res[True][1][k], res[False][1][k])]
+    assert not diff, diff[:8]
+    # a second, dense backward afterwards is untouched by the earlier sparse one (the context is gone)
+    model = _build(meta, 40, 64).train()
+    pred = model(b["images"], b["attention_maps"], b["performances"])
+    (pred["all_actions_prob"].sum() + pred["log_normal_mu"].sum()).backward()          # a loss that reads EVERY step: must stay dense
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    g_h = dict(model.named_parameters())["lstm.input_h.weight"].grad
+    assert float(g_h.abs().max()) > 0
 
 
 def test_state_dict_roundtrip_and_no_cpu_path():

@@ -618,6 +618,34 @@ def test_deferred_weight_gradient_of_a_repeated_conv_matches_fp64(wo, co, monkey
         _close(xd.grad.permute(0, 3, 1, 2), xr.grad, 2e-6, "dx")
 
 
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_deferred_weight_gradient_of_a_repeated_dense_layer(batched):
+    """F.DeferredGemmWgrad: a dense layer applied T times with the same weight (spatial_embed / semantic_embed, AiR/models/
+    baseline_attention.py:207-208,279-286; the contracted rank-1 filters, :40-50) gets its weight gradient from ONE GEMM over the
+    concatenated rows of all applications; inputs, bias and data gradients are untouched."""
+    from scanpaths_amd import functional as F
+    dev = _dev()
+    T, M, K, N, S = 4, 24, 96, 160, 2
+    w = _rand(*((S, N, K) if batched else (N, K)), seed=3, scale=0.1)
+    xs = [_rand(*((S, M, K) if batched else (M, K)), seed=10 + t) for t in range(T)]
+    gs = [_rand(*((S, M, N) if batched else (M, N)), seed=20 + t) * (3.0 ** t) for t in range(T)]
+    wr = w.double().requires_grad_(True)
+    xr = [x.double().requires_grad_(True) for x in xs]
+    sum((x @ wr.transpose(-1, -2) * g.double()).sum() for x, g in zip(xr, gs)).backward()
+    wd = w.to(dev).requires_grad_(True)
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    defer = F.DeferredGemmWgrad()
+    loss = 0.0
+    for x, g in zip(xd, gs):
+        loss = loss + (F.gemm(x, wd, None, "nk", defer=defer) * g.to(dev)).sum()
+    loss.backward()
+    assert not defer.items
+    _close(wd.grad, wr.grad, 3e-6, "dW")
+    for a, b in zip(xd, xr):
+        _close(a.grad, b.grad, 3e-6, "dx")
+
+
 def test_fused_amax_hints_equal_the_separate_pass():
     """producers (BN apply / backward, LSTM cell forward / backward) leave max|output| behind for the 2xfp16 operand split:
     the hinted split must be bit-identical to the split that runs its own amax pass, and a tensor without a hint still works"""
