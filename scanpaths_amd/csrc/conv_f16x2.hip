@@ -84,6 +84,12 @@ struct H2Args {
     // a sample (Ho * Wo % 256 == 0) is zero: written as zeros (or left alone under beta) without touching the operands.
     const int* row_last;
     int row_step;
+    // row_nimg > 0 (data gradient, whole tiles per sample, <= 64 samples): LIVE-FIRST tile order.  The plain order hands every XCD a
+    // contiguous range of M-tiles (xcd_remap: 4 samples of the 32 at the benchmark size), so with dead samples the launch lasts as
+    // long as the XCD with the most live samples (measured: 2.39 ms at 56 % live against 3.05 ms dense).  Here the first
+    // nlive * tiles-per-sample * tiles_n workgroups take the tiles of the live samples, dealt to the XCDs in equal contiguous ranges,
+    // and the remaining workgroups write the dead samples' zero tiles.  Which workgroup computes a tile changes, the tile does not.
+    int row_nimg;
 };
 
 // Block tile 256 x 128 x 32, 512 threads = 8 waves (4 along M x 2 along N, wave tile 64x64), 1 workgroup per CU, LDS-DMA
@@ -138,9 +144,33 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     // the two operand scales (device words written by the split kernels): requested FIRST, used by the epilogue -- behind the K loop
     // their latency would be exposed once per workgroup
     const float sx_dev = p.sx[0], sw_dev = p.sw_rows ? 1.f : p.sw[0];
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     int tn, tmi;
-    supertile_map(lid, gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
+    bool mapped = false;
+    if constexpr (MODE == 1 && !LSTM) {
+        if (p.row_nimg > 0) {                          // live-first order (H2Args::row_nimg); everything here is wave-uniform
+            const int mine = lane < p.row_nimg ? p.row_last[lane] : -1;
+            const uint64_t lm = __ballot(lane < p.row_nimg && mine >= p.row_step);
+            const uint64_t all = p.row_nimg == 64 ? ~0ull : ((1ull << p.row_nimg) - 1ull);
+            const int tps = (p.Ho * p.Wo) / HBM;        // tiles per sample
+            const int nlive = __popcll(lm);
+            const int nl = nlive * tps * p.tiles_n;
+            const int bid = blockIdx.x;
+            uint64_t mask;
+            int tml;
+            if (bid < nl) {
+                supertile_map(xcd_remap(bid, nl), nlive * tps, p.tiles_n, tml, tn, CBM);
+                mask = lm;
+            } else {
+                tn = (bid - nl) % p.tiles_n;
+                tml = (bid - nl) / p.tiles_n;
+                mask = all & ~lm;
+            }
+            for (int k = tml / tps; k > 0; --k) mask &= mask - 1ull;      // drop the k lowest set bits: sample = slot-th live / dead one
+            tmi = (__ffsll((unsigned long long)mask) - 1) * tps + tml % tps;
+            mapped = true;
+        }
+    }
+    if (!mapped) supertile_map(xcd_remap(blockIdx.x, gridDim.x), gridDim.x / p.tiles_n, p.tiles_n, tmi, tn, CBM);
     const int64_t m0 = (int64_t)tmi * HBM;
     const int n0 = LSTM ? tn * 32 : tn * HBN;          // LSTM: first CHANNEL of the tile
     if constexpr (!LSTM) {
@@ -1982,6 +2012,8 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
     a.sx = x_scale; a.sw = w_scale; a.sw_rows = d->w_scale_rows ? 1 : 0;
     // row sparsity: the data gradient of a conv (tiles inside one sample) or a batched forward GEMM with one item per sample
     a.row_last = ((d->mode == 1 && d->nbatch == 1) || (d->mode == 0 && d->nbatch > 1)) ? d->row_last : nullptr; a.row_step = d->row_step;
+    a.row_nimg = (a.row_last && d->mode == 1 && d->nbatch == 1 && d->N_img <= 64 && ((int64_t)d->Ho * d->Wo) % HBM == 0 &&
+                  sp_tuning_get(SP_TUNE_ROW_ORDER, 1) == 1) ? d->N_img : 0;
     a.M = rows_b * d->nbatch;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Kc = d->Kc; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Nout = d->Nout; a.ldc = d->ldc;

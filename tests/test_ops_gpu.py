@@ -619,6 +619,44 @@ def test_deferred_weight_gradient_of_a_repeated_conv_matches_fp64(wo, co, monkey
 
 
 
+@pytest.mark.parametrize("nimg,last", [(5, [0, 3, 7, 1, -1]), (8, [9] * 8), (3, [-1, -1, -1]), (12, [0, 5, 2, 7, 7, 1, 4, 6, 0, 3, 5, 2]),
+                                       (64, [(7 * i) % 9 for i in range(64)]), (66, [(5 * i) % 8 for i in range(66)])])
+def test_row_sparse_data_gradient_in_live_first_tile_order_equals_the_dense_launch(nimg, last, monkeypatch):
+    """h2_kernel<dgrad> with row_last / row_step (masked-step sparsity of the backward pass): the tiles of the samples that
+    still receive loss gradient are dealt to the XCDs FIRST and evenly (H2Args::row_nimg), the other workgroups write zero tiles.  Which
+    workgroup computes a tile must not change the tile: the result equals, bit for bit, the dense launch on a gradient whose dead
+    samples' rows are zero -- 0 live samples, all live, live counts that are not multiples of 4 (no super-tiles), 64 samples (full
+    ballot mask), 66 (more than one mask word: the plain order)."""
+    from scanpaths_amd import functional as F
+    monkeypatch.setattr(F, "USE_BF16X3", True)
+    monkeypatch.setattr(F, "SPLIT_SCHEME", "f16x2")
+    monkeypatch.setattr(F, "_b3_pays", lambda M, N, K, Kc, nbatch=1, **kw: nbatch == 1 and Kc % 32 == 0)
+    dev = _dev()
+    H, W, Ci, Co, step = 8, 64, 160, 64, 4                        # 2 tiles of 256 pixels per sample, halo build; 2 N-tiles (ragged)
+    w = _rand(Co, Ci, 3, 3, seed=3, scale=1.0 / math.sqrt(9 * Ci)).to(dev)
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    lastd = torch.tensor(last, dtype=torch.int32, device=dev)
+    live = (lastd >= step).float().view(nimg, 1, 1, 1)
+    dy = _rand(nimg, H, W, Co, seed=7).to(dev) * live              # dead samples: exactly zero rows (what the recurrence produces)
+    x = torch.zeros(nimg, H, W, Ci, device=dev)
+    outs = []
+    for rows in (None, (F.RowsCtx(lastd), step)):
+        dys = F.split_op(dy, channel=True)
+        wT = F._weight_operand(wp, dys, {}, transposed=True)
+        dx = torch.full_like(x, float("nan"))
+        F._igemm_b3(dys, wT, None, dx, N_img=nimg, Hi=H, Wi=W, Kc=Co, ldx=Co, Ho=H, Wo=W, Nout=Ci, ldc=Ci, ldw=9 * Co, KH=3, KW=3,
+                    stride=1, pad=1, dil=1, mode=1, beta=0, rows=rows)
+        outs.append(dx)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
+    dead = [i for i, l in enumerate(last) if l < step]
+    if dead:
+        assert float(outs[1][dead].abs().max()) == 0.0
+    ref = TF.conv_transpose2d(dy.cpu().double().permute(0, 3, 1, 2), w.cpu().double(), padding=1).permute(0, 2, 3, 1)
+    _close(outs[1], ref, 2e-6, "row-sparse dx")
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_deferred_weight_gradient_of_a_repeated_dense_layer(batched):
     """F.DeferredGemmWgrad: a dense layer applied T times with the same weight (spatial_embed / semantic_embed, AiR/models/
