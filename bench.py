@@ -119,6 +119,8 @@ def parse():
     ap.add_argument("--dense-backward", action="store_true",
                     help="do not skip the (sample, decode step) pairs behind a sample's last masked-in step in the backward pass (their gradients "
                          "are exactly zero; default: skipped, results identical -- the line reports the dense time of the same process too)")
+    ap.add_argument("--no-dense-leg", action="store_true",
+                    help="do not time the dense backward after the timed region (kernel traces of the headline step only)")
     ap.add_argument("--force-bucketer", action="store_true",
                     help="1-GPU half of the scaling evidence: run the data-parallel machinery in an RCCL world of ONE (post-accumulate hooks, "
                          "32 MB buckets, async all-reduce on RCCL's stream) and report its cost next to the plain step (JSON key 'ddp')")
@@ -361,7 +363,7 @@ def main():
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
     sparsity = None
-    if args.mode == "train" and world == 1 and sparse_bwd[0]:
+    if args.mode == "train" and world == 1 and sparse_bwd[0] and not args.no_dense_leg:
         # the same step with the dense backward pass (what the reference computes), same process, after the timed region
         sparse_bwd[0] = False
         step()

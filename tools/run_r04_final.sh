@@ -8,7 +8,7 @@ python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pyte
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_nocpu.json 2> $O/bench_nocpu.err
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --dense-backward > $O/bench_dense.json 2> $O/bench_dense.err
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --force-bucketer > $O/bench_bucketer.json 2> $O/bench_bucketer.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-leg > $O/bench_prof.json 2> $O/bench_prof.err
 f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summarize_prof.py "${f%_kernel_trace.csv}" $O/r04 > $O/summ_bench.log 2>&1
 find $O -name "*trace.csv" -delete
 python3 tools/bench_backbone.py > $O/backbone.json 2> $O/backbone.err
