@@ -275,11 +275,21 @@ int sp_pad_lastdim(const float* x, int64_t rows, int Cin, int Cout, float* y, vo
  * fan-in of a tensor consumed by every decode step (x-gate pre-activations), one pass instead of count-1 adds */
 int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out,
              unsigned* out_amax /* nullable: float bits of max|out|, as sp_bn_apply's y_amax */, void* stream);
+/* ... with the masked-step sparsity of the backward pass (as sp_sum_n_mixed_rows below): term k belongs to decode step steps[k] (HOST
+ * array; -1: never skipped) and is exactly zero, hence not read, for a sample b (n / nsamples contiguous elements, a multiple of 4) with
+ * row_last[b] < steps[k] (row_last: device array [nsamples]); both NULL: sp_sum_n. */
+int sp_sum_n_rows(const float* const* inputs, int count, int64_t n, float* out, unsigned* out_amax, const int* row_last, const int* steps,
+                  int nsamples, void* stream);
 /* the same fan-in when some contributions exist only as 2xfp16 split operands (the gate gradient of a ConvLSTM step whose fp32 form
  * was left unwritten, sp_lstm_pointwise_bwd_split with dpre == NULL): inputs[k] != NULL -> fp32 term, else planes[k] / scales[k]
  * (sp_split2_f16 layout, device scale) -> the exact value of the split operand.  n % 16 == 0. */
 int sp_sum_n_mixed(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n, float* out,
                    unsigned* out_amax, void* stream);
+/* ... with the masked-step sparsity of the backward pass (AiR/models/loss.py:10-14,27-32: the loss multiplies by the masks): term k is
+ * the gate gradient of decode step steps[k] (-1: not tied to a step); for a sample b (n / nsamples contiguous elements each, a multiple of
+ * 16) with row_last[b] < steps[k] the term is exactly zero and is not read.  row_last: device array [nsamples], steps: HOST array [count]; both or neither. */
+int sp_sum_n_mixed_rows(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n, float* out,
+                        unsigned* out_amax, const int* row_last, const int* steps, int nsamples, void* stream);
 int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
 /* out = a + b (residual joins in backward), n elements */
 int sp_add(const float* a, const float* b, float* out, int64_t n, void* stream);
@@ -312,6 +322,10 @@ int sp_sempool_fwd(const float* a, const float* vf, int S, int B, int P, int C, 
                    void* stream);
 int sp_sempool_bwd(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C, float alpha,
                    float* da, float* dvf, void* stream);
+/* ... row_last != NULL: samples b with row_last[b] < row_step have an exactly-zero dout (masked-step sparsity of the backward pass): their
+ * da / dvf rows are written as zeros, vf is not read */
+int sp_sempool_bwd_rows(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C, float alpha,
+                        float* da, float* dvf, const int* row_last, int row_step, void* stream);
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
                           unsigned* dpre_amax /* nullable, as y_amax */, void* stream);
@@ -396,6 +410,9 @@ int sp_head_compose11_bwd(const float* dW11, const float* dcbsum, int nheads, in
 int sp_sal_gather_fwd(const float* T, int B, int Hm, int Wm, int ldt, int nsel, const int* hmap, float* Z2, void* stream);
 int sp_sal_gather_bwd(const float* dZ2, int B, int Hm, int Wm, int ldt, int nsel, int nsrc, const int* hmap, float* dT,
                       void* stream);
+/* ... row_last != NULL: samples b with row_last[b] < row_step have an exactly-zero dZ2: their dT rows are zeros, dZ2 is not read */
+int sp_sal_gather_bwd_rows(const float* dZ2, int B, int Hm, int Wm, int ldt, int nsel, int nsrc, const int* hmap, float* dT,
+                           const int* row_last, int row_step, void* stream);
 int sp_drt_direct_fwd(const float* h, const float* W11, const float* cbsum, const int* hmap, int B, int Hm, int Wm, int C,
                       int nsel, float* Dpre, void* stream);
 int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
@@ -403,6 +420,9 @@ int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, const int* hmap
 int64_t sp_drt_direct_bwd_weight_workspace(int B, int Hm, int Wm, int C, int nsel);
 int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
                              int nheads, void* workspace, float* dW11, float* dcbsum, void* stream);
+/* ... row_last != NULL: samples b with row_last[b] < row_step have an exactly-zero dDpre: their slabs are zeros, h is not read */
+int sp_drt_direct_bwd_weight_rows(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
+                                  int nheads, void* workspace, float* dW11, float* dcbsum, const int* row_last, int row_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss (models/loss.py:10-14,27-32; AiR/train.py:192-197) -- value and gradient in one pass.

@@ -772,7 +772,31 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
 struct SumList {
     const float* p[32];
     int n;
+    // row sparsity (masked-step sparsity of the backward pass, see SumListMixed): term k belongs to decode step step[k] and is exactly
+    // zero -- and not read -- for a sample b with row_last[b] < step[k]; quads_per_sample float4 per sample; row_last NULL: dense
+    const int* row_last;
+    int step[32];
+    int64_t quads_per_sample;
 };
+__global__ __launch_bounds__(256) void sum_n_rows_kernel(SumList l, float* o, int64_t n4, unsigned* amax) {
+    __shared__ float sh4[4];
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lastb = l.row_last[i / l.quads_per_sample];
+        double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;      // (fp64 accumulation in list order: the live terms of sum_n_kernel's sum)
+        bool first = true;
+        for (int k = 0; k < l.n; ++k) {
+            if (l.step[k] > lastb) continue;
+            const float4 v = reinterpret_cast<const float4*>(l.p[k])[i];
+            if (first) { ax = v.x; ay = v.y; az = v.z; aw = v.w; first = false; }
+            else { ax += (double)v.x; ay += (double)v.y; az += (double)v.z; aw += (double)v.w; }
+        }
+        const float4 acc = make_float4((float)ax, (float)ay, (float)az, (float)aw);
+        reinterpret_cast<float4*>(o)[i] = acc;
+        mx = amax4(mx, acc.x, acc.y, acc.z, acc.w);
+    }
+    if (amax) block_amax_commit(mx, amax, sh4);
+}
 __global__ __launch_bounds__(256) void sum_n_kernel(SumList l, float* o, int64_t n4, unsigned* amax) {
     __shared__ float sh4[4];
     float mx = 0.f;
@@ -800,6 +824,11 @@ struct SumListMixed {
     const uint16_t* pl[32];      // split form (used when f[k] is NULL)
     const float* sc[32];
     int n;
+    // row sparsity (masked-step sparsity of the backward pass): term k is the gate gradient of decode step step[k]; for a sample b with
+    // row_last[b] < step[k] it is exactly zero and is not read.  groups_per_sample 16-element groups per sample; row_last NULL: dense.
+    const int* row_last;
+    int step[32];
+    int64_t groups_per_sample;
 };
 __global__ __launch_bounds__(256) void sum_n_mixed_kernel(SumListMixed l, float* o, int64_t n16, unsigned* amax) {
     __shared__ float sh4[4];
@@ -809,7 +838,9 @@ __global__ __launch_bounds__(256) void sum_n_mixed_kernel(SumListMixed l, float*
         double acc[16];                      // fp64 accumulation over the (up to 32) contributions, see sum_n_kernel
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+        const int lastb = l.row_last ? l.row_last[i / l.groups_per_sample] : 0x7fffffff;
         for (int k = 0; k < l.n; ++k) {
+            if (l.step[k] > lastb) continue;         // an exactly-zero term
             if (l.f[k]) {
                 const float4* q = reinterpret_cast<const float4*>(l.f[k]) + i * 4;
 #pragma unroll
@@ -1095,28 +1126,43 @@ extern "C" int sp_add(const float* a, const float* b, float* out, int64_t n, voi
     return SP_OK;
 }
 
-extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, unsigned* out_amax, void* stream) {
+extern "C" int sp_sum_n_rows(const float* const* inputs, int count, int64_t n, float* out, unsigned* out_amax, const int* row_last,
+                             const int* steps, int nsamples, void* stream) {
     if (!inputs || !out) return SP_ENULL;
     if (count < 1 || count > 32 || n % 4) return SP_EINVAL;
+    if ((row_last != nullptr) != (steps != nullptr)) return SP_ENULL;
+    if (row_last && (nsamples < 1 || n % nsamples || (n / nsamples) % 4)) return SP_EINVAL;      // whole float4 per sample
     SumList l;
     l.n = count;
+    l.row_last = row_last;
+    l.quads_per_sample = row_last ? n / nsamples / 4 : 1;
     for (int k = 0; k < count; ++k) {
         if (!inputs[k]) return SP_ENULL;
         l.p[k] = inputs[k];
+        l.step[k] = steps ? steps[k] : -1;
     }
     SP_RESET_AMAX(out_amax, stream);
-    hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4, out_amax);
+    if (row_last) hipLaunchKernelGGL(sum_n_rows_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4, out_amax);
+    else hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, l, out, n / 4, out_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
+extern "C" int sp_sum_n(const float* const* inputs, int count, int64_t n, float* out, unsigned* out_amax, void* stream) {
+    return sp_sum_n_rows(inputs, count, n, out, out_amax, nullptr, nullptr, 0, stream);
+}
 
-extern "C" int sp_sum_n_mixed(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n,
-                              float* out, unsigned* out_amax, void* stream) {
+extern "C" int sp_sum_n_mixed_rows(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n,
+                                   float* out, unsigned* out_amax, const int* row_last, const int* steps, int nsamples, void* stream) {
     if (!inputs || !planes || !scales || !out) return SP_ENULL;
     if (count < 1 || count > 32 || n % 16) return SP_EINVAL;
+    if ((row_last != nullptr) != (steps != nullptr)) return SP_ENULL;
+    if (row_last && (nsamples < 1 || n % nsamples || (n / nsamples) % 16)) return SP_EINVAL;      // whole 16-element groups per sample
     SumListMixed l;
     l.n = count;
+    l.row_last = row_last;
+    l.groups_per_sample = row_last ? n / nsamples / 16 : 1;
     for (int k = 0; k < count; ++k) {
+        l.step[k] = steps ? steps[k] : -1;
         if (!inputs[k] && (!planes[k] || !scales[k])) return SP_ENULL;
         if (!inputs[k] && ((uintptr_t)planes[k] & 15)) return SP_EINVAL;
         l.f[k] = inputs[k];
@@ -1127,6 +1173,10 @@ extern "C" int sp_sum_n_mixed(const float* const* inputs, const void* const* pla
     hipLaunchKernelGGL(sum_n_mixed_kernel, dim3(ew_blocks(n / 16)), dim3(256), 0, (hipStream_t)stream, l, out, n / 16, out_amax);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+extern "C" int sp_sum_n_mixed(const float* const* inputs, const void* const* planes, const float* const* scales, int count, int64_t n,
+                              float* out, unsigned* out_amax, void* stream) {
+    return sp_sum_n_mixed_rows(inputs, planes, scales, count, n, out, out_amax, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int sp_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream) {

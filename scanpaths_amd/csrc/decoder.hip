@@ -102,12 +102,20 @@ __global__ __launch_bounds__(256) void sempool_finish_kernel(const float* __rest
 __global__ __launch_bounds__(256) void sempool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ out,
                                                           const float* __restrict__ a, const float* __restrict__ vf, int S,
                                                           int B, int P, int C, float alpha, float* __restrict__ da,
-                                                          float* __restrict__ dvf) {
+                                                          float* __restrict__ dvf, const int* __restrict__ row_last, int row_step) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
     const int nq = C / 4;                         // channel quads; lane handles quads lane, lane+64
     for (int64_t bp = wave; bp < (int64_t)B * P; bp += nwaves) {
         const int b = (int)(bp / P), p = (int)(bp % P);
+        if (row_last && row_last[b] < row_step) {      // row sparsity: dz of this sample is exactly zero -> zero gradients, vf not read (wave-uniform)
+            for (int q = lane; q < nq; q += 64) *reinterpret_cast<f32x4*>(dvf + bp * C + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (lane == 0) {
+                da[((int64_t)0 * B + b) * P + p] = 0.f;
+                if (S > 1) da[((int64_t)1 * B + b) * P + p] = 0.f;
+            }
+            continue;
+        }
         const float a0 = a[((int64_t)0 * B + b) * P + p], a1 = S > 1 ? a[((int64_t)1 * B + b) * P + p] : 0.f;
         float d0 = 0.f, d1 = 0.f;
         for (int q = lane; q < nq; q += 64) {
@@ -765,14 +773,18 @@ extern "C" int sp_sempool_fwd(const float* a, const float* vf, int S, int B, int
     return SP_OK;
 }
 
-extern "C" int sp_sempool_bwd(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C,
-                              float alpha, float* da, float* dvf, void* stream) {
+extern "C" int sp_sempool_bwd_rows(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C,
+                                   float alpha, float* da, float* dvf, const int* row_last, int row_step, void* stream) {
     if (!dout || !out || !a || !vf || !da || !dvf) return SP_ENULL;
     if (S < 1 || S > 2 || B < 1 || P < 1 || C % 4) return SP_EINVAL;
     hipLaunchKernelGGL(sempool_bwd_kernel, dim3(ew_blocks((int64_t)B * P * 64)), dim3(256), 0, (hipStream_t)stream, dout, out, a,
-                       vf, S, B, P, C, alpha, da, dvf);
+                       vf, S, B, P, C, alpha, da, dvf, row_last, row_step);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+extern "C" int sp_sempool_bwd(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C,
+                              float alpha, float* da, float* dvf, void* stream) {
+    return sp_sempool_bwd_rows(dout, out, a, vf, S, B, P, C, alpha, da, dvf, nullptr, 0, stream);
 }
 
 extern "C" int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,

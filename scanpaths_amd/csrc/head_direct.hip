@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void sal_gather_fwd_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void sal_gather_bwd_kernel(const float* __restrict__ dZ2, int B, int Hm, int Wm, int ldt,
                                                              int nsel, int nsrc, const int* __restrict__ hmap,
-                                                             float* __restrict__ dT) {
+                                                             float* __restrict__ dT, const int* __restrict__ row_last, int row_step) {
     const int P = Hm * Wm, J = nsel * 2;
     const int64_t n = (int64_t)B * P * ldt;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void sal_gather_bwd_kernel(const float* __rest
         const int64_t bq = i / ldt;
         const int q = (int)(bq % P), b = (int)(bq / P);
         float v = 0.f;
-        if (col < nsrc * 50) {
+        // row sparsity: dZ2 of a sample behind its last loss step is exactly zero (not read)
+        if (col < nsrc * 50 && !(row_last && row_last[b] < row_step)) {
             const int src = col / 50, o = (col % 50) / 25, u = col % 25;
             const int py = q / Wm - (u / 5 - 2), px = q % Wm - (u % 5 - 2);
             if ((unsigned)py < (unsigned)Hm && (unsigned)px < (unsigned)Wm)
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void drt_bwd_data_kernel(const float* __restri
 constexpr int DRT_MAXS = MAXSITE * MAXSITE;
 __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __restrict__ dD, const float* __restrict__ h, int B,
                                                              int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
-                                                             float* __restrict__ slab) {
+                                                             float* __restrict__ slab, const int* __restrict__ row_last, int row_step) {
     __shared__ int s_pix[DRT_MAXS];
     __shared__ float s_g0[DRT_MAXS], s_g1[DRT_MAXS];
     __shared__ int s_cnt[2];
@@ -313,6 +314,13 @@ __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __rest
     f32x4* O40 = reinterpret_cast<f32x4*>(slab) + ((((int64_t)b * nsel + i0) * ncls + cls) * NV + v) * C4;
     f32x4* O41 = O40 + (int64_t)ncls * NV * C4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (row_last && row_last[b] < row_step) {      // row sparsity: dD of this sample is exactly zero -> zero slab, nothing read (block-uniform)
+        for (int c4 = tid; c4 < C4; c4 += blockDim.x) {
+            O40[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (two) O41[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     int n = 0;
     for (int s0 = 0; s0 < S; s0 += 128) {
         const int s = s0 + tid;
@@ -431,14 +439,18 @@ extern "C" int sp_sal_gather_fwd(const float* T, int B, int Hm, int Wm, int ldt,
     return SP_OK;
 }
 
-extern "C" int sp_sal_gather_bwd(const float* dZ2, int B, int Hm, int Wm, int ldt, int nsel, int nsrc, const int* hmap,
-                                 float* dT, void* stream) {
+extern "C" int sp_sal_gather_bwd_rows(const float* dZ2, int B, int Hm, int Wm, int ldt, int nsel, int nsrc, const int* hmap,
+                                      float* dT, const int* row_last, int row_step, void* stream) {
     if (!dZ2 || !hmap || !dT) return SP_ENULL;
     if (B < 1 || nsel < 1 || nsrc < 1 || ldt < nsrc * 50) return SP_EINVAL;
     hipLaunchKernelGGL(sal_gather_bwd_kernel, dim3(ew_grid((int64_t)B * Hm * Wm * ldt)), dim3(256), 0, (hipStream_t)stream, dZ2,
-                       B, Hm, Wm, ldt, nsel, nsrc, hmap, dT);
+                       B, Hm, Wm, ldt, nsel, nsrc, hmap, dT, row_last, row_step);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+extern "C" int sp_sal_gather_bwd(const float* dZ2, int B, int Hm, int Wm, int ldt, int nsel, int nsrc, const int* hmap,
+                                 float* dT, void* stream) {
+    return sp_sal_gather_bwd_rows(dZ2, B, Hm, Wm, ldt, nsel, nsrc, hmap, dT, nullptr, 0, stream);
 }
 
 extern "C" int sp_drt_direct_fwd(const float* h, const float* W11, const float* cbsum, const int* hmap, int B, int Hm, int Wm,
@@ -469,14 +481,15 @@ extern "C" int64_t sp_drt_direct_bwd_weight_workspace(int B, int Hm, int Wm, int
     return (int64_t)B * nsel * ay.ncls * ax.ncls * NV * C * (int64_t)sizeof(float);
 }
 
-extern "C" int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
-                                        int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, void* stream) {
+extern "C" int sp_drt_direct_bwd_weight_rows(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
+                                             int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, const int* row_last,
+                                             int row_step, void* stream) {
     if (!dDpre || !h || !hmap || !workspace || !dW11 || !dcbsum) return SP_ENULL;
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || nheads < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
     const int ncls = ay.ncls * ax.ncls;
     hipLaunchKernelGGL(drt_bwd_weight_kernel, dim3(NV * ncls, B, (nsel + 1) / 2), dim3(128), 0, (hipStream_t)stream, dDpre, h, B, C / 4,
-                       nsel, ncls, ay, ax, (float*)workspace);
+                       nsel, ncls, ay, ax, (float*)workspace, row_last, row_step);
     SP_LAUNCH_CHECK();
     const int64_t per_head4 = (int64_t)ncls * NV * (C / 4);
     hipLaunchKernelGGL(drt_slab_reduce_kernel, dim3(ew_grid(nheads * per_head4)), dim3(256), 0, (hipStream_t)stream,
@@ -486,4 +499,8 @@ extern "C" int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, cons
                        dcbsum);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+extern "C" int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
+                                        int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, void* stream) {
+    return sp_drt_direct_bwd_weight_rows(dDpre, h, hmap, B, Hm, Wm, C, nsel, nheads, workspace, dW11, dcbsum, nullptr, 0, stream);
 }

@@ -97,7 +97,7 @@ _apply_config()
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
-                 "row_sparse_bwd": 0}
+                 "row_sparse_bwd": 0, "fan_in_rows": 0}
 
 
 # ---- row sparsity of the backward pass implied by the loss masks (scanpath_loss(skip_masked_backward=True)) ---------------------------
@@ -143,10 +143,11 @@ class SplitOperand:
                               gradient (K = pixels); in a forward / data-gradient GEMM the weight operand must absorb the vector;
                   "rows"   -- weights with one scale per row = output column of the GEMM (scale = [rows] vector); `absorbed` names the
                               channel-scale vector the rows were divided by (None: none)."""
-    __slots__ = ("buf", "scale", "scheme", "kind", "absorbed")
+    __slots__ = ("buf", "scale", "scheme", "kind", "absorbed", "rows")
 
     def __init__(self, buf, scale, scheme, kind="scalar", absorbed=None):
         self.buf, self.scale, self.scheme, self.kind, self.absorbed = buf, scale, scheme, kind, absorbed
+        self.rows = None      # (RowsCtx, decode step) of a gradient operand whose samples behind their last loss step are exactly zero
 
 
 def _scheme_for(kc: int) -> str:
@@ -501,8 +502,8 @@ class _FanOut(Function):
     identity autograd does not guarantee (a hook that returns a new tensor, an accumulation, a cloning wrapper: ADVICE r3) -- and
     raises if a recorded contribution's gradient never arrived or arrives marked as unwritten without a record."""
     @staticmethod
-    def forward(ctx, x, n, token):
-        ctx.n, ctx.token = n, token
+    def forward(ctx, x, n, token, step=None):
+        ctx.n, ctx.token, ctx.step = n, token, step
         ctx.set_materialize_grads(False)      # an alias nobody consumed contributes None, not a full-size zero tensor to sum
         return tuple(x.view_as(x) for _ in range(n))
 
@@ -514,7 +515,7 @@ class _FanOut(Function):
                 raise RuntimeError(f"scanpaths_amd: fan-out alias {i} recorded a split-only gradient but no gradient arrived for it")
         idx = [i for i, g in enumerate(grads) if g is not None]
         if not idx:
-            return None, None, None
+            return None, None, None, None
         for i in idx:
             if i not in tok and getattr(grads[i], "_sp_skipped", False):
                 raise RuntimeError("scanpaths_amd: a gradient whose fp32 form was left unwritten reached a fan-in without its record")
@@ -529,32 +530,59 @@ class _FanOut(Function):
             pl = (C.c_void_p * len(gs))(*[op.buf.data_ptr() if op is not None else None for op in ops])
             sc = (C.c_void_p * len(gs))(*[op.scale.data_ptr() if op is not None else None for op in ops])
             hint = _amax_hint(out.device)
-            check(hip.lib().sp_sum_n_mixed(f, pl, sc, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n_mixed")
+            # contributions of decode steps behind a sample's last loss step are exactly zero (rows_ctx): not read
+            rcs = [op.rows[0] for op in ops if op is not None and op.rows is not None]
+            rc = rcs[0] if (rcs and all(r is rcs[0] for r in rcs) and (n // rcs[0].B) % 16 == 0 and n % rcs[0].B == 0) else None
+            steps = (C.c_int * len(gs))(*[(op.rows[1] if (op is not None and op.rows is not None) else -1) for op in ops]) if rc else None
+            check(hip.lib().sp_sum_n_mixed_rows(f, pl, sc, len(gs), n, ptr(out), _hint_ptr(hint), ptr(rc.last) if rc else None, steps,
+                                                rc.B if rc else 0, hip.stream()), "sp_sum_n_mixed_rows")
             if hint is not None:
                 out._sp_amax = hint
-            return out, None, None
+            return out, None, None, None
         if len(gs) == 1:
-            return gs[0], None, None
+            return gs[0], None, None, None
         out = torch.empty_like(gs[0])
         n = out.numel()
         if n % 4 or len(gs) > 32:
             acc = gs[0]
             for g in gs[1:]:
                 acc = _add_raw(acc, g)
-            return acc, None, None
+            return acc, None, None, None
         arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
         hint = _amax_hint(out.device)          # max|sum|: the LSTM cell's backward bounds its split operand with it
-        check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n")
+        # masked-step sparsity: every term of a tensor that lives at decode step ctx.step (h_t: the two heads' and the next step's
+        # h-gate gradients), or the terms a producer marked with their memory update (_sp_rows: semantic pooling -> vf), are exact
+        # zeros for the samples behind their last loss step -- not read (a lost hint only makes the pass dense again)
+        rc0 = rows_ctx(ctx.step, gs[0].shape[0]) if gs[0].dim() > 1 else None
+        marks = [getattr(grads[i], "_sp_rows", None) for i in idx]
+        if rc0 is None and any(m is not None for m in marks):
+            cand = next(m[0] for m in marks if m is not None)
+            if cand is _ROWS and gs[0].dim() > 1 and cand.B == gs[0].shape[0]:
+                rc0 = cand
+        steps = None
+        if rc0 is not None and n % rc0.B == 0 and (n // rc0.B) % 4 == 0:
+            if ctx.step is not None:
+                steps = [int(ctx.step)] * len(gs)
+            else:
+                steps = [int(m[1]) if (m is not None and m[0] is rc0) else -1 for m in marks]
+        if steps is not None and any(st >= 0 for st in steps):
+            FUSION_COUNTS["fan_in_rows"] += 1
+            check(hip.lib().sp_sum_n_rows(arr, len(gs), n, ptr(out), _hint_ptr(hint), ptr(rc0.last), (C.c_int * len(gs))(*steps), rc0.B,
+                                          hip.stream()), "sp_sum_n_rows")
+        else:
+            check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n")
         if hint is not None:
             out._sp_amax = hint
-        return out, None, None
+        return out, None, None, None
 
 
-def fanout(x: torch.Tensor, n: int):
-    """n aliases of x whose gradients are summed in ONE pass; the operand-split cache and the fused-amax hint travel with them"""
+def fanout(x: torch.Tensor, n: int, step=None):
+    """n aliases of x whose gradients are summed in ONE pass; the operand-split cache and the fused-amax hint travel with them.
+    step: x lives at this decode step (dim 0 = samples): under the masked-step sparsity of the backward pass (rows_ctx) the samples behind
+    their last loss step contribute exact zeros that the fan-in does not read."""
     split_ok = x.numel() % 16 == 0 and n <= 32
     token = {} if split_ok else None
-    outs = _FanOut.apply(x, n, token)
+    outs = _FanOut.apply(x, n, token, step)
     for attr in ("_sp_cache", "_sp_amax"):
         v = getattr(x, attr, None)
         if v is not None:
@@ -1436,6 +1464,8 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
               "sp_lstm_pointwise_bwd_rows")
         dpre._sp_amax = hint
         dpre._sp_cache = {"f16x2": SplitOperand(planes, hint, "f16x2")}
+        if rc is not None:
+            dpre._sp_cache["f16x2"].rows = (rc, int(step))
         if skip:
             fan[0][fan[1]] = dpre._sp_cache["f16x2"]      # xg's fan-in takes this contribution from the record, by alias index
     else:
@@ -1674,7 +1704,7 @@ def mul_relu(a, b):
 class _SemPool(Function):
     """amaps [S,B,P], vf [B,P,C] -> relu(mean_p(amaps * vf)) [B,S,C]   (get_channel_semantic + ReLU)"""
     @staticmethod
-    def forward(ctx, amaps, vf):
+    def forward(ctx, amaps, vf, step=None):
         amaps, vf = amaps.contiguous(), vf.contiguous()
         S, B, P = amaps.shape
         Cc = vf.shape[-1]
@@ -1683,6 +1713,7 @@ class _SemPool(Function):
         ws = hip.workspace(L.sp_sempool_workspace(S, B, P, Cc), vf.device, slot=0)
         check(L.sp_sempool_fwd(ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(ws), ptr(out), hip.stream()), "sp_sempool_fwd")
         ctx.save_for_backward(amaps, vf, out)
+        ctx.step = step
         return out
 
     @staticmethod
@@ -1691,13 +1722,17 @@ class _SemPool(Function):
         S, B, P = amaps.shape
         Cc = vf.shape[-1]
         da, dvf = torch.empty_like(amaps), torch.empty_like(vf)
-        check(hip.lib().sp_sempool_bwd(ptr(dout.contiguous()), ptr(out), ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(da), ptr(dvf),
-                                       hip.stream()), "sp_sempool_bwd")
-        return da, dvf
+        rc = rows_ctx(ctx.step, B)      # memory update `step` feeds decode steps >= step only: samples whose last loss step is earlier get zeros
+        check(hip.lib().sp_sempool_bwd_rows(ptr(dout.contiguous()), ptr(out), ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(da), ptr(dvf),
+                                            ptr(rc.last) if rc is not None else None, int(ctx.step) if rc is not None else 0,
+                                            hip.stream()), "sp_sempool_bwd_rows")
+        if rc is not None:
+            dvf._sp_rows = (rc, int(ctx.step))      # hint for vf's gradient fan-in (dead samples' rows are exact zeros): F._FanOut
+        return da, dvf, None
 
 
-def semantic_pool(amaps, vf):
-    return _SemPool.apply(amaps, vf)
+def semantic_pool(amaps, vf, step=None):
+    return _SemPool.apply(amaps, vf, step)
 
 
 class _RowMean(Function):
@@ -1861,12 +1896,13 @@ def compose11(G, cb, nheads, HC, hw):
 class _SalGather(Function):
     """tap partials T [B,Hm,Wm,ldt] -> maps Z2 [B,Hm,Wm,2*nsel]; hmap int32 [B,nsel] = source head of each output slot"""
     @staticmethod
-    def forward(ctx, T, hmap, nsel, nsrc):
+    def forward(ctx, T, hmap, nsel, nsrc, step=None):
         T = T.contiguous()
         B, Hm, Wm, ldt = T.shape
         Z2 = torch.empty((B, Hm, Wm, 2 * nsel), dtype=torch.float32, device=T.device)
         check(hip.lib().sp_sal_gather_fwd(ptr(T), B, Hm, Wm, ldt, nsel, ptr(hmap), ptr(Z2), hip.stream()), "sp_sal_gather_fwd")
         ctx.cfg = (B, Hm, Wm, ldt, nsel, nsrc)
+        ctx.step = step
         ctx.save_for_backward(hmap)
         return Z2
 
@@ -1876,19 +1912,21 @@ class _SalGather(Function):
         hmap, = ctx.saved_tensors
         dZ2 = dZ2.contiguous()
         dT = torch.empty((B, Hm, Wm, ldt), dtype=torch.float32, device=dZ2.device)
-        check(hip.lib().sp_sal_gather_bwd(ptr(dZ2), B, Hm, Wm, ldt, nsel, nsrc, ptr(hmap), ptr(dT), hip.stream()),
-              "sp_sal_gather_bwd")
-        return dT, None, None, None
+        rc = rows_ctx(ctx.step, B)
+        check(hip.lib().sp_sal_gather_bwd_rows(ptr(dZ2), B, Hm, Wm, ldt, nsel, nsrc, ptr(hmap), ptr(dT), ptr(rc.last) if rc is not None else None,
+                                               int(ctx.step) if rc is not None else 0, hip.stream()), "sp_sal_gather_bwd_rows")
+        return dT, None, None, None, None
 
 
-def sal_gather(T, hmap, nsel, nsrc):
-    return _SalGather.apply(T, hmap, nsel, nsrc)
+def sal_gather(T, hmap, nsel, nsrc, step=None):
+    return _SalGather.apply(T, hmap, nsel, nsrc, step)
 
 
 class _DrtDirect(Function):
     """h [B,Hm,Wm,C], W11 [nheads,ncls,121,C], cbsum [nheads,ncls] -> Dpre [nsel,B,dh*dw]"""
     @staticmethod
-    def forward(ctx, h, W11, cbsum, hmap, nsel):
+    def forward(ctx, h, W11, cbsum, hmap, nsel, step=None):
+        ctx.step = step
         h = h.contiguous()
         W11 = W11.contiguous()
         cbsum = cbsum.contiguous()
@@ -1916,13 +1954,15 @@ class _DrtDirect(Function):
             dW = torch.empty(wshape, dtype=torch.float32, device=h.device)
             dcs = torch.empty(cshape, dtype=torch.float32, device=h.device)
             ws = hip.workspace(L.sp_drt_direct_bwd_weight_workspace(B, Hm, Wm, C_, nsel), h.device, slot=0)
-            check(L.sp_drt_direct_bwd_weight(ptr(dD), ptr(h), ptr(hmap), B, Hm, Wm, C_, nsel, nheads, ptr(ws), ptr(dW), ptr(dcs),
-                                             hip.stream()), "sp_drt_direct_bwd_weight")
-        return dh, dW, dcs, None, None
+            rc = rows_ctx(ctx.step, B)      # samples behind their last loss step: exactly-zero dD -> zero slabs, h not read
+            check(L.sp_drt_direct_bwd_weight_rows(ptr(dD), ptr(h), ptr(hmap), B, Hm, Wm, C_, nsel, nheads, ptr(ws), ptr(dW), ptr(dcs),
+                                                  ptr(rc.last) if rc is not None else None, int(ctx.step) if rc is not None else 0,
+                                                  hip.stream()), "sp_drt_direct_bwd_weight_rows")
+        return dh, dW, dcs, None, None, None
 
 
-def drt_direct(h, W11, cbsum, hmap, nsel):
-    return _DrtDirect.apply(h, W11, cbsum, hmap, nsel)
+def drt_direct(h, W11, cbsum, hmap, nsel, step=None):
+    return _DrtDirect.apply(h, W11, cbsum, hmap, nsel, step)
 
 
 # ----------------------------------------------------------------------------------------------------

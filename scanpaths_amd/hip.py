@@ -95,7 +95,9 @@ SIGNATURES = {
     "sp_conv_igemm_f16x2_stats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_bn_bwd_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_sum_n": (_I, [_P, _I, _L, _P, _P, _P]),
+    "sp_sum_n_rows": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P]),
     "sp_sum_n_mixed": (_I, [_P, _P, _P, _I, _L, _P, _P, _P]),
+    "sp_sum_n_mixed_rows": (_I, [_P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P]),
     "sp_relu_bwd": (_I, [_P, _P, _L, _P, _P]),
     "sp_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sp_maxpool3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "sp_sempool_workspace": (_L, [_I, _I, _I, _I]),
     "sp_sempool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_sempool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "sp_sempool_bwd_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
     "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "sp_lstm_pointwise_bwd_split": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
     "sp_lstm_pointwise_bwd_rows": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
@@ -130,10 +133,12 @@ SIGNATURES = {
     "sp_head_compose11_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sp_sal_gather_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sp_sal_gather_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sp_sal_gather_bwd_rows": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "sp_drt_direct_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_drt_direct_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sp_drt_direct_bwd_weight_workspace": (_L, [_I, _I, _I, _I, _I]),
     "sp_drt_direct_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "sp_drt_direct_bwd_weight_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "sp_scanmatch_max_len": (_I, []),
     "sp_scanmatch_submatrix": (_I, [_I, _I, C.c_double, _P, _P, _P]),
     "sp_scanmatch_sequences": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, C.c_double, C.c_double, C.c_double, _P, _I, _P, _P, _P]),

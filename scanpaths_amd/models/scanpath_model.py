@@ -391,9 +391,9 @@ class ScanpathModel(nn.Module):
             # T - k - 1 small adds autograd issues for a tensor that sits in T - k stacks (~250 launches per step over both lists)
             spf = F.mul_relu(amaps, mvfs.pop())
             sp_list.append(rep(F.linear(spf.view(S * B, P), spw.pop(), spb.pop(), defer=sp_defer), T - k))
-            vf3 = vfs.pop().view(B, P, Cc)
-            pooled = F.semantic_pool(amaps, vf3) if (S <= 2 and Cc <= 512) else \
-                F.gemm(amaps.transpose(0, 1).contiguous(), vf3, None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
+            vf4 = vfs.pop()           # (4-D as it is: the gradient it returns carries the memory update's row-sparsity mark to vf's fan-in)
+            pooled = F.semantic_pool(amaps, vf4, step=k) if (S <= 2 and Cc <= 512) else \
+                F.gemm(amaps.transpose(0, 1).contiguous(), vf4.view(B, P, Cc), None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
             se_list.append(rep(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop(), defer=se_defer), T - k))
             sp_mem = F.list_attention(torch.stack([a.pop() for a in sp_list], 0), u_spas.pop())        # [S*B,P]
             se_mem = F.list_attention(torch.stack([a.pop() for a in se_list], 0), u_sems.pop())        # [S*B,C]
@@ -420,9 +420,11 @@ class ScanpathModel(nn.Module):
                 h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc, step=t)
             # h has three consumers (two heads now, the h-gate conv of the next step): one fan-in pass for its gradient
             nuse = 3 if t + 1 < T else 2
-            h_sal, h_drt, h = (tuple(F.fanout(h, nuse)) + (None,))[:3] if h.requires_grad else (h, h, h)
-            Z2 = F.sal_gather(F.conv2d(h_sal, Wsals.pop(), None, pad=0), hmap, nh, nsrc)
-            Dpre = F.drt_direct(h_drt, W11s.pop(), cbsums.pop(), hmap, nh)
+            # (step=t: under the masked-step sparsity of the backward pass the gradients of step t's heads are exact zeros for the samples
+            # whose last loss step is earlier -- their backward kernels and h's fan-in skip those samples, functional.rows_ctx)
+            h_sal, h_drt, h = (tuple(F.fanout(h, nuse, step=t)) + (None,))[:3] if h.requires_grad else (h, h, h)
+            Z2 = F.sal_gather(F.conv2d(h_sal, Wsals.pop(), None, pad=0, step=t), hmap, nh, nsrc, step=t)
+            Dpre = F.drt_direct(h_drt, W11s.pop(), cbsums.pop(), hmap, nh, step=t)
             logits, amap, mu, s2 = F.head_finish(Z2, cbs.pop(), w2s.pop(), b2s.pop(), nh, HC, not self.training,
                                                  per_sample=per_sample, dpre=Dpre)
             outs["logits"].append(logits)

@@ -648,6 +648,8 @@ def test_masked_step_sparsity_of_the_backward_is_bit_identical_to_the_dense_back
         assert F._ROWS is None                                      # the context never outlives the backward pass
         assert F.FUSION_COUNTS["row_sparse_bwd"] == int(sparse) and F.FUSION_COUNTS["wgrad_multi"] >= 1, F.FUSION_COUNTS
         assert F.FUSION_COUNTS["gateconv_lstm"] == T - 1
+        # h's fan-in of every decode step and vf's fan-in (semantic-pooling terms marked with their memory update) skip the dead samples
+        assert (F.FUSION_COUNTS["fan_in_rows"] >= T + 1) if sparse else (F.FUSION_COUNTS["fan_in_rows"] == 0), F.FUSION_COUNTS
         res[sparse] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
     assert res[True][0] == res[False][0]
     assert res[True][1].keys() == res[False][1].keys()

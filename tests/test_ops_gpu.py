@@ -913,6 +913,28 @@ def test_fan_in_of_split_only_gradients_and_cell_backward_without_fp32_output():
     assert float(amax.view(torch.float32)[0]) == float(out.abs().max())                      # fused max|sum| (float bits)
     assert L.sp_sum_n_mixed(f, pl, sc, 3, n - 8, hip.ptr(out), None, hip.stream()) == -1
     del poison
+    # masked-step sparsity (sp_sum_n_mixed_rows): a term of decode step s is exactly zero for samples whose last loss step is < s and
+    # is then not read -- same result, bit for bit, as the dense pass over terms whose dead samples hold zeros (4 samples here)
+    nb = 4
+    last = torch.tensor([0, 2, 1, -1], dtype=torch.int32, device=dev)
+    steps = [0, 1, 2]
+    zs = []
+    for t, st in zip(ts, steps):
+        z = t.clone().view(nb, -1)
+        z[(last < st).nonzero().flatten()] = 0.0
+        zs.append(z.view(-1))
+    zops = [F.split_op(z.view(-1, 256), "f16x2") for z in zs]
+    f2 = (C.c_void_p * 3)(None, zs[1].data_ptr(), None)
+    pl2 = (C.c_void_p * 3)(zops[0].buf.data_ptr(), None, zops[2].buf.data_ptr())
+    sc2 = (C.c_void_p * 3)(zops[0].scale.data_ptr(), None, zops[2].scale.data_ptr())
+    dense, sparse = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    assert L.sp_sum_n_mixed(f2, pl2, sc2, 3, n, hip.ptr(dense), None, hip.stream()) == 0
+    for z, st in zip(zs, steps):                               # dead samples now hold NaN: reading them would show
+        z.view(nb, -1)[(last < st).nonzero().flatten()] = float("nan")
+    st_arr = (C.c_int * 3)(*steps)
+    assert L.sp_sum_n_mixed_rows(f2, pl2, sc2, 3, n, hip.ptr(sparse), None, hip.ptr(last), st_arr, nb, hip.stream()) == 0
+    assert torch.equal(dense, sparse)
+    assert L.sp_sum_n_mixed_rows(f2, pl2, sc2, 3, n, hip.ptr(sparse), None, hip.ptr(last), None, nb, hip.stream()) == -2
     # cell backward: same planes with and without the fp32 output
     rows, Cc = 64, 256
     gates = torch.rand(rows, 4 * Cc, generator=g).to(dev)
