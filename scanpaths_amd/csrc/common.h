@@ -83,6 +83,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh4) {
     __syncthreads();
     return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
+// four independent block-wide sums at once (same partition and order as block_sum_256, hence the same bits): one pair of barriers
+// for four values -- the attention kernels' per-entry dot products were a chain of T dependent load -> reduce -> barrier rounds
+__device__ __forceinline__ void block_sum4_256(float (&v)[4], float* sh16) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh16[w * 4 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = sh16[k] + sh16[4 + k] + sh16[8 + k] + sh16[12 + k];
+}
 __device__ __forceinline__ float block_max_256(float v, float* sh4) {
     v = wave_max(v);
     const int w = threadIdx.x >> 6;

@@ -446,15 +446,23 @@ constexpr int MAXT = 40;
 
 __global__ __launch_bounds__(256) void listatt_fwd_kernel(const float* L, const float* u, int T, int R, int D, float* mem,
                                                           float* alpha) {
-    __shared__ float sh4[4];
+    __shared__ float sh16[16];
     __shared__ float sc[MAXT];
     const int r = blockIdx.x;
-    for (int t = 0; t < T; ++t) {
-        const float* row = L + ((int64_t)t * R + r) * D;
-        float s = 0.f;
-        for (int d = threadIdx.x; d < D; d += 256) s += row[d] * u[d];
-        s = block_sum_256(s, sh4);
-        if (threadIdx.x == 0) sc[t] = s;
+    for (int t0 = 0; t0 < T; t0 += 4) {          // four list entries per round (block_sum4_256: same bits as one at a time)
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float ud = u[d];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t0 + k < T) s[k] += L[((int64_t)(t0 + k) * R + r) * D + d] * ud;
+        }
+        block_sum4_256(s, sh16);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t0 + k < T) sc[t0 + k] = s[k];
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -473,16 +481,24 @@ __global__ __launch_bounds__(256) void listatt_fwd_kernel(const float* L, const 
 __global__ __launch_bounds__(256) void listatt_bwd_kernel(const float* dmem, const float* L, const float* u,
                                                           const float* alpha, int T, int R, int D, float* dL,
                                                           float* du_partial) {
-    __shared__ float sh4[4];
+    __shared__ float sh16[16];
     __shared__ float gs[MAXT];
     const int r = blockIdx.x;
     const float* dm = dmem + (int64_t)r * D;
-    for (int t = 0; t < T; ++t) {
-        const float* row = L + ((int64_t)t * R + r) * D;
-        float s = 0.f;
-        for (int d = threadIdx.x; d < D; d += 256) s += row[d] * dm[d];
-        s = block_sum_256(s, sh4);
-        if (threadIdx.x == 0) gs[t] = s;
+    for (int t0 = 0; t0 < T; t0 += 4) {          // four list entries per round (block_sum4_256: same bits as one at a time)
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float dmd = dm[d];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t0 + k < T) s[k] += L[((int64_t)(t0 + k) * R + r) * D + d] * dmd;
+        }
+        block_sum4_256(s, sh16);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t0 + k < T) gs[t0 + k] = s[k];
+        }
     }
     __syncthreads();
     float mean = 0.f;

@@ -93,7 +93,8 @@ class GradBucketer:
             # a second backward before step() (gradient accumulation, two losses): this parameter already reported -- its bucket's
             # all-reduce may be in flight on the RCCL stream while autograd accumulates into the same memory, or (bucket not launched
             # yet) the bucket would be launched one report early; either way the replicas would drift silently
-            raise RuntimeError("GradBucketer: a parameter's gradient was produced twice before FlatAdam.step() (gradient accumulation "
+            raise RuntimeError(f"GradBucketer: the gradient of parameter #{i} (bucket {b}, next bucket to launch {self.next_b}, already "
+                               f"reported: {self.reported[i]}) was produced twice before FlatAdam.step() (gradient accumulation "
                                "or two backward passes per step); the overlapped bucketed all-reduce supports ONE backward per step -- "
                                "construct FlatAdam(bucket_mb=0) for a single un-overlapped all-reduce in step(); after a backward whose "
                                "step() is skipped call FlatAdam.zero_grad() (it drains and resets the buckets)")

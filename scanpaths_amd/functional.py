@@ -86,7 +86,7 @@ def _apply_config():
                       ("LSTM_BWD_SPLIT", "lstm_bwd_split"), ("RANK1_DSP_SPLIT", "rank1_dsp_split"), ("RANK1_DWC_SPLIT", "rank1_dwc_split"),
                       ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
                       ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single"),
-                      ("ROW_SPARSITY", "row_sparsity")):
+                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad")):
         g[name] = bool(c[key])
 
 
@@ -97,7 +97,37 @@ _apply_config()
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
-                 "row_sparse_bwd": 0, "fan_in_rows": 0}
+                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0}
+
+
+# ---- parameter gradients written straight into the optimizer's flat gradient buffer -------------------------------------------------
+# FlatAdam gives every parameter a view of ONE flat gradient buffer as its .grad and marks it (`_sp_flat`).  A backward kernel that
+# produces the gradient of such a LEAF parameter, and is the first to do so since FlatAdam.zero_grad() cleared the buffer, writes into
+# that view and hands autograd None: the ~160 per-parameter read-modify-write adds of AccumulateGrad (and as many temporaries) per
+# training step go away.  The optimizer's post-accumulate hook (gradient-ready bookkeeping, bucketed all-reduce) is called by hand.
+# A second gradient for the same parameter before the next zero_grad() takes the ordinary autograd path and is added.
+def _grad_slot(param):
+    """the marker of a leaf parameter whose .grad is a FlatAdam view, else None"""
+    if not DIRECT_GRAD or param is None or not getattr(param, "is_leaf", False):
+        return None
+    return getattr(param, "_sp_flat", None)
+
+
+def _take_grad_view(param, phys_perm=None):
+    """-> (slot, tensor to write the gradient into) when the gradient may be written in place, else (None, None).
+    phys_perm: permutation that must make the view contiguous (conv weights: (0, 2, 3, 1) = [Co, KH, KW, Ci])"""
+    slot = _grad_slot(param)
+    if slot is None:
+        return None, None
+    g = slot.peek(param)
+    if g is None:
+        return None, None
+    v = g.permute(*phys_perm) if phys_perm is not None else g
+    if not v.is_contiguous():
+        return None, None
+    slot.take()
+    FUSION_COUNTS["direct_grad"] += 1
+    return slot, v
 
 
 # ---- row sparsity of the backward pass implied by the loss masks (scanpath_loss(skip_masked_backward=True)) ---------------------------
@@ -402,6 +432,9 @@ def _w3_pays(M, Co, K, Ci, nbatch=1, free_splits=False):
     return flops * (1 / 1.0e14 - 1 / (3.2e14 if f16 else 1.6e14)) > split_bytes / 4e12 and flops > 2e9
 
 
+HW2_SINGLE_MIN_FLOPS = 9e10      # smallest single weight gradient routed to hw2_kernel (256 x 256 tiles, single-level accumulation over <= 20480 pixels): the x-gate conv, sal_conv and -- round 4, tools/encoder_census.py --hw2-min-flops: -2.0 ms per step -- the encoder's layer-3 / layer-4 weight gradients from Co x K = 256 x 2304 on (below that the 256 KB slab tiles cost more than the larger tile saves)
+
+
 def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, stride=1, pad=0, dil=1, beta=0, alpha=1.0,
               ws_slot=0):
     if not isinstance(Xs, SplitOperand):
@@ -415,7 +448,7 @@ def _wgrad_b3(Xs, dYs, dW, *, N_img, Hi, Wi, Ci, Ho, Wo, Co, ldo, KH=1, KW=1, st
     M = N_img * Ho * Wo
     # large single weight gradients whose shape fits the 256 x 256-tile kernel (x-gate conv, sal_conv): hw2_kernel with one segment
     big = L.sp_conv_wgrad_f16x2_multi_workspace(C.byref(d), 1) if (f16 and HW2_SINGLE and not THROUGHPUT_MODE
-                                                                   and 2.0 * M * COST_M_SCALE * Co * KH * KW * Ci >= 1e12) else 0
+                                                                   and 2.0 * M * COST_M_SCALE * Co * KH * KW * Ci >= HW2_SINGLE_MIN_FLOPS) else 0
     ws = hip.workspace(big if big > 0 else (L.sp_conv_wgrad_f16x2_workspace if f16 else L.sp_conv_wgrad_bf16x3_workspace)(C.byref(d)),
                        dW.device, slot=ws_slot)
 
@@ -681,6 +714,7 @@ class _Conv2d(Function):
         # grad_store / grad_accum: GradMerge of a block input -- leave the input gradient there / accumulate into what is there
         # step: the decode step this application belongs to (row sparsity of its backward, see rows_ctx)
         ctx.grad_store, ctx.grad_accum, ctx.step = grad_store, grad_accum, step
+        ctx.w_param = w if (_grad_slot(w) is not None and w.dim() == 4) else None      # its gradient may go straight into the flat buffer
         defer = wcache.get("defer") if isinstance(wcache, dict) else None       # DeferredWgrad of a weight applied T times
         ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
         ctx.dy_token = None
@@ -753,7 +787,7 @@ class _Conv2d(Function):
             check(hip.lib().sp_relu_bwd(ptr(dy), ptr(y), dy.numel(), ptr(dyr), hip.stream()), "sp_relu_bwd")
             dy = dyr
         dx, dw = _conv_backward(x, wp, dy, xs, stride, pad, dil, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                accum=ctx.grad_accum, defer_final=ctx.defer_final, step=ctx.step)
+                                accum=ctx.grad_accum, defer_final=ctx.defer_final, step=ctx.step, w_param=ctx.w_param)
         if ctx.grad_store is not None and dx is not None:
             ctx.grad_store.first = dx
         db = _colsum_any(dy, wp.shape[0]) if (has_bias and ctx.needs_input_grad[2]) else None
@@ -822,7 +856,7 @@ def _flush_deferred(defer, wp, geom):
     return dwp.permute(0, 3, 1, 2)
 
 
-def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None, defer_final=False, step=None):
+def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, accum=None, defer_final=False, step=None, w_param=None):
     """data and weight gradient of y = conv(x, wp) (NHWC, physical weight [Co,KH,KW,Ci]); xs: the forward's split x or None;
     accum: GradMerge whose ``first`` (another consumer's gradient of x) the data gradient is added to in place"""
     N, H, W_, Ci = x.shape
@@ -860,8 +894,12 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
             _fp32_required(dy, "the fp32 data-gradient GEMM")
             _igemm(dy, wp, None, dx, N_img=N, Hi=Ho, Wi=Wo, Kc=Co, ldx=Co, Ho=H, Wo=W_, Nout=Ci, ldc=Ci, ldw=Ci, KH=KH,
                    KW=KW, stride=stride, pad=pad, dil=dil, mode=1, beta=beta)
+    slot = None
     if need_dw and not deferred:
-        dwp = torch.empty_like(wp)
+        if defer is None:          # (a weight with deferred applications is summed by _flush_deferred: ordinary path)
+            slot, dwp = _take_grad_view(w_param, (0, 2, 3, 1))
+        if slot is None:
+            dwp = torch.empty_like(wp)
         wsch = _wgrad_scheme(Ci, Co)
         if dys is None and dy_cached is not None and wsch in dy_cached:
             dys = dy_cached[wsch]
@@ -874,7 +912,10 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
             _fp32_required(dy, "the fp32 weight-gradient GEMM")
             _wgrad(x, dy, dwp, N_img=N, Hi=H, Wi=W_, Ci=Ci, ldx=Ci, Ho=Ho, Wo=Wo, Co=Co, ldy=Co, ldo=KH * KW * Ci,
                    KH=KH, KW=KW, stride=stride, pad=pad, dil=dil)
-        dw = dwp.permute(0, 3, 1, 2)
+        if slot is not None:
+            slot.done()            # written into the parameter's flat-buffer view: autograd gets None
+        else:
+            dw = dwp.permute(0, 3, 1, 2)
     if need_dw and defer is not None and defer_final and defer.items:
         # this application runs last in backward: the recorded applications (its own among them, unless it took the plain path) in
         # one launch
@@ -1128,6 +1169,7 @@ class _BnActSplit(Function):
     def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre, res_store=None,
                 dy_token=None, skip_z=False):
         ctx.res_store = res_store          # GradMerge: the residual's gradient is left there for conv1's data gradient to add to
+        ctx.params = (gamma if _grad_slot(gamma) is not None else None, beta if _grad_slot(beta) is not None else None)
         ctx.dy_token = dy_token            # set: the producing conv's backward reads only the split gradient -> dx stays unwritten
         # pre: (partial, mm, G) -- first statistics stage already done by the producing conv's epilogue (conv2d bn_stats=True)
         x = x.contiguous()
@@ -1176,8 +1218,12 @@ class _BnActSplit(Function):
         dev = x.device
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
+        gslot, dgamma = _take_grad_view(ctx.params[0]) if ctx.needs_input_grad[1] else (None, None)
+        bslot, dbeta = _take_grad_view(ctx.params[1]) if ctx.needs_input_grad[2] else (None, None)
+        if dgamma is None:
+            dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
+        if dbeta is None:
+            dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
         planes = torch.empty(2 * x.numel() + 32, dtype=torch.float16, device=dev) if emit else None
         ws = hip.workspace(L.sp_bn_split_workspace(M, Cc), dev, slot=1)
         dhint, bhint = _amax_hint(dev), _amax_hint(dev)
@@ -1197,6 +1243,12 @@ class _BnActSplit(Function):
             dx._sp_cache = {"f16x2": SplitOperand(planes, dhint, "f16x2")}
         if ctx.res_store is not None and dres is not None:
             ctx.res_store.first = dres
+        if gslot is not None:
+            gslot.done()
+            dgamma = None
+        if bslot is not None:
+            bslot.done()
+            dbeta = None
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
 
 

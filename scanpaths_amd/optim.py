@@ -25,6 +25,33 @@ from .hip import check, ptr
 ALIGN = 4  # elements (16 bytes)
 
 
+class _FlatSlot:
+    """Marker FlatAdam leaves on a parameter (``p._sp_flat``): lets a backward kernel write the parameter's gradient straight into its
+    view of the flat gradient buffer instead of handing autograd a temporary to add (functional._take_grad_view).  Only the FIRST
+    gradient since zero_grad() may do so (the view then holds zeros); later ones take autograd's accumulate path."""
+    __slots__ = ("opt", "i")
+
+    def __init__(self, opt, i):
+        self.opt, self.i = opt, i
+
+    def peek(self, p):
+        o = self.opt
+        g = p.grad
+        if not o._fresh[self.i] or g is None or g.data_ptr() != o.flat_g.data_ptr() + 4 * o._offs[self.i]:
+            return None
+        return g
+
+    def take(self):
+        self.opt._fresh[self.i] = False
+
+    def done(self):
+        # The parameter's AccumulateGrad node still runs once every contribution of this backward has been produced -- with an undefined
+        # gradient when this was the only one -- and this torch fires the post-accumulate hook then (gradient-ready bookkeeping, bucketed
+        # all-reduce): reporting here as well made every such parameter report twice.  Should a torch version skip the hook for an
+        # undefined gradient, FlatAdam.step() reports the parameters still pending.
+        self.opt._direct_pending[self.i] = True
+
+
 class FlatAdam(torch.optim.Optimizer):
     """clip: max total gradient norm (0 = no clipping).  Data parallel (torch.distributed initialised, process_group not
     False): the flat parameter buffer is broadcast from rank 0 at construction (nn.DataParallel replicates replica 0's weights,
@@ -63,6 +90,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._steps = [0] * len(params)          # per-parameter Adam step (torch.optim.Adam keeps it per parameter)
         self._touched = [False] * len(params)    # did this backward produce a gradient for the parameter?
+        self._fresh = [True] * len(params)       # nothing has been written into the parameter's gradient view since it was zeroed
+        self._direct_pending = [False] * len(params)      # gradient written in place, post-accumulate hook not seen yet (_FlatSlot.done)
         self._sticky = False                     # zero_grad(set_to_none=False) semantics, see the class docstring
         # reference_zero_grad: a bare zero_grad() zero-fills like the reference's pinned torch==1.6.0 (sp_baseline.yml:116) instead of
         # following the installed torch's set_to_none=True default -- COCO_Search18 heads then keep decaying / momentum-stepping
@@ -91,9 +120,12 @@ class FlatAdam(torch.optim.Optimizer):
                     self._bucketer = GradBucketer(self.flat_g, offs, total, int(bucket_mb * (1 << 20)), process_group)
         for i, p in enumerate(params):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+            p._sp_flat = _FlatSlot(self, i)      # functional._take_grad_view: backward kernels may write this parameter's gradient in place
 
     def _on_grad(self, i: int):
         self._touched[i] = True
+        self._fresh[i] = False
+        self._direct_pending[i] = False
         if self._bucketer is not None and self._params[i].grad.data_ptr() == self.flat_g.data_ptr() + 4 * self._offs[i]:
             self._bucketer.mark_ready(i)      # (a foreign .grad tensor is copied into the flat buffer in step(): no early launch)
 
@@ -117,6 +149,8 @@ class FlatAdam(torch.optim.Optimizer):
             self._bucketer.drain()
         self.flat_g.zero_()
         self._touched = [False] * len(self._params)
+        self._fresh = [True] * len(self._params)
+        self._direct_pending = [False] * len(self._params)
         for p, o in zip(self._params, self._offs):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = torch.as_strided(self.flat_g, p.shape, self._dense_strides(p), o)
@@ -142,6 +176,9 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        for i, pend in enumerate(self._direct_pending):
+            if pend:                      # in-place gradient whose hook never fired (see _FlatSlot.done)
+                self._on_grad(i)
         foreign = self._gather_foreign_grads()
         g = self.param_groups[0]
         world = 1

@@ -114,3 +114,45 @@ def test_zero_grad_semantics_follow_stock_adam(set_to_none):
     assert sa == sb == ([4, 1, 2] if set_to_none else [4, 4, 4])
     for a, b in zip(pa, pb):
         assert float((a - b).abs().max()) <= 1e-6, float((a - b).abs().max())
+
+
+def test_parameter_gradients_written_into_the_flat_buffer_equal_autograds_accumulation(monkeypatch):
+    """functional._take_grad_view: the encoder's conv-weight and BatchNorm gradients are written by their backward kernels straight
+    into the parameter's view of FlatAdam's flat gradient buffer (no temporary, no AccumulateGrad add) when they are the first gradient
+    since zero_grad().  Same bits as the ordinary path -- after one backward, and after a second backward without zero_grad()
+    (gradient accumulation: the second contribution takes autograd's add) -- and every such parameter is reported to the optimizer."""
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.models.baseline_attention import baseline_osie
+    from scanpaths_amd.models.loss import supervised_loss
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.synth import make_batch
+    T = 2
+    b = {k: v.to(DEV) for k, v in make_batch("OSIE", 2, 240, 320, T, seed=3).items()}
+    res = {}
+    for direct in (False, True):
+        monkeypatch.setattr(F, "DIRECT_GRAD", direct)
+        m = baseline_osie(convLSTM_length=T, arch="resnet18")
+        fill_module(m, 9)
+        m = m.to(DEV).train()
+        opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5)
+        F.reset_fusion_counts()
+        snaps = []
+        opt.zero_grad()
+        for rep in range(2):
+            pred = m(b["images"])
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+            loss.backward()
+            torch.cuda.synchronize()
+            snaps.append(opt.flat_g.clone())
+            if rep == 0:
+                n_direct = F.FUSION_COUNTS["direct_grad"]
+                assert all(opt._touched), [n for (n, _), t in zip(m.named_parameters(), opt._touched) if not t][:5]
+        assert (n_direct > 40) if direct else (n_direct == 0), n_direct
+        assert F.FUSION_COUNTS["direct_grad"] == n_direct          # the second backward found the views occupied
+        opt.step()
+        torch.cuda.synchronize()
+        res[direct] = (snaps, opt.flat_p.clone())
+    assert torch.equal(res[False][0][0], res[True][0][0])
+    assert torch.equal(res[False][0][1], res[True][0][1])
+    assert torch.equal(res[False][1], res[True][1])

@@ -10,8 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--hw2-min-flops", type=float, default=None, help="experiment: route smaller weight gradients to hw2_kernel")
+    ap.add_argument("--only", type=str, default=None, help="print only rows whose kind contains this")
     a = ap.parse_args()
     from scanpaths_amd import hip
+    if a.hw2_min_flops is not None:
+        from scanpaths_amd import functional as F
+        F.HW2_SINGLE_MIN_FLOPS = a.hw2_min_flops
     from scanpaths_amd.models.baseline_attention import baseline
     from scanpaths_amd.procedural import fill_module
     from scanpaths_amd.synth import make_batch
@@ -49,6 +54,8 @@ def main():
     rows.sort(key=lambda r: -gap(r))
     print("sorted by (time - ideal); ideal = max(3-product matrix time at 530 TFLOP/s, bytes at 5.5 TB/s)")
     for r in rows:
+        if a.only and a.only not in r[0]:
+            continue
         kind, M, N, K, n, avg, ms, tf, fl, by = r
         ideal = max(fl / 530e12, by / 5.5e12) * 1e6
         print(f"{kind[:18]:18s} M={M:8d} N={N:5d} K={K:6d} n={n:3d} avg {avg*1e3:7.1f} us  total {ms:6.2f} ms  {tf:6.1f} TF/s  "
