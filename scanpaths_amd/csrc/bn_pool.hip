@@ -97,10 +97,25 @@ __device__ __forceinline__ bool final_reduce(const double* __restrict__ partial,
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-    if (c < C)
-        for (int g = ty; g < G; g += FL)
+    if (c < C) {
+        // four slab rows per round: their loads are independent and go out together (one at a time, every add waited for its own
+        // load: a chain of G / FL global round trips, 17-24 us per launch for a few MB); the adds keep their order -> same bits
+        int g = ty;
+        for (; g + 3 * FL < G; g += 4 * FL) {
+            double t[4][NV];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) t[u][v] = partial[((int64_t)(g + u * FL) * NV + v) * C + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += t[u][v];
+        }
+        for (; g < G; g += FL)
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[v] += partial[((int64_t)g * NV + v) * C + c];
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) shf[v][ty][tx] = acc[v];
     __syncthreads();
@@ -311,11 +326,26 @@ __device__ __forceinline__ void final_minmax(const float* __restrict__ mm, int C
     const int tx = threadIdx.x & (FC - 1), ty = threadIdx.x / FC;
     const int c = blockIdx.x * FC + tx;
     float a = INFINITY, b = -INFINITY;
-    if (c < C)
-        for (int g = ty; g < G; g += FL) {
+    if (c < C) {
+        int g = ty;
+        for (; g + 3 * FL < G; g += 4 * FL) {          // (four rows per round, as final_reduce)
+            float ta[4], tb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ta[u] = mm[((int64_t)(g + u * FL) * 2 + 0) * C + c];
+                tb[u] = mm[((int64_t)(g + u * FL) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a = fminf(a, ta[u]);
+                b = fmaxf(b, tb[u]);
+            }
+        }
+        for (; g < G; g += FL) {
             a = fminf(a, mm[((int64_t)g * 2 + 0) * C + c]);
             b = fmaxf(b, mm[((int64_t)g * 2 + 1) * C + c]);
         }
+    }
     shx[0][ty][tx] = a;
     shx[1][ty][tx] = b;
     __syncthreads();

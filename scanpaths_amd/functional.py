@@ -818,6 +818,12 @@ def _flush_deferred(defer, wp, geom):
     """dW of all recorded applications: one multi-application launch where the kernel's shape constraints hold, else one launch per
     application accumulating in place"""
     items, defer.items, defer.claimed = defer.items, [], False
+    if all(st is not None for _, _, st in items):
+        # decode-step order, earliest first (backward recorded them latest first).  The launch dispatches its workgroups segment by
+        # segment: under the masked-step sparsity the early steps have the most live samples, i.e. the longest workgroups -- started
+        # first they leave a tail of short ones (latest-first ended the launch on its longest workgroups).  Dense and sparse launches
+        # use the same order, so the fixed-order slab reduce keeps them bit-identical.
+        items = sorted(items, key=lambda it: it[2])
     Co, KH, KW, Ci = wp.shape
     dwp = torch.empty_like(wp)
     L = hip.lib()
@@ -874,7 +880,7 @@ def _conv_backward(x, wp, dy, xs, stride, pad, dil, wcache, need_dx, need_dw, ac
         if wsch == "f16x2" and xs is not None and xs.scheme == wsch and \
                 _w3_pays(N * Ho * Wo, Co, KH * KW * Ci, Ci, free_splits=dy_cached is not None and wsch in dy_cached):
             dys = dy_cached[wsch] if (dy_cached is not None and wsch in dy_cached) else split_op(dy, wsch, channel=True)
-            defer.items.append((xs, dys, step if rc is not None else None))
+            defer.items.append((xs, dys, step))
             deferred = True
     if need_dx:
         beta = 0
