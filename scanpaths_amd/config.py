@@ -45,7 +45,7 @@ _ENV = {       # env name -> (switch, parser)
 }
 # timing-library knobs (sp_set_tuning; honoured by libscanpaths_amd_timing.so only): passed through under SP_ALLOW_ENV_TUNING=1
 TIMING_KNOBS = {"SP_H2_DBG": b"h2_dbg", "SP_HW_DBG": b"hw_dbg", "SP_B3_DBG": b"b3_dbg", "SP_HW_SPLITS": b"hw_splits", "SP_H2_HALO": b"h2_halo",
-                "SP_ROW_ORDER": b"row_order"}
+                "SP_ROW_ORDER": b"row_order", "SP_HW_CAP": b"hw_cap"}
 
 settings = dict(DEFAULTS)
 _announced = set()

@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // libscanpaths_amd_timing.so, `make timing`, loaded by tools/ through SP_LIBRARY=timing); the product build reads no environment variable.
 // (Schedule variants that lost their A/B were removed in round 3; their measurements are in DESIGN.md.)
 enum { SP_TUNE_AMAX_RESET = 0, SP_TUNE_HW_SPLITS = 1, SP_TUNE_H2_HALO = 2, SP_TUNE_H2_DBG = 3, SP_TUNE_HW_DBG = 4, SP_TUNE_B3_DBG = 5,
-       SP_TUNE_ROW_ORDER = 6, SP_TUNE_COUNT = 7 };
+       SP_TUNE_ROW_ORDER = 6, SP_TUNE_HW_CAP = 7, SP_TUNE_COUNT = 8 };
 extern int sp_tuning_values[SP_TUNE_COUNT];
 #ifdef SP_TIMING_VARIANTS
 static inline int sp_tuning_get(int key, int dflt) { return sp_tuning_values[key] < 0 ? dflt : sp_tuning_values[key]; }

@@ -1633,7 +1633,7 @@ int hw_splits(const sp_wgrad_desc* d) {
     const int64_t tiles = sp_cdiv(d->Co, 256) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, 128);
     int64_t want = sp_cdiv(forced >= 256 ? forced : 2048, tiles); // 1 workgroup per CU: aim for >= 8 rounds of 256
     want = std::min<int64_t>(want, std::max<int64_t>(1, M / 1024));   // >= 32 K-tiles per split
-    want = std::min<int64_t>(want, 64);
+    want = std::min<int64_t>(want, tiles <= 16 ? sp_tuning_get(SP_TUNE_HW_CAP, 64) : 64);
     return (int)std::max<int64_t>(1, want);
 }
 

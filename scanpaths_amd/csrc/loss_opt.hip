@@ -193,11 +193,11 @@ extern "C" int sp_scale_by(const float* x, const float* scale, int64_t n, float*
 
 extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
 
-int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
+int sp_tuning_values[SP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
 
 extern "C" int sp_set_tuning(const char* name, int value) {
     if (!name) return SP_ENULL;
-    const char* names[SP_TUNE_COUNT] = {"amax_reset", "hw_splits", "h2_halo", "h2_dbg", "hw_dbg", "b3_dbg", "row_order"};
+    const char* names[SP_TUNE_COUNT] = {"amax_reset", "hw_splits", "h2_halo", "h2_dbg", "hw_dbg", "b3_dbg", "row_order", "hw_cap"};
     for (int i = 0; i < SP_TUNE_COUNT; ++i) {
         const char *a = names[i], *b = name;
         while (*a && *a == *b) { ++a; ++b; }

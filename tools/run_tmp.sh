@@ -1,7 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04r; mkdir -p $O
-timeout 300 python -m pytest tests/test_ops_gpu.py -q -m gpu -k "deferred_weight or bn_act or batchnorm or statistics" > $O/t_ops.log 2>&1; tail -3 $O/t_ops.log
-timeout 300 python -m pytest tests/test_model_gpu.py -q -m gpu -k "masked_step or train_step_matches_reference" > $O/t_model.log 2>&1; tail -3 $O/t_model.log
-for i in 1 2; do timeout 200 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dense-leg 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])
-for g in d['roofline']['timed_gemms']: print('   ', g['kernel'][:34], g['M'], g['N'], g['K'], g['launches_per_step'], g['avg_launch_ms'], g['tflops'])"; done
+O=gpurun_out/r04s; mkdir -p $O
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-leg > $O/bench_prof.json 2> $O/bench_prof.err
+f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summarize_prof.py "${f%_kernel_trace.csv}" $O/r04s > $O/summ_bench.log 2>&1
+find $O -name "*trace.csv" -delete
