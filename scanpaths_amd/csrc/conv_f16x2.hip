@@ -1631,10 +1631,30 @@ int hw_splits(const sp_wgrad_desc* d) {
     const int forced = sp_tuning_get(SP_TUNE_HW_SPLITS, 0);      // timing build only: < 256 = split count, >= 256 = workgroup target
     if (forced > 0 && forced < 256) return (int)std::min<int64_t>(forced, std::max<int64_t>(1, M / 32));
     const int64_t tiles = sp_cdiv(d->Co, 256) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, 128);
-    int64_t want = sp_cdiv(forced >= 256 ? forced : 2048, tiles); // 1 workgroup per CU: aim for >= 8 rounds of 256
-    want = std::min<int64_t>(want, std::max<int64_t>(1, M / 1024));   // >= 32 K-tiles per split
-    want = std::min<int64_t>(want, tiles <= 16 ? sp_tuning_get(SP_TUNE_HW_CAP, 64) : 64);
-    return (int)std::max<int64_t>(1, want);
+    if (forced >= 256 || sp_tuning_get(SP_TUNE_HW_CAP, 0) == 1) {      // round-3 rule (timing build: A/B against the cost rule below)
+        int64_t want = sp_cdiv(forced >= 256 ? forced : 2048, tiles); // 1 workgroup per CU: aim for >= 8 rounds of 256
+        want = std::min<int64_t>(want, std::max<int64_t>(1, M / 1024));   // >= 32 K-tiles per split
+        want = std::min<int64_t>(want, 64);
+        return (int)std::max<int64_t>(1, want);
+    }
+    // One workgroup per CU: the launch lasts  rounds x (K-tiles of a split + a workgroup's fixed cost),  rounds = ceil(tiles x splits /
+    // 256).  The old rule (>= 2048 workgroups, at most 64 splits) ignored the round quantisation that decides the few-tile shapes of
+    // the encoder: 5 tiles x 64 splits = 320 workgroups = 2 rounds of 160 K-tiles where 51 splits = 255 workgroups run ONE round of 201
+    // (measured on the 64 x 576 weight gradient at 80x128 maps: 393 us with 64 splits, 326 us with 128; tools/encoder_census.py under
+    // SP_LIBRARY=timing SP_HW_CAP).  Fixed cost of a workgroup (dispatch, prologue, 128 KB slab tile) ~ 12 K-tiles of this kernel; the
+    // slab reduce reads `splits` slabs: half a K-tile per split and round.  Large shapes keep their 8 splits under this rule.
+    const int64_t smax = std::min<int64_t>(128, std::max<int64_t>(1, M / 1024));       // >= 32 K-tiles per split
+    int64_t best = 1;
+    double best_cost = 1e30;
+    for (int64_t sp = 1; sp <= smax; ++sp) {
+        const double rounds = (double)sp_cdiv(tiles * sp, 256);
+        const double cost = rounds * ((double)sp_cdiv(sp_cdiv(M, sp), 32) + 12.0 + 0.5 * (double)sp);
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best = sp;
+        }
+    }
+    return (int)best;
 }
 
 // ---- scale + split kernels ------------------------------------------------------------------------------------

@@ -201,13 +201,22 @@ int choose_splits(const sp_wgrad_desc* d) {
     if (d->nbatch > 1) return 1;
     const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
     const int64_t tiles = sp_cdiv(d->Co, BM) * sp_cdiv((int64_t)d->KH * d->KW * d->Ci, BN);
-    // 2 workgroups fit per CU (LDS) -> 512 concurrent; aim for >= 8 full rounds so the last, partly filled round
-    // costs little (measured: 1152 blocks = 2.25 rounds ran the h-gate wgrad at 88 TF/s vs 125 TF/s for the forward)
-    int64_t want = sp_cdiv(4096, tiles);
-    const int64_t max_by_rows = std::max<int64_t>(1, M / 256);   // keep >= 8 K-tiles per split
-    want = std::min(want, max_by_rows);
-    want = std::min<int64_t>(want, tiles <= 8 ? 128 : 64);   // few-tile cases (Co <= 128 x K <= 512) need > 64 slabs to reach 512 workgroups
-    return (int)std::max<int64_t>(1, want);
+    // 2 workgroups fit per CU (LDS) -> 512 run together; the launch lasts  rounds x (K-tiles of a split + ~3 K-tiles of fixed cost),
+    // rounds = ceil(tiles x splits / 512)  (this kernel's K-tile is long: register-staged loads, one barrier pair per tile).  The old
+    // rule capped the few-tile shapes at 128 splits: the stem's weight gradient (2 tiles) ran 256 workgroups of 320 K-tiles on half
+    // the slots (1.15 ms), the 64 x 64 pointwise one 128 workgroups of 80 (0.32 ms).  >= 8 K-tiles per split.
+    const int64_t smax = std::min<int64_t>(512, std::max<int64_t>(1, M / 256));
+    int64_t best = 1;
+    double best_cost = 1e30;
+    for (int64_t sp = 1; sp <= smax; ++sp) {
+        const double rounds = (double)sp_cdiv(tiles * sp, 512);
+        const double cost = rounds * ((double)sp_cdiv(sp_cdiv(M, sp), BKP) + 3.0) + 0.02 * (double)sp;
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best = sp;
+        }
+    }
+    return (int)best;
 }
 
 }  // namespace
