@@ -2235,11 +2235,28 @@ extern "C" int sp_conv_wgrad_f16x2(const sp_wgrad_desc* d, const void* Xsplit, c
 static int hw2_splits(const sp_wgrad_desc* d, int nseg) {
     const int64_t M = (int64_t)d->N_img * d->Ho * d->Wo;
     const int64_t tiles = (int64_t)(d->Co / 256) * ((int64_t)d->KH * d->KW * d->Ci / 256);
-    // >= 8 rounds of 256 workgroups for the whole launch, chains of at most 20480 pixels (single-level accumulation), >= 64 K-tiles
-    // per workgroup (its 256 KB slab tile must stay a small part of its work)
-    int64_t want = std::max<int64_t>(sp_cdiv(8 * 256, tiles * nseg), sp_cdiv(M, 20480));
-    want = std::min<int64_t>(want, std::max<int64_t>(1, M / 2048));
-    return (int)std::max<int64_t>(1, want);
+    // chains of at most 20480 pixels (single-level accumulation), >= 64 K-tiles per workgroup (its 256 KB slab tile must stay a small
+    // part of its work); between these bounds the split count that minimises  rounds x (K-tiles of a split + ~20 K-tiles of fixed cost
+    // per workgroup),  rounds = ceil(tiles x nseg x splits / 256): the round-3 rule (>= 8 rounds) ran the few-tile single launches of the
+    // encoder on 1.4-2.5 rounds' worth of short workgroups (36 tiles x 40 splits = 5.6 rounds of 64 K-tiles where 7 splits are one
+    // round of 366).  The deferred h-gate launch (2160 tile-segments) keeps its 4 splits.
+    const int64_t smin = sp_cdiv(M, 20480), smax = std::max<int64_t>(smin, M / 2048);
+    if (sp_tuning_get(SP_TUNE_HW_CAP, 0) == 1) {      // timing build: the round-3 rule, for the A/B
+        int64_t want = std::max<int64_t>(sp_cdiv(8 * 256, tiles * nseg), smin);
+        want = std::min<int64_t>(want, std::max<int64_t>(1, M / 2048));
+        return (int)std::max<int64_t>(1, want);
+    }
+    int64_t best = smin;
+    double best_cost = 1e30;
+    for (int64_t sp = smin; sp <= smax; ++sp) {
+        const double rounds = (double)sp_cdiv(tiles * nseg * sp, 256);
+        const double cost = rounds * ((double)sp_cdiv(sp_cdiv(M, sp), 32) + 20.0 + 0.5 * (double)sp);
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best = sp;
+        }
+    }
+    return (int)std::max<int64_t>(1, best);
 }
 static bool hw2_applies(const sp_wgrad_desc* d, int nseg) {
     if (nseg < 1 || nseg > HW_MAXSEG || d->nbatch != 1) return false;
