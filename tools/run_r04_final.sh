@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 artifact run (GPU box, repo root): full -m gpu suite, bench lines (headline, dense backward, RCCL world of one), kernel trace,
 # backbone bench, the other BASELINE configurations, gradient-error table, example.  PMC passes: tools/run_r04_pmc.sh.
-O=gpurun_out/r04final2
+O=gpurun_out/r04final3
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
