@@ -319,3 +319,37 @@ def test_halo_block_swizzle_is_bank_conflict_free_for_every_base():
     assert conflicts(range(600), halo) == 0
     assert conflicts(range(0, 256, 16), ring) == 0            # the ring's fragment rows start at multiples of 16
     assert conflicts(range(600), ring) > 3000
+
+
+def test_split_counts_of_the_weight_gradient_kernels_follow_the_round_quantisation_rule():
+    """Host logic, no GPU: the split-K count of a weight-gradient launch minimises  rounds x (K-tiles of a split + fixed cost)  with
+    rounds = ceil(tiles x splits / resident workgroups).  Read back through the workspace queries (bytes = splits x Co x
+    ldo x 4): the few-tile shapes of the encoder fill ONE round instead of one and a fraction, the h-gate shapes keep 8 / 4 splits."""
+    from scanpaths_amd import hip
+    L = hip.lib()
+
+    def desc(M_img, Ho, Wo, Ci, Co, k):
+        return hip.WgradDesc(M_img, Ho, Wo, Ci, Ci, Ho, Wo, Co, Co, k, k, 1, k // 2, 1, k * k * Ci, 0, 1.0, 1, 0, 0, 0)
+
+    def splits(fn, d, *a):
+        Co, ldo = d.Co, d.ldo
+        return fn(ctypes.byref(d), *a) // (Co * ldo * 4)
+
+    hw = L.sp_conv_wgrad_f16x2_workspace
+    hw2 = L.sp_conv_wgrad_f16x2_multi_workspace
+    # hw_kernel: tiles = ceil(Co / 256) x ceil(K / 128), one workgroup per CU
+    assert splits(hw, desc(32, 80, 128, 64, 64, 3)) == 51          # 5 tiles: 255 workgroups = one round (was 64 -> 320 = two)
+    assert splits(hw, desc(32, 80, 128, 128, 128, 3)) == 28        # 9 tiles: 252 workgroups
+    assert splits(hw, desc(32, 40, 64, 256, 1024, 1)) == 32        # 8 tiles: 256 workgroups
+    assert splits(hw, desc(32, 40, 64, 512, 2048, 3)) == 8         # the h-gate conv: 288 tiles, 9 rounds, as before
+    # hw2_kernel: tiles = (Co / 256) x (K / 256); chains <= 20480 pixels, >= 64 K-tiles per split
+    assert splits(hw2, desc(32, 40, 64, 512, 512, 3), 1) == 7      # 36 tiles: 252 workgroups (was 40 splits = 5.6 rounds)
+    assert splits(hw2, desc(32, 40, 64, 256, 256, 3), 1) == 28     # 9 tiles
+    assert splits(hw2, desc(32, 40, 64, 512, 2048, 3), 15) == 15 * 4    # the deferred h-gate launch (15 segments x 4 splits): unchanged
+    for d in (desc(32, 40, 64, 512, 2048, 3), desc(2, 40, 64, 512, 2048, 3)):
+        M = d.N_img * d.Ho * d.Wo
+        s = splits(hw2, d, 1)
+        assert -(-M // s) <= 20480 and s >= 1, (M, s)             # single-level accumulation bounds the chain
+    # fp32 wgrad_kernel: two workgroups per CU
+    fp = L.sp_conv_wgrad_workspace
+    assert splits(fp, desc(32, 80, 128, 64, 64, 1)) == 512         # one tile: 512 workgroups (was 128)
