@@ -104,21 +104,36 @@ FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm"
 # FlatAdam gives every parameter a view of ONE flat gradient buffer as its .grad and marks it (`_sp_flat`).  A backward kernel that
 # produces the gradient of such a LEAF parameter, and is the first to do so since FlatAdam.zero_grad() cleared the buffer, writes into
 # that view and hands autograd None: the ~160 per-parameter read-modify-write adds of AccumulateGrad (and as many temporaries) per
-# training step go away.  The optimizer's post-accumulate hook (gradient-ready bookkeeping, bucketed all-reduce) is called by hand.
+# training step go away.  The parameter's AccumulateGrad node still runs (with an undefined gradient) and fires the optimizer's
+# post-accumulate hook (gradient-ready bookkeeping, bucketed all-reduce) once all contributions of the backward pass exist.
 # A second gradient for the same parameter before the next zero_grad() takes the ordinary autograd path and is added.
 def _grad_slot(param):
-    """the marker of a leaf parameter whose .grad is a FlatAdam view, else None"""
-    if not DIRECT_GRAD or param is None or not getattr(param, "is_leaf", False):
+    """(parameter, its AccumulateGrad node) of a leaf parameter whose .grad is a FlatAdam view, else None"""
+    if not DIRECT_GRAD or param is None or not getattr(param, "is_leaf", False) or not param.requires_grad:
         return None
-    return getattr(param, "_sp_flat", None)
+    if getattr(param, "_sp_flat", None) is None:
+        return None
+    try:
+        return param, torch.autograd.graph.get_gradient_edge(param).node
+    except Exception:          # (a torch without gradient edges: ordinary path)
+        return None
 
 
-def _take_grad_view(param, phys_perm=None):
+def _take_grad_view(pn, phys_perm=None):
     """-> (slot, tensor to write the gradient into) when the gradient may be written in place, else (None, None).
-    phys_perm: permutation that must make the view contiguous (conv weights: (0, 2, 3, 1) = [Co, KH, KW, Ci])"""
-    slot = _grad_slot(param)
-    if slot is None:
+    pn: what _grad_slot returned in forward.  phys_perm: permutation that must make the view contiguous (conv weights: (0, 2, 3, 1)).
+    Only inside a backward pass that ACCUMULATES into this parameter (loss.backward()): under torch.autograd.grad(), or
+    backward(inputs=...) without it, the engine does not run the parameter's AccumulateGrad node and the caller wants the gradient
+    returned -- writing it into .grad there would be a silent side effect."""
+    if pn is None:
         return None, None
+    param, node = pn
+    try:
+        if not torch._C._will_engine_execute_node(node):
+            return None, None
+    except RuntimeError:       # "a leaf node was passed ... running autograd.grad()"
+        return None, None
+    slot = param._sp_flat
     g = slot.peek(param)
     if g is None:
         return None, None
@@ -714,7 +729,7 @@ class _Conv2d(Function):
         # grad_store / grad_accum: GradMerge of a block input -- leave the input gradient there / accumulate into what is there
         # step: the decode step this application belongs to (row sparsity of its backward, see rows_ctx)
         ctx.grad_store, ctx.grad_accum, ctx.step = grad_store, grad_accum, step
-        ctx.w_param = w if (_grad_slot(w) is not None and w.dim() == 4) else None      # its gradient may go straight into the flat buffer
+        ctx.w_param = _grad_slot(w) if w.dim() == 4 else None      # its gradient may go straight into the flat buffer
         defer = wcache.get("defer") if isinstance(wcache, dict) else None       # DeferredWgrad of a weight applied T times
         ctx.defer_final = defer.claim() if (defer is not None and ctx.needs_input_grad[1]) else False
         ctx.dy_token = None
@@ -1175,7 +1190,7 @@ class _BnActSplit(Function):
     def forward(ctx, x, gamma, beta, rmean, rvar, residual, momentum, eps, relu, emit_fwd, emit_bwd, pre, res_store=None,
                 dy_token=None, skip_z=False):
         ctx.res_store = res_store          # GradMerge: the residual's gradient is left there for conv1's data gradient to add to
-        ctx.params = (gamma if _grad_slot(gamma) is not None else None, beta if _grad_slot(beta) is not None else None)
+        ctx.params = (_grad_slot(gamma), _grad_slot(beta))
         ctx.dy_token = dy_token            # set: the producing conv's backward reads only the split gradient -> dx stays unwritten
         # pre: (partial, mm, G) -- first statistics stage already done by the producing conv's epilogue (conv2d bn_stats=True)
         x = x.contiguous()

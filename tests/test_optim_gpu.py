@@ -156,3 +156,23 @@ def test_parameter_gradients_written_into_the_flat_buffer_equal_autograds_accumu
     assert torch.equal(res[False][0][0], res[True][0][0])
     assert torch.equal(res[False][0][1], res[True][0][1])
     assert torch.equal(res[False][1], res[True][1])
+    # torch.autograd.grad() must get its gradients RETURNED and leave .grad alone: the in-place path is taken only inside a
+    # backward pass whose engine will run the parameter's AccumulateGrad node
+    monkeypatch.setattr(F, "DIRECT_GRAD", True)
+    m = baseline_osie(convLSTM_length=T, arch="resnet18")
+    fill_module(m, 9)
+    m = m.to(DEV).train()
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=5e-4, clip=12.5)
+    opt.zero_grad()
+    F.reset_fusion_counts()
+    pred = m(b["images"])
+    loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+    names = dict(m.named_parameters())
+    picks = [names["resnet.7.1.conv2.weight"], names["resnet.7.1.bn2.weight"], names["sal_conv.weight"]]
+    gs = torch.autograd.grad(loss, picks)
+    torch.cuda.synchronize()
+    assert F.FUSION_COUNTS["direct_grad"] == 0
+    assert float(opt.flat_g.abs().max()) == 0.0
+    i0 = [n for n, _ in m.named_parameters()].index("resnet.7.1.conv2.weight")
+    ref = res[True][0][0][opt._offs[i0]:opt._offs[i0] + picks[0].numel()]
+    assert torch.equal(gs[0].permute(0, 2, 3, 1).reshape(-1), ref)          # (the flat view keeps the channels_last layout)
