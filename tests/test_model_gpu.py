@@ -615,21 +615,23 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
 
 
 
-def test_masked_step_sparsity_of_the_backward_is_bit_identical_to_the_dense_backward(monkeypatch):
+@pytest.mark.parametrize("task", ["AiR", "OSIE", "COCO_Search18"])
+def test_masked_step_sparsity_of_the_backward_is_bit_identical_to_the_dense_backward(task, monkeypatch):
     """supervised_loss(skip_masked_backward=True): behind a sample's last masked-in decode step every gradient of the decoder's
     recurrence is exactly zero (the loss multiplies by action_masks / duration_masks, AiR/models/loss.py:10-14,27-32; AiR/train.py:190-197);
     the cell backward (zeros without reading), the h-gate conv's data gradient (zero tiles without multiplying) and its deferred weight
     gradient (those samples' pixels skipped, pixel ranges that cut samples) use that -- loss and EVERY parameter gradient must equal the
     dense backward bit for bit, on the benchmark's kernel path (40x64 map, fused cell, deferred hw2 launch), with scanpaths that end at
-    the first step, in the middle, at the last step, and a sample without any loss term."""
+    the first step, in the middle, at the last step, and a sample without any loss term.  All three tasks: two decoder streams and two
+    heads (AiR), one stream (OSIE), per-sample heads selected by the task id (COCO_Search18)."""
     from scanpaths_amd import functional as F
     from scanpaths_amd.models.loss import supervised_loss
     from scanpaths_amd.synth import make_batch
     if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3 or F.THROUGHPUT_MODE:
         pytest.skip("2xfp16 back-end not active")
     T, NB, seed = 8, 5, 4
-    meta = dict(task="AiR", arch="resnet18", T=T, weight_seed=seed, weight_family="tame")
-    b = {k: v.to(DEV) for k, v in make_batch("AiR", NB, 320, 512, T, seed=seed).items()}
+    meta = dict(task=task, arch="resnet18", T=T, weight_seed=seed, weight_family="tame")
+    b = {k: v.to(DEV) for k, v in make_batch(task, NB, 320, 512, T, seed=seed).items()}
     lengths = [1, 4, T, 2, 0]                                      # last loss step per sample: 0, 3, T - 1, 1, none
     am, dm = torch.zeros(NB, T, device=DEV), torch.zeros(NB, T, device=DEV)
     for i, L in enumerate(lengths):
@@ -641,7 +643,7 @@ def test_masked_step_sparsity_of_the_backward_is_bit_identical_to_the_dense_back
     for sparse in (False, True):
         model = _build(meta, 40, 64).train()
         F.reset_fusion_counts()
-        pred = model(b["images"], b["attention_maps"], b["performances"])
+        pred = _call(model, meta, b)
         loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], am, dm, 1.0, skip_masked_backward=sparse)
         loss.backward()
         torch.cuda.synchronize()
@@ -657,8 +659,8 @@ def test_masked_step_sparsity_of_the_backward_is_bit_identical_to_the_dense_back
     assert not diff, diff[:8]
     # a second, dense backward afterwards is untouched by the earlier sparse one (the context is gone)
     model = _build(meta, 40, 64).train()
-    pred = model(b["images"], b["attention_maps"], b["performances"])
-    (pred["all_actions_prob"].sum() + pred["log_normal_mu"].sum()).backward()          # a loss that reads EVERY step: must stay dense
+    pred = _call(model, meta, b)
+    (pred["actions" if task == "OSIE" else "all_actions_prob"].sum() + pred["log_normal_mu"].sum()).backward()          # a loss that reads EVERY step: must stay dense
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     g_h = dict(model.named_parameters())["lstm.input_h.weight"].grad
     assert float(g_h.abs().max()) > 0
