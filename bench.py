@@ -117,8 +117,14 @@ def parse():
     ap.add_argument("--arch", type=str, default="resnet50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-backward", action="store_true",
-                    help="do not skip the (sample, decode step) pairs behind a sample's last masked-in step in the backward pass (their gradients "
-                         "are exactly zero; default: skipped, results identical -- the line reports the dense time of the same process too)")
+                    help="config row_sparsity off: multiply the exact zeros behind every sample's last masked-in decode step like the reference "
+                         "does (default: the decoder's backward derives them from the gradient that reaches its outputs and skips them, results "
+                         "identical -- the line reports the dense time of the same process too)")
+    ap.add_argument("--dropin", action="store_true",
+                    help="make the reference's literal call sequence (AiR/train.py:188-205: two loss calls, clip_grad_norm_, torch.optim.Adam, "
+                         "LambdaLR) the timed region of the line instead of the fused-loss / FlatAdam step (default: timed as a secondary leg, "
+                         "JSON key 'dropin')")
+    ap.add_argument("--no-dropin-leg", action="store_true", help="do not time the drop-in call sequence after the timed region")
     ap.add_argument("--no-dense-leg", action="store_true",
                     help="do not time the dense backward after the timed region (kernel traces of the headline step only)")
     ap.add_argument("--force-bucketer", action="store_true",
@@ -229,6 +235,42 @@ def call_model(model, args, b, training):
     return model(b["images"], b["attention_maps"], b["tasks"])
 
 
+def dropin_step(args, model, b):
+    """The reference's own supervised iteration on the HIP model, call for call (AiR/train.py:116-117 optimizer, :156-167 LambdaLR,
+    :188-205 the iteration; OSIE/train.py and COCO_Search18/train.py have the same shape): stock torch.optim.Adam, the two separate loss
+    calls summed by autograd, torch.nn.utils.clip_grad_norm_, LambdaLR.step.  Only the tensorboard scalars of :206-210 are left out
+    (logging is outside SURVEY 8's path).  Returns the step function."""
+    from scanpaths_amd.models.loss import CrossEntropyLoss, MLPLogNormalDistribution
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-08,
+                                 weight_decay=5e-5 if args.task == "air" else 5e-4)
+    iters_per_epoch, warmup_epoch, start_rl_epoch = 1000, 1, 10
+
+    def lr_lambda(iteration):          # :156-164 (supervised branches)
+        if iteration <= iters_per_epoch * warmup_epoch:
+            return iteration / (iters_per_epoch * warmup_epoch)
+        return 1 - (iteration - iters_per_epoch * warmup_epoch) / (iters_per_epoch * (start_rl_epoch - warmup_epoch))
+    for g_ in optimizer.param_groups:          # (LambdaLR with last_epoch >= 0 resumes: it wants the groups' initial_lr, as a loaded checkpoint has)
+        g_.setdefault("initial_lr", g_["lr"])
+    lr_scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lr_lambda, last_epoch=iters_per_epoch // 2)
+    scanpaths, durations = b["scanpaths"], b["durations"]
+    action_masks, duration_masks = b["action_masks"], b["duration_masks"]
+    clip, lambda_1 = 12.5, 1.0
+
+    def step():
+        optimizer.zero_grad()
+        predicts = call_model(model, args, b, True)
+        loss_actions = CrossEntropyLoss(predicts["actions" if "actions" in predicts else "all_actions_prob"], scanpaths, action_masks)
+        loss_duration = MLPLogNormalDistribution(predicts["log_normal_mu"], predicts["log_normal_sigma2"], durations, duration_masks)
+        loss = loss_actions + lambda_1 * loss_duration
+        loss.backward()
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        optimizer.step()
+        lr_scheduler.step()
+        return loss
+    return step
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` (N > 1) without a torch.distributed launcher around it: THIS process never touches the GPU (no HIP
     call, no exec of an initialised process); it starts N ranks -- one process per GPU, RCCL -- as a child
@@ -302,8 +344,16 @@ def main():
     model = build_model(args, dev)
     b = {k: v.to(dev) for k, v in make_batch(task, args.batch, args.height, args.width, args.T, seed=0, rank=rank).items()}
 
-    sparse_bwd = [not args.dense_backward]       # (a cell: the dense leg below flips it for the same step function)
-    if args.mode == "train":
+    if args.dense_backward:
+        sp_config.set(row_sparsity=False)            # tagged in config.non_default_switches
+    sparse_on = sp_config.settings["row_sparsity"]
+    if args.mode == "train" and args.dropin:
+        if world != 1:
+            raise SystemExit("bench.py: --dropin times the reference's single-process call sequence (its DataParallel has no counterpart "
+                             "here; the multi-GPU path is FlatAdam's bucketed all-reduce)")
+        model.train()
+        step = dropin_step(args, model, b)
+    elif args.mode == "train":
         model.train()
         if world > 1:
             from scanpaths_amd.ddp import broadcast_module_state_
@@ -321,8 +371,7 @@ def main():
                 from scanpaths_amd.ddp import global_mask_normaliser
                 mask_sums = global_mask_normaliser(torch.cat([F.device_sum(b["action_masks"]),
                                                               F.device_sum(b["duration_masks"])]))
-            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0,
-                                         mask_sums, skip_masked_backward=sparse_bwd[0])
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0, mask_sums)
             loss.backward()
             opt.step()
             return loss
@@ -362,10 +411,18 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
-    sparsity = None
-    if args.mode == "train" and world == 1 and sparse_bwd[0] and not args.no_dense_leg:
+    sparsity, dropin = None, None
+    act_frac = None
+    if args.mode == "train":
+        # what the gate derived from the gradient of the last step: last[b] per sample -> the live fraction of (sample, step) pairs of steps 1..T-1
+        rows_tok = getattr(model, "last_decode_rows", None)
+        if sparse_on and rows_tok is not None and rows_tok.rc is not None:
+            last = rows_tok.rc.last
+            Tn = args.T
+            act_frac = float((last.view(-1, 1) >= torch.arange(1, Tn, device=last.device).view(1, -1)).float().mean()) if Tn > 1 else 1.0
+    if args.mode == "train" and world == 1 and sparse_on and not args.no_dense_leg:
         # the same step with the dense backward pass (what the reference computes), same process, after the timed region
-        sparse_bwd[0] = False
+        sp_config.set(row_sparsity=False)
         step()
         sync()
         t1 = time.perf_counter()
@@ -373,20 +430,37 @@ def main():
             step()
         sync()
         dense_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        sparse_bwd[0] = True
-        am, dm = b["action_masks"], b["duration_masks"]
-        Tn = am.shape[1]
-        last = (((am > 0) | (dm > 0)).int() * torch.arange(1, Tn + 1, device=am.device, dtype=torch.int32)).amax(1) - 1
-        frac = float((last.view(-1, 1) >= torch.arange(1, Tn, device=am.device).view(1, -1)).float().mean())
-        sparsity = {"skip_masked_backward": True, "dense_backward_ms_per_step": round(dense_ms, 2),
+        sp_config.set(row_sparsity=True)
+        sparsity = {"derived_from_output_gradient": True, "dense_backward_ms_per_step": round(dense_ms, 2),
                     "dense_backward_images_per_s": round(args.batch * 1e3 / dense_ms, 3),
-                    "active_fraction_of_sample_steps": round(frac, 4),
+                    "active_fraction_of_sample_steps": round(act_frac, 4) if act_frac is not None else None,
                     "note": "the loss multiplies by action_masks / duration_masks (AiR/models/loss.py:10-14,27-32): behind a sample's last "
-                            "masked-in step every gradient of the decoder's recurrence is EXACTLY zero; the cell backward, the h-gate conv's data "
-                            "gradient and its deferred weight gradient skip those (sample, step) pairs instead of multiplying zeros -- gradients "
-                            "bit-identical to the dense backward (tests/test_model_gpu.py::test_masked_step_sparsity...); forward, loss, "
-                            "clip and Adam are unchanged; synthetic scanpath lengths are uniform in 1..T (SURVEY.md 8d); `--dense-backward` "
-                            "times the dense form as the headline instead"}
+                            "masked-in step every gradient of the decoder's recurrence is EXACTLY zero.  An identity node behind decode()'s "
+                            "outputs reads last[b] off the gradient that arrives (any consumer set; no switch, no caller promise) and the cell "
+                            "backward, the h-gate conv's data gradient, its deferred weight gradient and the fan-ins skip those (sample, step) "
+                            "pairs instead of multiplying zeros -- gradients bit-identical to the dense backward "
+                            "(tests/test_model_gpu.py::test_masked_step_sparsity...); forward, loss, clip and Adam are unchanged; synthetic "
+                            "scanpath lengths are uniform in 1..T (SURVEY.md 8d), real length distributions skip less or more; "
+                            "`--dense-backward` makes the dense form the line"}
+    if args.mode == "train" and world == 1 and not args.dropin and not args.no_dropin_leg and not args.force_bucketer:
+        # the reference's literal call sequence on a second, identically initialised model (the first one's parameters live in FlatAdam's
+        # flat buffers): same process, same box, after the timed region
+        model2 = build_model(args, dev).train()
+        dstep = dropin_step(args, model2, b)
+        for _ in range(max(args.warmup, 1)):
+            dstep()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            dloss = dstep()
+        sync()
+        d_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        dropin = {"dropin_ms_per_step": round(d_ms, 2), "dropin_images_per_s": round(args.batch * 1e3 / d_ms, 3),
+                  "vs_headline_step": round(d_ms / (dt / args.steps * 1e3), 4), "loss": round(float(dloss.detach()), 5),
+                  "sequence": "AiR/train.py:188-205 call for call on the HIP model: optimizer.zero_grad(); model(...); CrossEntropyLoss + "
+                              "MLPLogNormalDistribution (two calls) ; loss.backward(); torch.nn.utils.clip_grad_norm_; torch.optim.Adam.step; "
+                              "LambdaLR.step (tensorboard scalars left out); the masked-step sparsity applies by itself"}
+        del model2, dstep
     ddp_info = None
     if args.force_bucketer:
         ddp_info = bucketer_overhead(opt, step, sync, args.steps, dt / args.steps * 1e3)
@@ -404,11 +478,7 @@ def main():
     summ = timer.summary()
     # launches that skip samples behind their last masked-in step ("_rows" keys) EXECUTE only the active fraction of the dense FLOPs
     # their key was priced with: the roofline below counts the executed ones
-    if args.mode == "train":
-        am_, dm_ = b["action_masks"], b["duration_masks"]
-        Tn_ = am_.shape[1]
-        last_ = (((am_ > 0) | (dm_ > 0)).int() * torch.arange(1, Tn_ + 1, device=am_.device, dtype=torch.int32)).amax(1) - 1
-        act_frac = float((last_.view(-1, 1) >= torch.arange(1, Tn_, device=am_.device).view(1, -1)).float().mean())
+    if args.mode == "train" and act_frac is not None:
         for k_, d_ in summ.items():
             if k_[0].endswith("_rows"):
                 d_["flops_per_launch"] *= act_frac
@@ -477,10 +547,20 @@ def main():
         # end to end: reduced (necessary) FLOPs per image x images/s, SURVEY.md §8(d) line "roofline.achieved"
         gmac = reduced_fwd_gmac(args.arch, args.height, args.width, args.T, args.task)
         tflop_per_img = gmac * 2e9 * (3.0 if args.mode == "train" else 1.0) / 1e12
+        # FLOPs the step EXECUTES: the masked-step sparsity removes the data and weight gradient of the h-gate conv (2 x 24.16 GMAC at
+        # 320x512 per application) for the dead (sample, step) pairs of steps 1..T-1
+        exec_per_img = tflop_per_img
+        if args.mode == "train" and act_frac is not None:
+            exec_per_img -= 2 * 24.16 * (args.height * args.width / (320.0 * 512.0)) * 2e9 * (args.T - 1) * (1.0 - act_frac) / 1e12
         roofline["end_to_end"] = {"reduced_tflop_per_image": round(tflop_per_img, 3),
-                                  "achieved_tflops": round(tflop_per_img * value / world, 1),
-                                  "frac_of_2500": round(tflop_per_img * value / world / PEAK_F16_MFMA_TFLOPS, 4),
-                                  "note": "reduced-column FLOPs/img (BASELINE.md §3; train = 3x forward) x measured img/s per GPU"}
+                                  "executed_tflop_per_image": round(exec_per_img, 3),
+                                  "achieved_tflops_executed": round(exec_per_img * value / world, 1),
+                                  "frac_of_2500_executed": round(exec_per_img * value / world / PEAK_F16_MFMA_TFLOPS, 4),
+                                  "achieved_tflops_dense_equivalent": round(tflop_per_img * value / world, 1),
+                                  "frac_of_2500_dense_equivalent": round(tflop_per_img * value / world / PEAK_F16_MFMA_TFLOPS, 4),
+                                  "note": "reduced-column FLOPs/img (BASELINE.md §3; train = 3x forward) x measured img/s per GPU; 'executed' "
+                                          "subtracts the h-gate data / weight gradients of the (sample, step) pairs the sparse backward skips, "
+                                          "'dense_equivalent' prices the step as if it had multiplied those zeros (what the reference does)"}
 
     headline = (args.task == "air" and args.mode == "train" and args.precision == "f32" and args.batch == 32 and args.T == 16
                 and (args.height, args.width) == (320, 512) and args.arch == "resnet50")
@@ -511,7 +591,12 @@ def main():
     if sparsity is not None:
         out["backward_sparsity"] = sparsity
     elif args.mode == "train":
-        out["backward_sparsity"] = {"skip_masked_backward": bool(sparse_bwd[0])}
+        out["backward_sparsity"] = {"derived_from_output_gradient": bool(sparse_on),
+                                    "active_fraction_of_sample_steps": round(act_frac, 4) if act_frac is not None else None}
+    if dropin is not None:
+        out["dropin"] = dropin
+    if args.mode == "train" and args.dropin:
+        out["metric"] = metric + " [--dropin: the reference's literal call sequence AiR/train.py:188-205]"
     if ddp_info is not None:
         out["ddp"] = ddp_info
         out["metric"] = metric + " [--force-bucketer: RCCL world of one, NOT the headline line]"

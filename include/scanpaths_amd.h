@@ -28,7 +28,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* unsupported shape / alignment */
 #define SP_ENULL (-2)    /* required pointer is NULL */
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2
 int sp_abi_version(void);
 
 /* The ONE piece of process-wide state in the product library: sp_set_tuning("amax_reset", 1) tells the launchers that the caller
@@ -443,6 +443,12 @@ int sp_log_action(const float* p, const float* mask, int B, int T, const float* 
 int sp_log_duration(const float* d, const float* mu, const float* sigma2, const float* mask, int B, int T, const float* mask_sum,
                     float* out, float* dmu, float* dsigma2, void* stream);
 int sp_rowscale(const float* coef, const float* g, int B, int T, float* out, void* stream);
+/* Masked-step sparsity of the backward pass, derived from the gradient that actually reaches the model's outputs (the reference
+ * multiplies every loss term by action_masks / duration_masks, AiR/models/loss.py:10-14,27-32, AiR/train.py:190-197, and computes the
+ * resulting zeros densely).  grads: HOST array of `count` (<= 8) device pointers to contiguous fp32 output gradients
+ * [nstack][B][T][row_len[k]] (NULL entry: that gradient never arrived = zero); last[b] (device, [B]) = the last decode step t at
+ * which any element of any of them is non-zero (NaN counts), -1 when there is none.  No host synchronisation. */
+int sp_rows_last(const float* const* grads, const int64_t* row_len, int count, int nstack, int B, int T, int* last, void* stream);
 /* out = x * (*scale) with the scalar on the device (chain-rule factor of the loss, no host sync) */
 int sp_scale_by(const float* x, const float* scale, int64_t n, float* out, void* stream);
 /* deterministic sums (fp64 accumulation); workspace >= sp_sumsq_workspace(n) bytes for both */

@@ -181,7 +181,50 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* coef, const 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = coef[i] * g[i / T];
 }
 
+// last[b] = the last decode step at which ANY output gradient of sample b is non-zero (NaN counts as non-zero); -1: none.
+// One block per sample; steps are visited from the last one down and the block stops at the first live step, so a sample whose
+// scanpath fills all T steps costs one row per tensor and a sample without any loss term reads its rows once.
+struct RowsLastList {
+    const float* g[8];
+    long long row_len[8];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void rows_last_kernel(RowsLastList l, int nstack, int B, int T, int* __restrict__ last) {
+    const int b = blockIdx.x;
+    int t = T - 1;
+    for (; t >= 0; --t) {
+        int live = 0;
+        for (int k = 0; k < l.count; ++k) {
+            const long long rl = l.row_len[k];
+            for (int h = 0; h < nstack; ++h) {
+                const float* row = l.g[k] + (((long long)h * B + b) * T + t) * rl;
+                for (long long i = threadIdx.x; i < rl; i += 256) live |= (row[i] != 0.f);
+            }
+        }
+        if (__syncthreads_or(live)) break;
+    }
+    if (threadIdx.x == 0) last[b] = t;
+}
+
 }  // namespace
+
+extern "C" int sp_rows_last(const float* const* grads, const int64_t* row_len, int count, int nstack, int B, int T, int* last,
+                            void* stream) {
+    if (!grads || !row_len || !last) return SP_ENULL;
+    if (count < 1 || count > 8 || nstack < 1 || B < 1 || T < 1) return SP_EINVAL;
+    RowsLastList l;
+    l.count = 0;
+    for (int k = 0; k < count; ++k) {
+        if (!grads[k]) continue;                  // a gradient that never arrived is a zero gradient
+        if (row_len[k] < 1) return SP_EINVAL;
+        l.g[l.count] = grads[k];
+        l.row_len[l.count++] = row_len[k];
+    }
+    hipLaunchKernelGGL(rows_last_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, l, nstack, B, T, last);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
 
 extern "C" int sp_scale_by(const float* x, const float* scale, int64_t n, float* out, void* stream) {
     if (!x || !scale || !out) return SP_ENULL;

@@ -97,7 +97,7 @@ _apply_config()
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
-                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0}
+                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0}
 
 
 # ---- parameter gradients written straight into the optimizer's flat gradient buffer -------------------------------------------------
@@ -112,6 +112,8 @@ def _grad_slot(param):
     if not DIRECT_GRAD or param is None or not getattr(param, "is_leaf", False) or not param.requires_grad:
         return None
     if getattr(param, "_sp_flat", None) is None:
+        return None
+    if getattr(param, "_backward_hooks", None):      # a user tensor hook (p.register_hook: scaling, logging) must see the gradient: autograd's path
         return None
     try:
         return param, torch.autograd.graph.get_gradient_edge(param).node
@@ -145,17 +147,20 @@ def _take_grad_view(pn, phys_perm=None):
     return slot, v
 
 
-# ---- row sparsity of the backward pass implied by the loss masks (scanpath_loss(skip_masked_backward=True)) ---------------------------
-# A sample whose scanpath ended at step L receives no loss gradient at any decode step t > L (the loss multiplies by action_masks /
-# duration_masks, AiR/models/loss.py:10-14,27-32; AiR/train.py:190-197), and nothing of sample b reaches another sample in the decoder:
-# the whole backward recurrence of (b, t > L_b) is EXACTLY zero.  The reference computes those zeros densely; here the loss leaves
-# `last[b]` (device int32, no host sync) in this context for the duration of ITS backward pass and the three kernels that carry the
-# recurrence's cost consult it: the cell backward writes zeros without reading, the h-gate conv's data gradient writes zero tiles without
-# multiplying, its deferred weight gradient skips those samples' pixels.  With scanpath lengths uniform in 1..T that is 44 % of the
-# (sample, step) pairs.  Only valid when the loss is the ONLY consumer of the model's outputs -- hence opt-in at the loss call.
-_ROWS = None
-
-
+# ---- masked-step sparsity of the backward pass, derived from the gradient that reaches the model's outputs ----------------------------
+# The reference multiplies every loss term by action_masks / duration_masks (AiR/models/loss.py:10-14,27-32; AiR/train.py:190-197): a
+# sample whose scanpath ended at step L sends no gradient into any prediction of a decode step t > L, nothing of sample b reaches
+# another sample inside the decoder (no BatchNorm there, per-sample attention memories), so the whole backward recurrence of
+# (b, t > L_b) is EXACTLY zero.  The reference computes those zeros densely.  Here nobody has to promise anything: decode() hands its
+# outputs through ONE identity node (_OutputGate).  Autograd runs that node's backward once the gradients of ALL outputs exist -- from
+# whatever consumed them: the fused loss, the reference's two separate loss calls, an auxiliary loss, the RL losses -- and before any
+# node of the decoder.  It computes last[b] = the last decode step at which any output gradient of sample b is non-zero (sp_rows_last:
+# device, no host sync; NaN counts as non-zero, a gradient that never arrived as zero) and leaves it on the forward's own token
+# (DecodeRows); the step-tagged backward kernels of THAT decode read it from the token they were built with (DecodeStep).  A consumer
+# that reads every step makes last[b] = T - 1 and the pass dense "because the gradient says so"; two forwards inside one backward
+# carry two tokens; a retained graph recomputes the context at the gate of every backward.  (One semantic difference from multiplying
+# the zeros: a sample whose incoming gradient is exactly zero behind step L but whose ACTIVATIONS there are inf / NaN gets zero instead
+# of NaN gradient contributions from those steps.)
 class RowsCtx:
     __slots__ = ("last", "B")
 
@@ -163,17 +168,69 @@ class RowsCtx:
         self.last, self.B = last, int(last.numel())
 
 
+class DecodeRows:
+    """token of one decode() call: .rc = the RowsCtx of the backward pass in flight through that decode's graph (set by _OutputGate)"""
+    __slots__ = ("rc",)
+
+    def __init__(self):
+        self.rc = None
+
+    def at(self, t: int) -> "DecodeStep":
+        return DecodeStep(t, self)
+
+
+class DecodeStep(int):
+    """decode step (or memory-update) index t that also knows which decode() it belongs to: what the step-tagged ops take as `step=`"""
+    def __new__(cls, t, rows):
+        o = int.__new__(cls, t)
+        o.rows = rows
+        return o
+
+
 def rows_ctx(step, nsamples):
-    """the active row-sparsity context if this op belongs to decode step `step` of a batch of nsamples samples, else None"""
-    rc = _ROWS
-    if rc is None or step is None or rc.B != nsamples or not ROW_SPARSITY:
+    """the row-sparsity context of the backward pass in flight, if this op was tagged with a DecodeStep of a batch of nsamples samples"""
+    tok = getattr(step, "rows", None)
+    if tok is None or not ROW_SPARSITY:
+        return None
+    rc = tok.rc
+    if rc is None or rc.B != nsamples:
         return None
     return rc
 
 
-def _clear_rows():
-    global _ROWS
-    _ROWS = None
+class _OutputGate(Function):
+    """identity over the stacked outputs of decode() ([nstack, B, T, ...] each); its backward derives last[b] from the incoming gradients"""
+    @staticmethod
+    def forward(ctx, tok, *outs):
+        ctx.tok = tok
+        ctx.set_materialize_grads(False)          # an output nobody consumed contributes None, not a zero tensor to scan
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tok = ctx.tok
+        tok.rc = None
+        live = [g for g in grads if g is not None]
+        if ROW_SPARSITY and live:
+            gs = [None if g is None else g.contiguous() for g in grads]
+            nstack, B, T = live[0].shape[:3]
+            for g in gs:
+                if g is not None and (g.dtype != torch.float32 or tuple(g.shape[:3]) != (nstack, B, T)):
+                    return (None,) + tuple(grads)              # (nothing this build produces; stay dense rather than guess)
+            n = len(gs)
+            arr = (C.c_void_p * n)(*[None if g is None else ptr(g) for g in gs])
+            rl = (C.c_int64 * n)(*[0 if g is None else g.numel() // (nstack * B * T) for g in gs])
+            last = torch.empty(B, dtype=torch.int32, device=live[0].device)
+            check(hip.lib().sp_rows_last(arr, rl, n, nstack, B, T, ptr(last), hip.stream()), "sp_rows_last")
+            tok.rc = RowsCtx(last)
+            FUSION_COUNTS["output_gate"] += 1
+            grads = gs
+        return (None,) + tuple(grads)
+
+
+def output_gate(tok: DecodeRows, outs):
+    """outs: list of decode() output stacks -> the same tensors behind the gate node (see the block comment above)"""
+    return list(_OutputGate.apply(tok, *outs))
 
 
 def reset_fusion_counts():
@@ -604,8 +661,8 @@ class _FanOut(Function):
         rc0 = rows_ctx(ctx.step, gs[0].shape[0]) if gs[0].dim() > 1 else None
         marks = [getattr(grads[i], "_sp_rows", None) for i in idx]
         if rc0 is None and any(m is not None for m in marks):
-            cand = next(m[0] for m in marks if m is not None)
-            if cand is _ROWS and gs[0].dim() > 1 and cand.B == gs[0].shape[0]:
+            cand = next(m[0] for m in marks if m is not None)      # (a mark is made by a backward node of THIS pass from its own token)
+            if gs[0].dim() > 1 and cand.B == gs[0].shape[0] and ROW_SPARSITY:
                 rc0 = cand
         steps = None
         if rc0 is not None and n % rc0.B == 0 and (n // rc0.B) % 4 == 0:
@@ -845,7 +902,8 @@ def _flush_deferred(defer, wp, geom):
     xs0, dys0, _ = items[0]
     same = all(x.kind == xs0.kind and y.kind == dys0.kind for x, y, _ in items)
     steps = [st for _, _, st in items]
-    rc = _ROWS if (all(st is not None for st in steps) and _ROWS is not None and _ROWS.B == geom["N_img"] and ROW_SPARSITY) else None
+    toks = [getattr(st, "rows", None) for st in steps]
+    rc = rows_ctx(steps[0], geom["N_img"]) if (toks and toks[0] is not None and all(tk is toks[0] for tk in toks)) else None
     d = WgradDesc(geom["N_img"], geom["Hi"], geom["Wi"], Ci, Ci, geom["Ho"], geom["Wo"], Co, geom.get("ldy", Co), KH, KW, geom["stride"],
                   geom["pad"], geom["dil"], KH * KW * Ci, 0, 1.0, 1, 0, 0, 0)
     d.x_scale_vec, d.y_scale_vec = int(xs0.kind == "cols"), int(dys0.kind == "cols")
@@ -2052,14 +2110,7 @@ def device_sum(x: torch.Tensor) -> torch.Tensor:
 
 class _ScanpathLoss(Function):
     @staticmethod
-    def forward(ctx, z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums, skip_rows=False):
-        ctx.last = None
-        if skip_rows and ROW_SPARSITY:
-            # last[b] = the last decode step at which sample b has a loss term (device, no host sync); -1: none.  Published to the
-            # backward kernels of the decoder for the duration of this loss's backward pass (rows_ctx)
-            Tn = amask.shape[1]
-            act = ((amask > 0) | (dmask > 0)).to(torch.int32)
-            ctx.last = ((act * torch.arange(1, Tn + 1, dtype=torch.int32, device=amask.device)).amax(1) - 1).to(torch.int32).contiguous()
+    def forward(ctx, z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums):
         z, mu, sigma2 = z.contiguous(), mu.contiguous(), sigma2.contiguous()
         gt, amask, dur, dmask = gt.contiguous(), amask.contiguous(), dur.contiguous(), dmask.contiguous()
         B, T, A = z.shape
@@ -2080,10 +2131,6 @@ class _ScanpathLoss(Function):
 
     @staticmethod
     def backward(ctx, g, _ga, _gd):
-        if ctx.last is not None:
-            global _ROWS
-            _ROWS = RowsCtx(ctx.last)
-            torch.autograd.Variable._execution_engine.queue_callback(_clear_rows)      # dropped when this backward pass ends
         dz, dmu, ds2 = ctx.saved_tensors
         g = g.reshape(1).contiguous().to(torch.float32)
         L = hip.lib()
@@ -2092,14 +2139,13 @@ class _ScanpathLoss(Function):
             o = torch.empty_like(t)
             check(L.sp_scale_by(ptr(t), ptr(g), t.numel(), ptr(o), hip.stream()), "sp_scale_by")
             outs.append(o)
-        return outs[0], outs[1], outs[2], None, None, None, None, None, None, None
+        return outs[0], outs[1], outs[2], None, None, None, None, None, None
 
 
-def scanpath_loss(z, mu, sigma2, gt, amask, dur, dmask, lambda1=1.0, mask_sums=None, skip_masked_backward=False):
+def scanpath_loss(z, mu, sigma2, gt, amask, dur, dmask, lambda1=1.0, mask_sums=None):
     """loss, loss_actions, loss_duration (AiR/train.py:192-197).  mask_sums: device tensor
     [sum(action_masks), sum(duration_masks)]; computed locally when None (single-process semantics).
-    skip_masked_backward: the caller guarantees that this loss is the ONLY consumer of the model's outputs; the backward pass then
-    skips the (sample, step) pairs behind every sample's last masked-in step, whose gradients are exactly zero (see rows_ctx)."""
+    (The gradient rows of masked-out steps are exact zeros; the decoder's backward pass skips what they imply by itself, see _OutputGate.)"""
     if mask_sums is None:
         mask_sums = torch.cat([device_sum(amask), device_sum(dmask)])
-    return _ScanpathLoss.apply(z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums, bool(skip_masked_backward))
+    return _ScanpathLoss.apply(z, mu, sigma2, gt, amask, dur, dmask, lambda1, mask_sums)

@@ -51,6 +51,7 @@ class WgradDesc(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+ABI_VERSION = 2      # = SP_ABI_VERSION of include/scanpaths_amd.h (held equal by tests/test_cpu_host.py)
 
 # name -> (restype, argtypes); must list every symbol include/scanpaths_amd.h declares
 SIGNATURES = {
@@ -159,6 +160,7 @@ SIGNATURES = {
     "sp_log_action": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "sp_log_duration": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "sp_rowscale": (_I, [_P, _P, _I, _I, _P, _P]),
+    "sp_rows_last": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "sp_scale_by": (_I, [_P, _P, _L, _P, _P]),
     "sp_sumsq_workspace": (_L, [_L]),
     "sp_sum": (_I, [_P, _L, _P, _P, _P]),
@@ -182,8 +184,10 @@ def lib() -> C.CDLL:
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
-        if _lib.sp_abi_version() != 1:
-            raise RuntimeError("libscanpaths_amd.so ABI version mismatch")
+        if _lib.sp_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {_lib.sp_abi_version()}, this binding expects {ABI_VERSION} (SP_ABI_VERSION in "
+                               "include/scanpaths_amd.h; bumped whenever a descriptor layout or an entry point's meaning changes): rebuild "
+                               "with `make -C scanpaths_amd/csrc`")
         # every max|.| slot this host passes comes zeroed from functional._amax_hint's pool and is used once: the launchers add
         # their reset node only while a stream is being captured (graph replays re-use the slot)
         if not _config.settings["always_reset_amax"]:

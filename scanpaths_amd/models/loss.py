@@ -11,16 +11,13 @@ from .. import functional as F
 epsilon = 1e-7
 
 
-def supervised_loss(predicts, scanpaths, durations, action_masks, duration_masks, lambda_1=1.0, mask_sums=None,
-                    skip_masked_backward=False):
-    """loss = L_actions + lambda_1 * L_duration of the supervised phase (AiR/train.py:192-197) -> (loss, L_actions, L_duration).
-    skip_masked_backward=True: the caller guarantees that this loss is the ONLY consumer of `predicts`; the decoder's backward pass then
-    skips, per sample, the decode steps behind its last masked-in step -- their gradients are exactly zero (the loss multiplies by the
-    masks), the reference computes them densely; results are identical (functional.rows_ctx).  Leave it off when anything else reads the
-    predictions inside the same backward pass (an auxiliary loss, a regulariser on the logits)."""
+def supervised_loss(predicts, scanpaths, durations, action_masks, duration_masks, lambda_1=1.0, mask_sums=None):
+    """loss = L_actions + lambda_1 * L_duration of the supervised phase (AiR/train.py:192-197) -> (loss, L_actions, L_duration); ONE launch
+    for value and gradient.  Like the two separate calls below it sends exact zeros into the predictions of masked-out steps; the decoder's
+    backward pass finds those in the gradient it receives and skips what they imply (functional._OutputGate) -- nothing to switch on."""
     z = predicts["actions"] if "actions" in predicts else predicts["all_actions_prob"]
     return F.scanpath_loss(z, predicts["log_normal_mu"], predicts["log_normal_sigma2"], scanpaths, action_masks, durations,
-                           duration_masks, lambda_1, mask_sums, skip_masked_backward)
+                           duration_masks, lambda_1, mask_sums)
 
 
 def CrossEntropyLoss(input, gt, mask):

@@ -179,6 +179,7 @@ class ScanpathModel(nn.Module):
             self.int2object = {i: n for i, n in enumerate(self.object_name)}
             self.object_sal_layer = nn.ModuleDict({k: _Conv(512, 512, 5) for k in self.object_name})
         self.object_head = _Head(Hm, Wm)
+        self.last_decode_rows = None          # functional.DecodeRows of the latest decode() with autograd on (see decode)
         self.init_weights()
 
     # ---- init: resnet.py:112-118 (He normal, BN 1/0); mmcv xavier_init (normal) for convs, normal_init(std=0.01) for
@@ -312,6 +313,7 @@ class ScanpathModel(nn.Module):
         logits [nh,B,T,A], mu [nh,B,T], sigma2 [nh,B,T], amap [nh,B,T,P]."""
         T = self.convLSTM_length
         S = len(self.streams)
+        grad_on_outer = torch.is_grad_enabled()
         vf = F.conv2d(enc, self.sal_conv.weight, self.sal_conv.bias, pad=1, relu=True)       # :270
         B, Hm, Wm, Cc = vf.shape
         assert (Hm, Wm) == (self.map_height, self.map_width), \
@@ -364,6 +366,11 @@ class ScanpathModel(nn.Module):
         Wsal = torch.cat([Gp[:, :2].reshape(nsrc * 50, 512), torch.zeros(R - nsrc * 50, 512, device=dev)], 0).view(R, 512, 1, 1)
         W11, cbsum = F.compose11(G, cbt if per_sample else cb, nsrc, HC, (Hm, Wm))
         w2, b2 = self.object_head.drt_layer_2.weight, self.object_head.drt_layer_2.bias
+        # masked-step sparsity of the backward pass: every step-tagged op below carries this decode's token; the gate at the end of
+        # this function fills it from the gradient that reaches the outputs (functional._OutputGate) -- no caller promise involved
+        rows = F.DecodeRows() if grad_on_outer else None
+        self.last_decode_rows = rows          # (diagnostics / tests: after backward, .rc.last = the horizon the gate derived per sample)
+        at = (lambda t: rows.at(t)) if rows is not None else (lambda t: t)
         sp_list: List[List[torch.Tensor]] = []      # per memory entry: its remaining aliases (see push)
         se_list: List[List[torch.Tensor]] = []
 
@@ -392,7 +399,7 @@ class ScanpathModel(nn.Module):
             spf = F.mul_relu(amaps, mvfs.pop())
             sp_list.append(rep(F.linear(spf.view(S * B, P), spw.pop(), spb.pop(), defer=sp_defer), T - k))
             vf4 = vfs.pop()           # (4-D as it is: the gradient it returns carries the memory update's row-sparsity mark to vf's fan-in)
-            pooled = F.semantic_pool(amaps, vf4, step=k) if (S <= 2 and Cc <= 512) else \
+            pooled = F.semantic_pool(amaps, vf4, step=at(k)) if (S <= 2 and Cc <= 512) else \
                 F.gemm(amaps.transpose(0, 1).contiguous(), vf4.view(B, P, Cc), None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
             se_list.append(rep(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop(), defer=se_defer), T - k))
             sp_mem = F.list_attention(torch.stack([a.pop() for a in sp_list], 0), u_spas.pop())        # [S*B,P]
@@ -408,7 +415,8 @@ class ScanpathModel(nn.Module):
         if torch.is_grad_enabled() and Wh.requires_grad:
             wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight-gradient GEMMs run on a side stream, summed in place
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
-        for t in range(T):
+        for t_ in range(T):
+            t = at(t_)          # (an int that also names this decode: the backward kernels of step t find the row context through it)
             se = se_mem.view(S, B, Cc).unbind(0)      # (unbind: ONE stack in backward instead of a zero-fill + copy per stream and an add)
             parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk", defer=wr_defer[s]).view(B, 3 * 512, 9) for s in range(S)]
             wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
@@ -433,7 +441,11 @@ class ScanpathModel(nn.Module):
             outs["s2"].append(s2)
             if t + 1 < T:
                 sp_mem, se_mem = push(amap, t + 1)
-        return {k: torch.stack(v, 2) for k, v in outs.items()}
+        stacks = {k: torch.stack(v, 2) for k, v in outs.items()}
+        if rows is not None and any(v.requires_grad for v in stacks.values()):
+            keys = list(stacks)
+            stacks = dict(zip(keys, F.output_gate(rows, [stacks[k] for k in keys])))
+        return stacks
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, images, attention_maps=None, third=None):

@@ -30,7 +30,9 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/scanpaths_amd.h but not exported"
     assert sorted(hip.SIGNATURES) == syms, set(hip.SIGNATURES) ^ set(syms)
-    assert lib.sp_abi_version() == 1          # pure host call, no GPU needed
+    # pure host call, no GPU needed: the library, the header and the ctypes binding carry the same ABI version
+    hdr = int(re.search(r"#define SP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "scanpaths_amd.h")).read()).group(1))
+    assert lib.sp_abi_version() == hdr == hip.ABI_VERSION
 
 
 def test_ctypes_signatures_match_the_header():
@@ -353,3 +355,42 @@ def test_split_counts_of_the_weight_gradient_kernels_follow_the_round_quantisati
     # fp32 wgrad_kernel: two workgroups per CU
     fp = L.sp_conv_wgrad_workspace
     assert splits(fp, desc(32, 80, 128, 64, 64, 1)) == 512         # one tile: 512 workgroups (was 128)
+
+
+def test_post_accumulate_hook_fires_for_an_undefined_gradient():
+    """functional._take_grad_view writes a leaf parameter's gradient straight into FlatAdam's flat buffer and hands autograd
+    None; the gradient-ready bookkeeping (bucketed all-reduce launch order, ddp.py) relies on the parameter's AccumulateGrad node still
+    running and firing the post-accumulate hook with that undefined gradient.  This is observed torch behaviour (2.10), not a documented
+    contract: pinned here so that a torch upgrade that drops it is noticed (FlatAdam.step() then still reports the parameters whose hook
+    never fired -- correct results, no overlap)."""
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, None          # "the gradient of w was written elsewhere"
+
+    w = torch.nn.Parameter(torch.ones(3))
+    x = torch.ones(3, requires_grad=True)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(p.grad))
+    Fn.apply(x, w).sum().backward()
+    assert fired == [None] and w.grad is None
+
+
+def test_direct_gradient_writes_step_aside_for_user_tensor_hooks():
+    """a parameter with a tensor hook (p.register_hook: scaling, clipping, logging) must receive its gradient through autograd so
+    that the hook sees it -- functional._grad_slot declines the in-place write for it."""
+    from scanpaths_amd import functional as F
+
+    class Slot:
+        pass
+    p = torch.nn.Parameter(torch.ones(4))
+    p._sp_flat = Slot()
+    assert F._grad_slot(p) is not None
+    h = p.register_hook(lambda g: g * 2)
+    assert F._grad_slot(p) is None
+    h.remove()
+    assert F._grad_slot(p) is not None
