@@ -123,17 +123,12 @@ __device__ __forceinline__ void block_amax_commit(float m, unsigned* amax, float
 // over all x, below half an ulp of the result's range; with the rcp ~2 ulp in total.  tanh(x) = 1 - 2 * rcp(1 + exp2(2x log2 e)):
 // absolute error ~1e-7 (one ulp of 1.0; relative accuracy is lost for |x| << 1, where the cell only needs g = tanh(pre) to an
 // absolute 1e-7 next to c of order 1).  Saturates correctly: exp2 -> inf gives rcp 0.
-#ifdef SP_LIBM_GATES      // A/B only (make timing TIMING_EXTRA=-DSP_LIBM_GATES): round 3's libm forms and LDS pitches of the fused cell epilogue
-__device__ __forceinline__ float sp_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float sp_tanh(float x) { return tanhf(x); }
-#else
 __device__ __forceinline__ float sp_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float sp_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
-#endif
 
 // ---- 2xfp16 operand split (conv_f16x2.hip; shared with the producers that emit split operands directly) ----
 // power-of-two scale with amax * s in [8192, 16384)

@@ -15,9 +15,6 @@
 // 32 k = 128 bytes per row.  A 64-byte zero block follows the data (masked loader lanes); the scale lives in a device float.
 #include "common.h"
 #include <algorithm>
-#ifndef SP_XG_PRE
-#define SP_XG_PRE 0      // float4s of the x-gate tile requested ahead of the rank-1 phase of the fused cell epilogue: 8 measured neutral (see there)
-#endif
 #include <cstdlib>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -74,6 +71,7 @@ struct H2Args {
     float* l_hscale;        // [2] {scale, bound}
     float l_hbound;
     int lC, lP, lKP;
+    int l_probe;            // timing build only (sp_set_tuning("h2_dbg", n) on the fused-cell launch): see the LSTM epilogue
     // BatchNorm batch statistics of the output, fused into the epilogue (forward, 16x16x32 build): per M-tile and output column
     // the sum and the sum of squares (fp64) and min / max (fp32) of the tile's valid rows, in the [G = M-tiles][2][Nout] layout
     // of bn_pool.hip's first reduction stage -- the BatchNorm behind this conv starts at its second stage
@@ -136,11 +134,25 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     static_assert(!LSTM || MODE == 0, "the LSTM epilogue belongs to the forward build");
     static_assert(!HALO || (CBM && NPROD == 3 && DBG == 0), "the halo build extends the channel-block-major schedule only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool LSTM_T = LSTM;      // the fused-cell build multiplies with the weights as the row operand (transposed tile), see mma_group
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
+#ifdef SP_TIMING_VARIANTS
+    // probe (wrong results unless only the stagger bits are set): bit 0 = no epilogue loads, bit 1 = no epilogue stores, bit 2 = no epilogue
+    // at all; bits 8.. = first-round stagger: G = (probe >> 8) & 15 groups of CUs start (group index) x 2 us x ((probe >> 12) & 31) late
+    const int probe = LSTM ? p.l_probe : 0;
+    if (LSTM && (probe >> 8) && blockIdx.x < 256) {
+        const int G = (probe >> 8) & 15, step_us = 2 * ((probe >> 12) & 31);
+        const long long wait = (long long)((blockIdx.x >> 3) % G) * step_us * 100;      // s_memrealtime: 100 MHz
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#else
+    constexpr int probe = 0;
+#endif
     // the two operand scales (device words written by the split kernels): requested FIRST, used by the epilogue -- behind the K loop
     // their latency would be exposed once per workgroup
     const float sx_dev = p.sx[0], sw_dev = p.sw_rows ? 1.f : p.sw[0];
@@ -195,14 +207,6 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                 }
                 return;
             }
-        }
-    }
-    float lstm_sw[4] = {1.f, 1.f, 1.f, 1.f};           // LSTM build: the lane's four per-row weight scales (gate q, its channel), see the epilogue
-    if constexpr (LSTM) {
-        const int chl = n0 + (wave & 1) * 16 + (lane & 15);
-        if (p.sw_rows && chl < p.lC) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lstm_sw[q] = p.sw[q * p.lC + chl];
         }
     }
     const int HoWo = p.Ho * p.Wo;
@@ -501,6 +505,16 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4& a4 = acc4[2 * kk + i][j];
+                    if constexpr (LSTM_T) {
+                        // transposed tile (weights as the row operand): the lane then holds 4 CONSECUTIVE CHANNELS of one pixel -- see
+                        // the cell epilogue; same fragments, same products, same sum order
+                        if constexpr (NPROD == 3) {
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j >> 1][j & 1][1], af[kk][i][0], a4, 0, 0, 0);
+                            a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j >> 1][j & 1][0], af[kk][i][1], a4, 0, 0, 0);
+                        }
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j >> 1][j & 1][0], af[kk][i][0], a4, 0, 0, 0);
+                        continue;
+                    }
                     if constexpr (NPROD == 3) {
                         a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][0], bf[j >> 1][j & 1][1], a4, 0, 0, 0);
                         a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i][1], bf[j >> 1][j & 1][0], a4, 0, 0, 0);
@@ -641,156 +655,160 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     if constexpr (!CBM) {
         if (p.w_bstride) swrow0 = (m0 / p.rows_per_batch) * (int64_t)p.Nout;
     }
-    if constexpr (LSTM) {
-        // every LDS read of the K loop was waited for before its last barrier (the late waves multiply from registers): the ring is free
+    if constexpr (LSTM_T) {
+        // ---- the ConvLSTM cell as the epilogue (AiR/models/baseline_attention.py:37-56), round 5 form: NO LDS, NO barrier ------------
+        // The K loop multiplied with the weights as the ROW operand, so in acc4[i][q] the lane holds, for pixel  m0 + wm*64 + i*16 + l16,
+        // gate q of the four consecutive channels  chb .. chb + 3,  chb = n0 + wn*16 + 4*g4: everything the cell reads and writes per
+        // (pixel, gate) is ONE 16-byte access per lane (x-gates in, activated gates / c / h out: 64-byte runs per pixel, the partner
+        // wave wn ^ 1 covers the other half of the 128-byte line) -- round 4 staged 128 KB in and 192 KB out per tile through the LDS
+        // ring behind five workgroup barriers (64 ds_read_b32 + 64 ds_write_b32 + 36 b128 per lane), with the matrix pipe idle.  The
+        // rank-1 gate term  sum_k spcol[pixel][k] * wc[gate][channel][k]  (k < KP <= 32) runs on the otherwise idle matrix pipe as
+        // v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chains in k order, like the VALU loop it replaces: 60 MFMAs instead of 960 v_fma per lane
+        // at KP = 20), its operands read straight from global memory (28 KB per tile, L2-resident) in the MFMA's own lane layout.
+        // Waves leave the K loop at different times (the late half one K-tile behind) and run their epilogues independently.
+        // Shapes: P % 256 == 0 and C % 32 == 0 (launcher) => every pixel row and channel of the tile exists.
+        if (probe & 4) return;
+        const bool nt_st = probe & 8, nt_ld = probe & 16;               // (A/B: streaming stores / loads)
+        auto st4 = [&](float* dst, const float4& v) {
+            const f32x4 x = {v.x, v.y, v.z, v.w};
+            if (nt_st) __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(dst));
+            else *reinterpret_cast<f32x4*>(dst) = x;
+        };
+        auto ld4 = [&](const float* src) {
+            const f32x4 x = nt_ld ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src)) : *reinterpret_cast<const f32x4*>(src);
+            return make_float4(x[0], x[1], x[2], x[3]);
+        };
         const int KP = p.lKP, C = p.lC;
-        const int WST = KP + 1;                                   // odd-ish stride: the 16 channel lanes hit distinct banks
-        float* sp_s = reinterpret_cast<float*>(smem);             // [256][KP]
-        float* wc_s = sp_s + HBM * KP;                            // [3][32][WST]
         const int b = (int)(m0 / p.lP);
-        const int cl = wn * 16 + l16, ch = n0 + cl;
-#ifdef SP_LIBM_GATES
-        constexpr int XG_PITCH = 128, HC_PITCH = 32;
-#else
-        constexpr int XG_PITCH = 132, HC_PITCH = 36;
-#endif
-        // The epilogue's global reads are requested FIRST -- the x-gate tile (16 float4 per lane) and the lane's 16 previous cell values;
-        // the per-row weight scales were fetched before the K loop -- so that their latency runs under the staging of the rank-1 operands and the rank-1 loop
-        // below instead of being exposed behind them (three dependent global round trips per tile before: ~2-3 us each of the tile's
-        // ~25 us epilogue, with the matrix pipe of this CU idle).
+        const int chb = n0 + wn * 16 + 4 * g4;
+        const int64_t mrow = m0 + wm * 64 + l16;                       // + 16 i
+        const int nk4 = (KP + 3) >> 2;                                 // k-steps of the rank-1 term (scalar)
+        // rank-1 operands in the 16x16x4 layout: A[row = channel l16 of the wave's 16][k = g4], B[col = pixel l16][k = g4]
+        const float* wc_l = p.l_wc + ((int64_t)b * 3 * C + n0 + wn * 16 + l16) * KP + g4;      // + q * C * KP + 4 kk
+        const float* sp_l = p.l_spcol + mrow * KP + g4;                                        // + 16 i * KP + 4 kk
+        float wa[3][4], sb[4][4];
+        auto load_rank1 = [&](int kk0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int kk = 0; kk < 4; ++kk) {
+                const bool ok = 4 * (kk0 + kk) + g4 < KP;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                          // weight row of (gate q, channel ch) = q * C + ch: its own scale
-                const float iswq = (p.sw_rows && ch < C) ? 1.f / lstm_sw[q] : isw;
+                for (int q = 0; q < 3; ++q) wa[q][kk] = ok ? wc_l[(int64_t)q * C * KP + 4 * (kk0 + kk)] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tot4[i][q][r] = ((tot4[i][q][r] + acc4[i][q][r]) * isx) * iswq;
-            }
-        __builtin_amdgcn_sched_barrier(0);                 // the loads below must not move up into the K loop's register budget
-        float4 v[16];
-        auto load_xg = [&](int k0, int k1) {
-#pragma unroll
-            for (int k = k0; k < k1; ++k) {
-                const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
-                const int64_t m = m0 + row;
-                v[k] = (m < p.M && n0 + c4 * 4 < C) ? *reinterpret_cast<const float4*>(p.l_xg + m * 4 * C + q * C + n0 + c4 * 4)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < 4; ++i) sb[i][kk] = ok ? sp_l[(int64_t)16 * i * KP + 4 * (kk0 + kk)] : 0.f;
             }
         };
-        // same-box A/B (make timing TIMING_EXTRA=-DSP_XG_PRE=8 against 0, three interleaved rounds): 311.3 vs 311.1 ms per step, fused launch
-        // 3.84 vs 3.83 ms -- neutral, and 8 costs 23 VGPRs (254 of 256; 12 spill): the default requests the tile after the rank-1 phase
-        constexpr int XG_PRE = SP_XG_PRE;
-        load_xg(0, XG_PRE);
-        float cpv[4][4];
+        auto mma_rank1 = [&](int kk0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (kk0 + kk < nk4) {                                  // (scalar)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            tot4[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[q][kk], sb[i][kk], tot4[i][q], 0, 0, 0);
+                }
+        };
+        float4 xv[4][4];                                               // x-gate pre-activations [i][gate]
+        auto load_xg = [&](int i0, int i1) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xv[i][q] = (probe & 1) ? make_float4(0.1f * q, 0.2f, 0.3f, 0.1f * i)
+                                           : ld4(p.l_xg + (mrow + 16 * i) * 4 * C + q * C + chb);
+        };
+        // the activation scale is undone first: the chunk accumulators die here and the epilogue's loads get their registers
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm * 64 + i * 16 + 4 * g4 + r;
-                cpv[i][r] = (p.l_cprev && ch < C && m < p.M) ? p.l_cprev[m * C + ch] : 0.f;
-            }
-        for (int i = t; i < HBM * KP; i += 512) sp_s[i] = (m0 + i / KP) < p.M ? p.l_spcol[m0 * KP + i] : 0.f;
-        for (int i = t; i < 96 * KP; i += 512) {
-            const int k = i % KP, qj = i / KP;                    // qj = gate * 32 + channel
-            const int chq = n0 + (qj & 31);
-            wc_s[qj * WST + k] = chq < C ? p.l_wc[((int64_t)b * 3 * C + (qj >> 5) * C + chq) * KP + k] : 0.f;
-        }
-        __syncthreads();
-        for (int k = 0; k < KP; ++k) {
-            const float w0 = wc_s[cl * WST + k], w1 = wc_s[(32 + cl) * WST + k], w2 = wc_s[(64 + cl) * WST + k];
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tot4[i][q][r] = (tot4[i][q][r] + acc4[i][q][r]) * isx;
+        __builtin_amdgcn_sched_barrier(0);
+        // every global read of the epilogue is requested now: weight-row scales, the first rank-1 operands, the x-gate tile, c_prev
+        float4 swv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            swv[q] = p.sw_rows ? *reinterpret_cast<const float4*>(p.sw + q * C + chb) : make_float4(sw_dev, sw_dev, sw_dev, sw_dev);
+        load_rank1(0);
+        float4 cpv[4];
+        auto load_cp = [&](int i0, int i1) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+                cpv[i] = (p.l_cprev && !(probe & 1)) ? ld4(p.l_cprev + (mrow + 16 * i) * C + chb)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        load_xg(0, 2);
+        load_cp(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // then the weight scale (the two power-of-two scales one after the other: their product can leave the fp32 range); per-row
+        // weight scales: row (gate q, channel) = q * C + channel
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float is[4] = {1.f / swv[q].x, 1.f / swv[q].y, 1.f / swv[q].z, 1.f / swv[q].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sv = sp_s[(wm * 64 + i * 16 + 4 * g4 + r) * KP + k];
-                    tot4[i][0][r] += sv * w0;
-                    tot4[i][1][r] += sv * w1;
-                    tot4[i][2][r] += sv * w2;
-                }
+                for (int r = 0; r < 4; ++r) tot4[i][q][r] *= is[r];
         }
-        // The x-gate tile comes in and the activated gates leave through the LDS ring as float4 per lane: per (row, gate) the 32
-        // channels of the workgroup are 128 contiguous bytes; read / written 4 bytes per lane straight from the MFMA layout they were
-        // 64-byte runs, and this epilogue (1.85 GB per launch) ran 0.47 ms with the matrix pipe idle.  xs [256 rows][4 gates][32 ch],
-        // row pitch XG_PITCH = 132 floats: the four row groups of a lane group (rows 4 apart) land 16 banks apart -- with the natural
-        // pitch of 128 floats they shared their banks (4-way conflicts on 12 accesses per element: 13.4 M SQ_LDS_BANK_CONFLICT cycles per
-        // launch in round 3's counters); the float4 side stays 16-byte aligned (528-byte rows).
-        load_xg(XG_PRE, 16);
-        __syncthreads();                                   // sp_s / wc_s are dead
-        float* xs = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = t + 512 * k;
-            *reinterpret_cast<float4*>(xs + (e >> 5) * XG_PITCH + (e & 31) * 4) = v[k];
+        mma_rank1(0);
+        if (nk4 > 4) {
+            load_rank1(4);
+            mma_rank1(4);
         }
-        __syncthreads();
-        float hmx = 0.f;
-        float hv[4][4], cv[4][4];                          // the lane's new hidden / cell values (stored below through the ring)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + i * 16 + 4 * g4 + r;
-                const int64_t m = m0 + row;
-                hv[i][r] = 0.f;
-                cv[i][r] = 0.f;
-                if (ch >= C || m >= p.M) continue;
-                float* px = xs + row * XG_PITCH + cl;
-                const float gi = h2_sigmoid(tot4[i][0][r] + px[0]);
-                const float gf = h2_sigmoid(tot4[i][1][r] + px[32]);
-                const float go = h2_sigmoid(tot4[i][2][r] + px[64]);
-                const float gg = sp_tanh(tot4[i][3][r] + px[96]);
-                const float cn = gf * cpv[i][r] + gi * gg;
-                const float hn = go * cn;
-                px[0] = gi;
-                px[32] = gf;
-                px[64] = go;
-                px[96] = gg;
-                cv[i][r] = cn;
-                hv[i][r] = hn;
-                hmx = fmaxf(hmx, fabsf(hn));
-            }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = t + 512 * k, row = e >> 5, q = (e >> 3) & 3, c4 = e & 7;
-            const int64_t m = m0 + row;
-            if (m < p.M && n0 + c4 * 4 < C)
-                *reinterpret_cast<float4*>(p.l_gates + m * 4 * C + q * C + n0 + c4 * 4) =
-                    *reinterpret_cast<const float4*>(xs + row * XG_PITCH + (e & 31) * 4);
-        }
-        // h and c leave the same way ([256 rows][32 channels] each: 128-byte runs, row pitch HC_PITCH = 36 floats for the same reason),
-        // and h also as the split operand of its consumers (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <=
-        // t + 1, so the operand scale needs no max|h| pass
-        __syncthreads();
-        float* hs = xs;
-        float* cs2 = xs + HBM * HC_PITCH;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + i * 16 + 4 * g4 + r;
-                hs[row * HC_PITCH + cl] = hv[i][r];
-                cs2[row * HC_PITCH + cl] = cv[i][r];
-            }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        load_xg(2, 4);                                     // second half of the tile: in flight under the gates of the first
+        load_cp(2, 4);
+        __builtin_amdgcn_sched_barrier(0);
         const float hsc = p.l_hplanes ? scale_of(__float_as_uint(p.l_hbound)) : 1.f;
+        float hmx = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // (wave-uniform: store_planes_quad)
-            const int e = t + 512 * k, row = e >> 3, c4 = e & 7;
-            const int64_t m = m0 + row;
-            const bool live = m < p.M && n0 + c4 * 4 < C;
-            const float4 h4 = *reinterpret_cast<const float4*>(hs + row * HC_PITCH + c4 * 4);
-            if (live) {
-                *reinterpret_cast<float4*>(p.l_h + m * C + n0 + c4 * 4) = h4;
-                *reinterpret_cast<float4*>(p.l_c + m * C + n0 + c4 * 4) = *reinterpret_cast<const float4*>(cs2 + row * HC_PITCH + c4 * 4);
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = mrow + 16 * i;
+            float4 gi, gf, go, gg, cn, hn;
+#define SP_CELL(e)                                                     \
+            gi.e = h2_sigmoid(tot4[i][0][ri] + xv[i][0].e);            \
+            gf.e = h2_sigmoid(tot4[i][1][ri] + xv[i][1].e);            \
+            go.e = h2_sigmoid(tot4[i][2][ri] + xv[i][2].e);            \
+            gg.e = sp_tanh(tot4[i][3][ri] + xv[i][3].e);               \
+            cn.e = gf.e * cpv[i].e + gi.e * gg.e;                      \
+            hn.e = go.e * cn.e;                                        \
+            hmx = fmaxf(hmx, fabsf(hn.e));
+            { constexpr int ri = 0; SP_CELL(x) }
+            { constexpr int ri = 1; SP_CELL(y) }
+            { constexpr int ri = 2; SP_CELL(z) }
+            { constexpr int ri = 3; SP_CELL(w) }
+#undef SP_CELL
+            if (probe & 2) {                                   // (timing probe: keep the values alive, store nothing)
+                asm volatile("" ::"v"(gi.x), "v"(gi.y), "v"(gi.z), "v"(gi.w), "v"(gf.x), "v"(gf.y), "v"(gf.z), "v"(gf.w));
+                asm volatile("" ::"v"(go.x), "v"(go.y), "v"(go.z), "v"(go.w), "v"(gg.x), "v"(gg.y), "v"(gg.z), "v"(gg.w));
+                asm volatile("" ::"v"(cn.x), "v"(cn.y), "v"(cn.z), "v"(cn.w), "v"(hn.x), "v"(hn.y), "v"(hn.z), "v"(hn.w));
+                continue;
             }
+            const int64_t ms = (probe & 64) ? (m & 1023) : m;        // (timing probe: every tile stores into the same 1024 rows)
+            float* gp = p.l_gates + ms * 4 * C + chb;
+            st4(gp, gi);
+            st4(gp + C, gf);
+            if (!(probe & 32)) {                               // (timing probe: half of the gate bytes)
+                st4(gp + 2 * C, go);
+                st4(gp + 3 * C, gg);
+            } else {
+                asm volatile("" ::"v"(go.x), "v"(go.y), "v"(go.z), "v"(go.w), "v"(gg.x), "v"(gg.y), "v"(gg.z), "v"(gg.w));
+            }
+            st4(p.l_c + ms * C + chb, cn);
+            st4(p.l_h + ms * C + chb, hn);
             if (p.l_hplanes) {
+                // h also as the split operand of its consumers (next step's h-gate conv, the saliency tap GEMM): |h| = |o * c| <= |c| <=
+                // t + 1, so the operand scale needs no max|h| pass.  Layout [16-channel group][plane][16]: the lane's four channels are
+                // 8 bytes of each plane (the four g4 lanes of a pixel complete the group's two 32-byte plane rows)
                 ushort4 pa, pb;
-                split2(h4.x, hsc, pa.x, pb.x);
-                split2(h4.y, hsc, pa.y, pb.y);
-                split2(h4.z, hsc, pa.z, pb.z);
-                split2(h4.w, hsc, pa.w, pb.w);
-                store_planes_quad(p.l_hplanes, (m * C + n0) / 4 + c4, live, pa, pb);
+                split2(hn.x, hsc, pa.x, pb.x);
+                split2(hn.y, hsc, pa.y, pb.y);
+                split2(hn.z, hsc, pa.z, pb.z);
+                split2(hn.w, hsc, pa.w, pb.w);
+                uint16_t* grp = p.l_hplanes + ((ms * C + chb) >> 4) * 32 + (chb & 15);
+                *reinterpret_cast<ushort4*>(grp) = pa;
+                *reinterpret_cast<ushort4*>(grp + 16) = pb;
             }
         }
         if (p.l_hplanes && blockIdx.x == 0) {
@@ -2132,6 +2150,7 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     a.l_gates = gates; a.l_c = c_out; a.l_h = h_out; a.l_hamax = h_amax;
     a.l_hplanes = (uint16_t*)hout_planes; a.l_hscale = hout_scale; a.l_hbound = hout_bound;
     a.lC = d->Kc; a.lP = P; a.lKP = KP;
+    a.l_probe = sp_tuning_get(SP_TUNE_H2_DBG, 0);      // (product build: always 0)
     hipStream_t st = (hipStream_t)stream;
     SP_RESET_AMAX(h_amax, st);
     if (halo_applies(d) && sp_tuning_get(SP_TUNE_H2_HALO, 1) == 1) return launch_h2<0, 3, true, true, true>(a, st);
