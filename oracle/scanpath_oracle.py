@@ -136,17 +136,23 @@ def spatial_att(sd, lists, cur):
     return (lists * F.softmax(s, 1)).sum(1)
 
 
-def predict_head(sd, feat, training):
+def predict_head(sd, feat, training, tap=None, tag=None):
     """predict_head.forward, baseline_attention.py:149-174.  drt_layer_2's kernel spans the whole
-    drt_layer_1 output ((6,8) at 30x40, :145); AvgPool over the whole map (:142)."""
+    drt_layer_1 output ((6,8) at 30x40, :145); AvgPool over the whole map (:142).
+    tap / tag (tests only): the pre-activations of the two ReLUs are recorded under tap["sal3_pre"][tag] / tap["drt1_pre"][tag]."""
     n = feat.shape[0]
     y = _conv(sd, "object_head.sal_layer_2", feat).squeeze(1)
     y = y.mean(dim=(1, 2), keepdim=False).view(n, 1, 1)
-    t = F.relu(_conv(sd, "object_head.drt_layer_1", feat, stride=5, padding=2))
+    t_pre = _conv(sd, "object_head.drt_layer_1", feat, stride=5, padding=2)
+    t = F.relu(t_pre)
     t = _conv(sd, "object_head.drt_layer_2", t)
     mu = t[:, 0].reshape(n, -1)
     sigma2 = torch.exp(t[:, 1]).reshape(n, -1)
-    x = F.relu(_conv(sd, "object_head.sal_layer_3", feat))
+    x_pre = _conv(sd, "object_head.sal_layer_3", feat)
+    if tap is not None:
+        tap.setdefault("sal3_pre", {})[tag] = x_pre.detach()
+        tap.setdefault("drt1_pre", {})[tag] = t_pre.detach()
+    x = F.relu(x_pre)
     z = torch.cat([y, x.reshape(n, 1, -1)], dim=-1)
     if not training:
         z = F.softmax(z, -1)
@@ -166,13 +172,18 @@ def sal_conv_key_in(sd):
 
 
 def forward(sd, task, images, attention_maps=None, performances=None, tasks=None, *, training, T=16,
-            arch="resnet50", bn_new=None) -> Dict[str, torch.Tensor]:
+            arch="resnet50", bn_new=None, tap=None) -> Dict[str, torch.Tensor]:
     """baseline.forward -> training_process / inference.
     AiR: baseline_attention.py:253-493; OSIE: OSIE/models/baseline_attention.py:239-396;
-    COCO: COCO_Search18/models/baseline_attention_multihead.py:246-406."""
+    COCO: COCO_Search18/models/baseline_attention_multihead.py:246-406.
+    tap (tests only, a dict): receives the inputs / pre-activations of the ReLUs whose parameters the gradient tests examine for
+    mask flips -- "enc", "sal_conv_pre", per decode step t "h"[t] and, per (head name, t), "sal3_pre" / "drt1_pre"."""
     n = images.shape[0]
     x = encoder(sd, images, arch, training, bn_new)
-    vf = F.relu(_conv(sd, "sal_conv", x, padding=1))
+    vf_pre = _conv(sd, "sal_conv", x, padding=1)
+    if tap is not None:
+        tap["enc"], tap["sal_conv_pre"] = x.detach(), vf_pre.detach()
+    vf = F.relu(vf_pre)
     hm, wm = vf.shape[2], vf.shape[3]
     if task == "OSIE":                      # OSIE/...:261 zero attention map
         attention_maps = images.new_zeros((n, 1, hm, wm))
@@ -200,13 +211,15 @@ def forward(sd, task, images, attention_maps=None, performances=None, tasks=None
         push(k, attention_maps)
     state = (torch.zeros_like(vf), torch.zeros_like(vf))
     per_head: List[List[dict]] = [[] for _ in range(ns)]
-    for _ in range(T):
+    for step in range(T):
         out, state = conv_lstm(sd, vf, state, sp_mem, se_mem, streams)
+        if tap is not None:
+            tap.setdefault("h", {})[step] = out.detach()
         if task == "AiR":
-            heads = [predict_head(sd, _conv(sd, "performance_sal_layer.True", out, padding=2), training),
-                     predict_head(sd, _conv(sd, "performance_sal_layer.False", out, padding=2), training)]
+            heads = [predict_head(sd, _conv(sd, "performance_sal_layer.True", out, padding=2), training, tap, ("True", step)),
+                     predict_head(sd, _conv(sd, "performance_sal_layer.False", out, padding=2), training, tap, ("False", step))]
         elif task == "OSIE":
-            heads = [predict_head(sd, _conv(sd, "performance_sal_layer", out, padding=2), training)]
+            heads = [predict_head(sd, _conv(sd, "performance_sal_layer", out, padding=2), training, tap, ("", step))]
         else:   # per-sample batch-1 convs keyed by task id, ...multihead.py:285-288
             feats = [_conv(sd, "object_sal_layer." + COCO_OBJECTS[int(tasks[b])], out[b:b + 1], padding=2)
                      for b in range(n)]

@@ -28,8 +28,9 @@ def _rng(key: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF))
 
 
-FAMILIES = ("default", "tame")
+FAMILIES = ("default", "tame", "tame_sharp")
 TAME_LAST_BN_GAIN = 0.25
+SHARP_HEAD_GAIN = 8.0          # family "tame_sharp": gain of the two layers that emit the action logits
 
 
 def _is_last_bn_of_block(prefix: str, bn_keys) -> bool:
@@ -51,9 +52,15 @@ def procedural_tensor(key: str, shape: Tuple[int, ...], bn_keys: Iterable[str], 
     family "tame": identical draws, except that the BatchNorm closing each residual branch has its weight scaled by
     TAME_LAST_BN_GAIN (the usual small-gamma residual initialisation).  Activations stay O(1-10) in both BN modes, the decoder
     works in its smooth regime, and the reference's fp32-vs-fp64 drift stays ~1e-5 of scale over all 16 steps -- so every step
-    can be held to the north-star bar (1e-4 on logits, exact argmax)."""
+    can be held to the north-star bar (1e-4 on logits, exact argmax).
+    family "tame_sharp": "tame" with the two layers that emit the action logits (object_head.sal_layer_2 / sal_layer_3, weights and
+    biases) scaled by SHARP_HEAD_GAIN: logits of trained-model magnitude (several units, peaked softmax) on a recurrence that stays
+    non-chaotic -- the absolute 1e-4 bar on logits is then a RELATIVE 1e-5 (VERDICT r4 "what's weak" #4)."""
     if family not in FAMILIES:
         raise ValueError(f"unknown weight family {family!r}")
+    if family == "tame_sharp":
+        t = procedural_tensor(key, shape, bn_keys, seed, "tame")
+        return t * SHARP_HEAD_GAIN if key.startswith(("object_head.sal_layer_2.", "object_head.sal_layer_3.")) else t
     rng = _rng(key, seed)
     prefix, _, leaf = key.rpartition(".")
     if leaf == "num_batches_tracked":

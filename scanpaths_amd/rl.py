@@ -11,7 +11,11 @@ path.  The pieces:
 
 Quirk kept from the reference: the ``+ args.lambda_5 * (...)`` terms of loss_actions / loss_duration stand on their own
 source lines (train.py:332-340) and are therefore no-op expression statements -- lambda_5 does not influence the loss.
-``rl_loss`` computes them as the reference's arithmetic would and returns them in ``info`` so a caller can opt in."""
+``rl_loss`` computes them as the reference's arithmetic would and returns them in ``info`` so a caller can opt in.
+
+OSIE / COCO_Search18 (``rl_loss_single_head`` / ``rl_step_single_head``; OSIE/train.py:197-262, COCO_Search18/train.py:212-283): ONE head,
+no performance split -- rl_sample_number samples per image, reward = harmonic mean of the two ScanMatch scores of a sample against
+the image's human scanpaths (pairs_eval columns 5:7 / pairs_eval_scanmatch), baseline = the mean over the samples."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
@@ -23,7 +27,8 @@ import torch
 from . import functional as F
 from .models.loss import LogAction, LogDuration
 from .utils.evaltools.scanmatch import SequenceTooLong
-from .utils.evaluation import gtpairs_eval_scanmatch_performance_related, pairs_eval_scanmatch_performance_related
+from .utils.evaluation import (gtpairs_eval_scanmatch_performance_related, pairs_eval, pairs_eval_scanmatch,
+                               pairs_eval_scanmatch_performance_related)
 
 
 def _hmean(a: np.ndarray) -> np.ndarray:
@@ -125,6 +130,71 @@ def rl_step(model, sampling, optimizer, images, attention_maps, gt_fix_vectors, 
         nld.append(F.scale_const(LogDuration(samples["durations"].detach(), mu, s2, duration_masks), -1.0))
     loss, info = rl_loss(torch.stack(nla, 0), torch.stack(nld, 0), np.stack(same_b, 0), np.stack(diff_b, 0), gt_good, gt_poor,
                          gt_diff, S, lambda_5)
+    loss.backward()
+    info["grad_norm"] = optimizer.step()
+    info["resamples"] = resamples
+    return loss.detach(), info
+
+
+def rl_loss_single_head(neg_log_actions: torch.Tensor, neg_log_durations: torch.Tensor, metrics_reward, task: str):
+    """neg_log_* [S, N]; metrics_reward [S, N, 11] (OSIE: pairs_eval) or [S, N, 2] (COCO_Search18: pairs_eval_scanmatch), float32 as the
+    reference collects them.  OSIE/train.py:248-258, COCO_Search18/train.py:269-279 -> (loss, info)"""
+    assert task in ("OSIE", "COCO_Search18"), task
+    r = np.asarray(metrics_reward, dtype=np.float32)
+    cols = r[:, :, 5:7] if task == "OSIE" else r
+    hm = np.asarray(_hmean(cols), dtype=np.float32)                           # [S, N]
+    base = hm.mean(0, keepdims=True)
+    adv = torch.from_numpy(np.ascontiguousarray(hm - base)).to(neg_log_actions.device)
+    loss_actions = _dot(neg_log_actions, adv)
+    loss_duration = _dot(neg_log_durations, adv)
+    loss = F.add(loss_actions.reshape(1), loss_duration.reshape(1))[0]
+    return loss, {"loss_actions": loss_actions, "loss_duration": loss_duration, "reward_hmean": hm, "baseline": base,
+                  "advantage": hm - base, "metrics_for_reward": r.mean(0).mean(0)}
+
+
+def rl_step_single_head(model, sampling, optimizer, images, gt_fix_vectors, ScanMatchwithDuration, ScanMatchwithoutDuration, task: str,
+                        attention_maps=None, tasks=None, rl_sample_number: int = 5, ablate_attention_info: bool = False,
+                        max_resamples: int = 100, multimatch=None):
+    """One RL iteration of OSIE (OSIE/train.py:205-262: model(images)) or COCO_Search18 (COCO_Search18/train.py:219-283:
+    model(images, attention_maps, tasks)).  ``optimizer`` is a FlatAdam (clip folded into step()).  Returns (loss, info)."""
+    assert task in ("OSIE", "COCO_Search18"), task
+    model.eval()
+    optimizer.zero_grad()
+    if task == "OSIE":
+        predict = model(images)
+    else:
+        if ablate_attention_info:
+            attention_maps = attention_maps * 0
+        predict = model(images, attention_maps, tasks)
+    prob, mu, s2 = predict["all_actions_prob"], predict["log_normal_mu"], predict["log_normal_sigma2"]
+    rewards: List[np.ndarray] = []
+    nla: List[torch.Tensor] = []
+    nld: List[torch.Tensor] = []
+    trial = resamples = 0
+    while trial < rl_sample_number:
+        samples = sampling.random_sample(prob, mu, s2)
+        fix, action_masks, duration_masks = sampling.generate_scanpath(images, samples["selected_actions_probs"], samples["durations"],
+                                                                       samples["selected_actions"])
+        finite = all(np.isfinite(np.asarray(f["duration"], dtype=np.float64)).all() for f in fix)
+        try:
+            if not finite:
+                raise SequenceTooLong("non-finite sampled duration")
+            if task == "OSIE":
+                reward = pairs_eval(gt_fix_vectors, fix, ScanMatchwithDuration, ScanMatchwithoutDuration, multimatch=multimatch)
+            else:
+                reward = pairs_eval_scanmatch(gt_fix_vectors, fix, ScanMatchwithDuration, ScanMatchwithoutDuration)
+        except SequenceTooLong:
+            reward = np.array([[np.nan]])
+        if np.any(np.isnan(reward)):                         # (OSIE/train.py:236-237) the sample is redrawn
+            resamples += 1
+            if resamples > max_resamples:
+                raise RuntimeError("rl_step_single_head: too many rejected samples (a reward row is NaN every time)")
+            continue
+        trial += 1
+        rewards.append(np.asarray(reward, dtype=np.float32))
+        nla.append(F.scale_const(LogAction(samples["selected_actions_probs"], action_masks), -1.0))
+        nld.append(F.scale_const(LogDuration(samples["durations"].detach(), mu, s2, duration_masks), -1.0))
+    loss, info = rl_loss_single_head(torch.stack(nla, 0), torch.stack(nld, 0), np.stack(rewards, 0), task)
     loss.backward()
     info["grad_norm"] = optimizer.step()
     info["resamples"] = resamples

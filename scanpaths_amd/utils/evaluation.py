@@ -278,3 +278,177 @@ def human_evaluation(dataloader, multimatch=None):
     human_metrics, human_metrics_std = _summarise(collect_all, collect_right, collect_wrong, "human")
     scores = {name: dict([(True, g), (False, p)]) for name, g, p in zip(gt_qid_name, good_scores, poor_scores)}
     return human_metrics, human_metrics_std, scores
+
+
+# ====================================================================================================================
+# OSIE / COCO_Search18 forms (SURVEY.md §8 rows f2 / f3 widened).  Free-viewing / visual-search scanpaths carry no answer
+# correctness, so there is no performance split: ONE metric set per call instead of all / right / wrong.
+#   evaluation(gt, pred)             OSIE/utils/evaluation.py:151-282 == COCO_Search18/utils/evaluation.py:180-311 (identical code)
+#   human_evaluation(loader, task=)  OSIE :11-148 (SED / STDE reshaped to [-1, n - 1]: equal scanpath counts; MultiMatch NaN rows NOT
+#                                    eliminated) / COCO_Search18 :11-178 (per-image ranges: ragged counts; NaN rows eliminated)
+#   pairs_eval                       OSIE :284-340  (RL reward, 11 columns)
+#   pairs_eval_scanmatch             COCO_Search18 :313-352 (RL reward, 2 columns)
+# As above: the pairs of a whole call are scored by batched device launches (ScanMatch x2, SED / STDE, MultiMatch), the grouping and the
+# statistics follow the reference line by line -- including (a) the per-pair rows hold the score WITH duration in column 5 and the one
+# WITHOUT in column 6 while the dicts are labelled correctly here (unlike AiR's :323-324), (b) pairs_eval divides an image's column sums
+# by the FULL number of its human scanpaths even after NaN rows were eliminated (:329), (c) pairs_eval scores ScanMatch / SED / STDE only
+# for the pairs MultiMatch could score.
+# ====================================================================================================================
+def _flat_metrics(mm_mean, mm_std, wd, wod, sed_all, stde_all, sed_best, stde_best):
+    mean = {"MultiMatch": dict(zip(("vector", "direction", "length", "position", "duration"), mm_mean)),
+            "ScanMatch": {"w/o duration": np.mean(wod), "with duration": np.mean(wd)},
+            "VAME": {"SED": sed_all.mean(), "STDE": stde_all.mean(), "SED_best": sed_best.mean(), "STDE_best": stde_best.mean()}}
+    std = {"MultiMatch": dict(zip(("vector", "direction", "length", "position", "duration"), mm_std)),
+           "ScanMatch": {"w/o duration": np.std(wod), "with duration": np.std(wd)},
+           "VAME": {"SED": sed_all.std(), "STDE": stde_all.std(), "SED_best": sed_best.std(), "STDE_best": stde_best.std()}}
+    return mean, std
+
+
+def _score_all(paths, pairs, mm_rows, sm_wd=None, sm_wod=None):
+    """[npairs, 9] float64 rows (5 MultiMatch, ScanMatch with / without duration, SED, STDE) for (first, second) path-index pairs"""
+    if sm_wd is None:
+        sm_wd, sm_wod = _make_scanmatch()
+    return _rows_for_pairs(paths, pairs, sm_wd, sm_wod, mm_rows)
+
+
+def evaluation(gt_fix_vectors, predict_fix_vectors, is_eliminating_nan=True, multimatch=None):
+    """(OSIE/utils/evaluation.py:151-282, COCO_Search18/utils/evaluation.py:180-311) -> cur_metrics, cur_metrics_std, scores_of_each_images.
+    Every (human scanpath of the image, prediction) pair; like the reference, SED / STDE are regrouped as [-1, number of human
+    scanpaths of the LAST image] for the "best" columns (equal counts per image expected)."""
+    mm = multimatch or _default_multimatch()
+    paths, pairs, cand, per_image = [], [], [], []
+    for index in range(len(gt_fix_vectors)):
+        pi = len(paths)
+        paths.append(_as_ms(predict_fix_vectors[index]))
+        per_image.append(len(gt_fix_vectors[index]))
+        for inner in gt_fix_vectors[index]:
+            paths.append(_as_ms(inner))
+            pairs.append((len(paths) - 1, pi))
+            cand.append((inner, predict_fix_vectors[index]))
+    mm_rows = _multimatch_rows(mm, cand)
+    rows = _score_all(paths, pairs, mm_rows)
+    scores_of_each_images, k = [], 0
+    for n in per_image:
+        scores_of_each_images.append(list(np.array([list(r) for r in rows[k:k + n]]).mean(axis=0)))
+        k += n
+    mmr = rows[:, :5]
+    if is_eliminating_nan:
+        mmr = mmr[np.isnan(mmr.sum(axis=1)) == False]          # noqa: E712
+    sed = rows[:, 7].reshape(-1, per_image[-1])
+    stde = rows[:, 8].reshape(-1, per_image[-1])
+    mean, std = _flat_metrics(np.mean(mmr, axis=0), np.std(mmr, axis=0), rows[:, 5], rows[:, 6], sed, stde, sed.min(-1), stde.max(-1))
+    return mean, std, scores_of_each_images
+
+
+def human_evaluation_free_viewing(dataloader, task="OSIE", multimatch=None):
+    """human_evaluation of OSIE (:11-148) / COCO_Search18 (:11-178): every ordered pair of distinct human scanpaths of an image;
+    batches carry "fix_vectors" and "img_names" -> human_metrics, human_metrics_std, {image name: mean score row of the image}"""
+    assert task in ("OSIE", "COCO_Search18"), task
+    mm = multimatch or _default_multimatch()
+    paths, pairs, cand, names, groups = [], [], [], [], []       # groups: per image, per first scanpath: number of pairs (n - 1)
+    for batch in dataloader:
+        names.extend(batch["img_names"])
+        for fix_vectors in batch["fix_vectors"]:
+            base = len(paths)
+            for fv in fix_vectors:
+                paths.append(_as_ms(fv))
+            n = len(fix_vectors)
+            groups.append(n)
+            for i1 in range(n):
+                for i2 in range(n):
+                    if i2 != i1:
+                        pairs.append((base + i1, base + i2))
+                        cand.append((fix_vectors[i1], fix_vectors[i2]))
+    rows = _score_all(paths, pairs, _multimatch_rows(mm, cand))
+    scores, k = [], 0
+    for n in groups:
+        cnt = n * (n - 1)
+        scores.append(list(np.array([list(r) for r in rows[k:k + cnt]]).mean(axis=0)))
+        k += cnt
+    mmr = rows[:, :5]
+    if task == "COCO_Search18":
+        mmr = mmr[np.isnan(mmr.sum(axis=1)) == False]          # noqa: E712  (:79; OSIE keeps the NaN rows, its means turn NaN)
+        sed_best, stde_best, k = [], [], 0
+        for n in groups:                                        # (:88-125) best over ALL ordered pairs of the image
+            cnt = n * (n - 1)
+            sed_best.append(rows[k:k + cnt, 7].min())
+            stde_best.append(rows[k:k + cnt, 8].max())
+            k += cnt
+        sed_all, stde_all = rows[:, 7], rows[:, 8]
+        sed_best, stde_best = np.array(sed_best), np.array(stde_best)
+    else:
+        sed_all = rows[:, 7].reshape(-1, groups[-1] - 1)       # (:86-87) one row per first scanpath: best over its n - 1 partners
+        stde_all = rows[:, 8].reshape(-1, groups[-1] - 1)
+        sed_best, stde_best = sed_all.min(-1), stde_all.max(-1)
+    mean, std = _flat_metrics(np.mean(mmr, axis=0), np.std(mmr, axis=0), rows[:, 5], rows[:, 6], sed_all, stde_all, sed_best, stde_best)
+    return mean, std, dict(zip(names, scores))
+
+
+def pairs_eval(gt_fix_vectors, predict_fix_vectors, ScanMatchwithDuration, ScanMatchwithoutDuration, is_eliminating_nan=True,
+               multimatch=None):
+    """(OSIE/utils/evaluation.py:284-340) RL reward of one sampled scanpath per image -> [N, 11] float: the 5 MultiMatch means, ScanMatch
+    without / with duration, SED, STDE (column sums over the scorable pairs divided by the image's FULL number of human scanpaths),
+    best SED (min) and best STDE (max); a NaN row where nothing was scorable (OSIE/train.py:236-238 then redraws the sample)."""
+    mm = multimatch or _default_multimatch()
+    cand = [(gt, predict_fix_vectors[index]) for index in range(len(gt_fix_vectors)) for gt in gt_fix_vectors[index]]
+    mm_all = _multimatch_rows(mm, cand)
+    paths, pairs, mm_rows, owner, k = [], [], [], [], 0
+    for index in range(len(gt_fix_vectors)):
+        pi = len(paths)
+        paths.append(_as_ms(predict_fix_vectors[index]))
+        for gt in gt_fix_vectors[index]:
+            rlt = mm_all[k]
+            k += 1
+            if np.any(np.isnan(np.asarray(rlt, dtype=np.float64))):
+                owner.append((index, None))                     # row of NaNs (:296-299): ScanMatch / SED / STDE are not run for it
+                continue
+            paths.append(_as_ms(gt))
+            pairs.append((len(paths) - 1, pi))
+            mm_rows.append(rlt)
+            owner.append((index, len(pairs) - 1))
+    rows = _rows_for_pairs(paths, pairs, ScanMatchwithDuration, ScanMatchwithoutDuration, mm_rows)
+    out = []
+    for index in range(len(gt_fix_vectors)):
+        coll = []
+        for i, slot in owner:
+            if i != index:
+                continue
+            if slot is None:
+                coll.append([np.nan] * 9)
+            else:
+                r = rows[slot]
+                coll.append(list(r[:5]) + [r[6], r[5], r[7], r[8]])          # (:323) [w/o duration, with duration, SED, STDE]
+        coll = np.array(coll, dtype=np.float64).reshape(-1, 9)
+        if is_eliminating_nan:
+            coll = coll[np.isnan(coll.sum(axis=1)) == False]   # noqa: E712
+        if coll.shape[0] != 0:
+            metric_mean = np.sum(coll, axis=0) / len(gt_fix_vectors[index])
+            v = np.zeros((11,), dtype=np.float32)
+            v[:9] = metric_mean[:9]
+            v[9], v[10] = coll[:, 7].min(), coll[:, 8].max()
+        else:
+            v = np.array([np.nan] * 11)
+        out.append(v)
+    return np.array(out)
+
+
+def pairs_eval_scanmatch(gt_fix_vectors, predict_fix_vectors, ScanMatchwithDuration, ScanMatchwithoutDuration, is_eliminating_nan=True):
+    """(COCO_Search18/utils/evaluation.py:313-352) RL reward -> [N, 2]: per image the ScanMatch score without / with duration of the
+    sampled scanpath against its human scanpaths, column sums over the non-NaN rows divided by the FULL number of human scanpaths."""
+    paths, pairs, owner = [], [], []
+    for index in range(len(gt_fix_vectors)):
+        pi = len(paths)
+        paths.append(_as_ms(predict_fix_vectors[index]))
+        for gt in gt_fix_vectors[index]:
+            paths.append(_as_ms(gt))
+            pairs.append((len(paths) - 1, pi))
+            owner.append(index)
+    wd = _score_pairs(ScanMatchwithDuration, paths, pairs)
+    wod = _score_pairs(ScanMatchwithoutDuration, paths, pairs)
+    out = []
+    for index in range(len(gt_fix_vectors)):
+        coll = np.array([[wod[k], wd[k]] for k, i in enumerate(owner) if i == index], dtype=np.float64).reshape(-1, 2)
+        if is_eliminating_nan:
+            coll = coll[np.isnan(coll.sum(axis=1)) == False]   # noqa: E712
+        out.append(np.sum(coll, axis=0) / len(gt_fix_vectors[index]) if coll.shape[0] != 0 else np.array([np.nan] * 2))
+    return np.array(out)

@@ -8,8 +8,8 @@ Per task it imports /root/reference/<task>/utils/evaluation.py where it lies and
   * evaluation(gt_fix_vectors, predict_fix_vectors)                         OSIE :151-282, COCO_Search18 :180-311
   * human_evaluation(dataloader)                                            OSIE :11-148 (equal scanpath counts), COCO_Search18 :11-178 (ragged)
   * pairs_eval (OSIE :284-340, 11 columns)  /  pairs_eval_scanmatch (COCO_Search18 :313-352, 2 columns)
-on seeded scanpath sets, and executes the reward / baseline / loss lines of the task's train.py (OSIE/train.py:249-262,
-COCO_Search18/train.py:266-279: read from the reference file at generation time and exec'd on seeded tensors -- nothing of it is
+on seeded scanpath sets, and executes the reward / baseline / loss lines of the task's train.py (OSIE/train.py:248-258,
+COCO_Search18/train.py:269-279: read from the reference file at generation time and exec'd on seeded tensors -- nothing of it is
 stored) with gradients.  Inputs + outputs go to tests/golden/eval_osie.npz / eval_coco.npz.
 
 Shims: as tests/golden/make_golden_eval.py (multimatch_gaze <- tests/helpers.py::toy_multimatch, tqdm no-op, cv2 / matplotlib empty)."""
@@ -24,8 +24,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 TASKS = {"osie": ("OSIE", "eval_osie.npz"), "coco": ("COCO_Search18", "eval_coco.npz")}
 # the reward -> loss lines of the RL branch: (first line, last line, text the first line must contain) in <task>/train.py
-RL_LINES = {"osie": (249, 262, "neg_log_actions_tensor = torch.cat(neg_log_actions_batch, dim=0)"),
-            "coco": (266, 279, "neg_log_actions_tensor = torch.cat(neg_log_actions_batch, dim=0)")}
+RL_LINES = {"osie": (248, 258, "neg_log_actions_tensor = torch.cat(neg_log_actions_batch, dim=0)"),
+            "coco": (269, 279, "neg_log_actions_tensor = torch.cat(neg_log_actions_batch, dim=0)")}
 
 
 def scanpath(g, n=None):
@@ -101,6 +101,16 @@ def run(task_key):
     out["hum_count"] = np.array(hcounts)
     out["hum_mean"], out["hum_std"] = table(hm), table(hstd)
     out["hum_scores"] = np.array([hscores[n] for n in names], dtype=np.float64)
+    # (OSIE's human_evaluation does not eliminate NaN rows: one unscorable pair makes its five MultiMatch means NaN -- kept, as the
+    # reference; a second set without short scanpaths pins those columns)
+    h2counts = [3, 3, 3] if task_key == "osie" else [3, 2, 4]
+    h2fix = [[scanpath(g, int(g.integers(3, 11))) for _ in range(c)] for c in h2counts]
+    names2 = [f"set2_{i:03d}.jpg" for i in range(len(h2counts))]
+    hm2, hstd2, hscores2 = REF.human_evaluation([{"fix_vectors": h2fix, "img_names": names2}])
+    out["hum2_fix"], out["hum2_len"] = flatten([f for l in h2fix for f in l])
+    out["hum2_count"] = np.array(h2counts)
+    out["hum2_mean"], out["hum2_std"] = table(hm2), table(hstd2)
+    out["hum2_scores"] = np.array([hscores2[n] for n in names2], dtype=np.float64)
     # ---- the reward of the RL branch: per image the mean over its human scanpaths (divided by their FULL count even after NaN rows
     #      were eliminated -- kept), NaN row for an image with nothing left --------------------------------------------------------
     wd = ScanMatch(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), TempBin=50, Threshold=3.5)

@@ -10,7 +10,7 @@ Two weight families (scanpaths_amd/procedural.py):
                  steps.  Bar, EVERY step, EVERY GEMM back-end:  err(hip32, ref64) <= max(1e-4 * scale, 5 * err(ref32, ref64))
                  (north_star: 1e-4 fp32 on logits) and the argmax fixation index exact at every (b, t) whose fp64 top-2 margin
                  exceeds twice that bar (the reference's own fp32 run cannot resolve less).  test_tame_* below; the per-step
-                 numbers are written to gpurun_out/parity/r03_parity_errors.json (committed copy: profiles/).
+                 numbers are written to gpurun_out/parity/r05_parity_errors.json (committed copy: profiles/).
   * "default" -- round-1 goldens; eval-mode BN does not normalise, the decoder gates saturate and the recurrence is chaotic
                  (the reference's fp32 run leaves its fp64 run by 1 % after ~3 steps).  Bar per step
                  max(1e-4 * scale, NOISE_X * running max of err(ref32, ref64)), compared while the reference's own drift is
@@ -53,12 +53,12 @@ def backend(request):
 
 
 def _record(rows):
-    """append per-step parity numbers to gpurun_out/parity/r03_parity_errors.json (merged back by gpurun; committed under profiles/)"""
+    """append per-step parity numbers to gpurun_out/parity/r05_parity_errors.json (merged back by gpurun; committed under profiles/)"""
     import json
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "parity")
     try:
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "r03_parity_errors.json")
+        path = os.path.join(d, "r05_parity_errors.json")
         old = json.load(open(path)) if os.path.exists(path) else []
         keyf = lambda r: (r["case"], r["backend"], r["key"], r["step"])
         have = {keyf(r): r for r in old}
@@ -73,38 +73,56 @@ MAX_KINKED = 2          # modules per case whose gradients may carry ReLU-kink e
 SMALL_NORM = 1e-6       # parameters whose gradient norm is below SMALL_NORM x the largest norm of the model are held to that floor
 
 
-def _kink_residual(d):
-    """norm of the gradient error that is NOT explained by at most two ReLU-kink events.  One event -- a pre-activation within the fp32
-    noise of zero gets the other mask in one implementation than in the other -- changes the gradient of the layer's parameters by ONE
-    element's contribution: a rank-one term of the weight gradient viewed as [output channels, inputs] (one output channel of the layer
-    itself: sal_conv.weight, profiles/r03_grad_error_concentration.log; or one PIXEL of a map the layer feeds, spread over all output
-    channels in proportion to the next layer's weights: performance_sal_layer.True.weight, profiles/r04_head_grad_probe.log -- a single
-    action-map mask flip at decode step 5, every other step agreeing to 5e-6), and two entries at most of a 1-D parameter."""
-    if d.dim() == 1:
-        if d.numel() < 64:
-            return None
-        sq = d.pow(2)
-        return float((sq.sum() - sq.topk(2).values.sum()).clamp(min=0).sqrt())
-    m = d.flatten(1)
-    if min(m.shape) < 2:
+def _kink_residual(name, d, kinks):
+    """norm of the gradient error of parameter `name` that is NOT explained by ReLU mask flips the ORACLE says are possible
+    (VERDICT r4 "next" #5: the round-4 rule removed the top two singular components of whatever the error was, which would equally
+    have excused a wrong per-row or per-channel scale).  kinks = helpers.kink_candidates of the case's fp64 oracle run: the ReLU
+    sites whose |pre-activation| is below 1e-5 of the tensor's maximum -- the only places where a fp32 implementation can take the
+    other side of the kink -- each with the rank-one direction its flip adds to a weight gradient viewed as [output channels, inputs]:
+      * sal_conv (vf = relu(sal_conv(enc)), baseline_attention.py:270): site (b, c, y, x) -> e_c (x) im2col3x3(enc)[b, y, x]: only ROW c,
+        only along that patch; the bias: entry c;
+      * performance_sal_layer.<head> (action_map = relu(sal_layer_3(head conv(h_t))), :154-158): site (b, t, y, x) ->
+        w3 (x) im2col5x5(h_t)[b, y, x] with w3 = sal_layer_3's 512 weights; the bias: along w3.
+    Everything outside the span of those directions must meet the bar.  None: the parameter has no candidate site (no exemption)."""
+    mod = name.rsplit(".", 1)[0]
+    k = (kinks or {}).get(mod)
+    if not k:
         return None
-    sv = torch.linalg.svdvals(m)
-    return float((sv.pow(2).sum() - sv[:2].pow(2).sum()).clamp(min=0).sqrt())
+    d = d.clone()
+    if "rows" in k:                                  # sal_conv
+        if name.endswith(".bias"):
+            for c in k["rows"]:
+                d[c] = 0.0
+            return float(d.norm())
+        m = d.flatten(1)
+        for c, P in k["rows"].items():               # P [sites of channel c, inputs]
+            P = torch.as_tensor(P, dtype=torch.float64)
+            coef = torch.linalg.lstsq(P.T, m[c].unsqueeze(1)).solution
+            m[c] -= (P.T @ coef).squeeze(1)
+        return float(m.norm())
+    u = torch.as_tensor(k["u"], dtype=torch.float64)
+    u = u / u.norm()
+    if name.endswith(".bias"):
+        return float((d - u * (u @ d)).norm())
+    V = torch.as_tensor(k["V"], dtype=torch.float64)                 # [sites, inputs]
+    m = d.flatten(1)
+    r = u @ m                                                        # the error's component along w3, as a function of the input index
+    coef = torch.linalg.lstsq(V.T, r.unsqueeze(1)).solution
+    return float((m - torch.outer(u, (V.T @ coef).squeeze(1))).norm())
 
 
-def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
+def _param_grad_check(case, named_got, g64, g32, backend="f16x2", kinks=None, record=True):
     """Per-parameter gradient bar (VERDICT r3 "what's weak" #1): every parameter is held to ITS OWN norm,
         ||got_k - ref64_k||  <=  max(10 * ||ref32_k - ref64_k||,  1e-4 * max(||ref64_k||, SMALL_NORM * top)),
     not to the largest gradient norm of the model -- Adam normalises per element, so a relative error of a small-norm parameter is
     exactly what the update sees (round 3's bar, relative to `top`, let performance_sal_layer.True.weight be wrong by 5.7 % of itself).
     named_got: {name: tensor or None}; g64 / g32: {name: tensor} (entries may be samples of the gradient: then `got` is sampled alike
-    by the caller).  ReLU-kink rule (_kink_residual): a parameter may exceed its bar if the error left after removing two kink
-    events meets the bar and the whole stays within 5e-3 of the norm; the small parameters of the SAME module (its bias) then share the
-    event.  At most MAX_KINKED modules per case.
+    by the caller).  ReLU-kink rule (_kink_residual, needs `kinks` from the case's oracle run): a parameter may exceed its bar if the
+    error OUTSIDE the directions of the oracle's candidate mask flips meets the bar and the whole stays within 5e-3 of the norm.  At
+    most MAX_KINKED modules per case.  Without `kinks` nothing is excused.
     Returns (rows, kinked, worst ratio to the oracle's own fp32 error, its parameter)."""
     top = max(float(torch.as_tensor(v).double().norm()) for v in g64.values())
     rows, kinked, worst, worst_name = [], [], 0.0, ""
-    pending = []
     for k, ref in g64.items():
         ref = torch.as_tensor(ref).double()
         got = named_got.get(k)
@@ -123,23 +141,17 @@ def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
         row = {"case": case, "backend": backend, "param": k, "err": e, "oracle32_err": floor, "norm": nrm, "bar": bar,
                "err_over_norm": e / max(nrm, 1e-300), "err_over_oracle32": e / max(floor, 1e-300), "kinked": False}
         if e > bar and e <= 5e-3 * nrm:
-            rest = _kink_residual(d)
+            rest = _kink_residual(k, d, kinks)
             if rest is not None and rest <= bar:
-                row["kinked"], row["err_without_two_events"] = True, rest
+                row["kinked"], row["err_outside_candidate_flips"] = True, rest
                 kinked.append((k, e / nrm, rest / nrm))
                 e = rest
-            elif d.dim() == 1:
-                pending.append(row)          # a bias / small parameter: may share the event of its module's weight (decided below)
         row["failed"] = bool(e > bar)
         rows.append(row)
         if floor > 1e-12 * top and e / floor > worst:
             worst, worst_name = e / floor, k
-    kinked_modules = {k.rsplit(".", 1)[0] for k, _, _ in kinked}
-    for row in pending:
-        if row["param"].rsplit(".", 1)[0] in kinked_modules:
-            row["kinked"], row["failed"] = True, False
-            kinked.append((row["param"], row["err_over_norm"], float("nan")))
-    _record_grads(rows)
+    if record:
+        _record_grads(rows)
     bad = [r for r in rows if r["failed"]]
     assert not bad, [(r["param"], f"err {r['err']:.3e} bar {r['bar']:.3e} norm {r['norm']:.3e} oracle32 {r['oracle32_err']:.3e}") for r in bad[:6]]
     assert len({k.rsplit(".", 1)[0] for k, _, _ in kinked}) <= MAX_KINKED, kinked
@@ -147,12 +159,12 @@ def _param_grad_check(case, named_got, g64, g32, backend="f16x2"):
 
 
 def _record_grads(rows):
-    """per-parameter gradient errors -> gpurun_out/parity/r04_grad_errors.json (committed copy: profiles/)"""
+    """per-parameter gradient errors -> gpurun_out/parity/r05_grad_errors.json (committed copy: profiles/)"""
     import json
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out", "parity")
     try:
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "r04_grad_errors.json")
+        path = os.path.join(d, "r05_grad_errors.json")
         old = json.load(open(path)) if os.path.exists(path) else []
         keyf = lambda r: (r["case"], r["backend"], r["param"])
         have = {keyf(r): r for r in old}
@@ -289,7 +301,10 @@ def test_eval_forward_matches_reference(name):
 
 
 TAME_EVAL = ["air_tame_eval_T16", "coco_tame_eval_T6", "osie_r18_tame_eval_T8"]
-TAME_TRAIN = ["air_tame_train_T16", "coco_tame_train_T6", "osie_r18_tame_train_T8"]
+TAME_TRAIN = ["air_tame_train_T16", "coco_tame_train_T6", "osie_r18_tame_train_T8",
+              # "tame_sharp": the logit-emitting layers x 8 -> logits span +-5.3 (peaked softmax, trained-model magnitude) on a recurrence
+              # that stays non-chaotic (reference fp32-vs-fp64 drift <= 4.2e-5 over all 16 steps): the absolute 1e-4 bar is a relative 2e-5
+              "air_sharp_train_T16"]
 
 
 @pytest.mark.parametrize("backend", BACKENDS, indirect=True)
@@ -301,7 +316,7 @@ def test_tame_all_steps_meet_the_north_star_bar(name, backend):
     and the argmax fixation index is exact at every (b, t) whose fp64 top-2 margin exceeds 2x that bar.  AiR/models/
     baseline_attention.py:303-336 (train loop), :385-493 (inference)."""
     meta, g = load_golden(name)
-    assert meta["weight_family"] == "tame"
+    assert meta["weight_family"].startswith("tame")
     b = case_inputs(meta, torch.float32)
     train = meta["mode"] == "train"
     model = _build(meta)
@@ -330,7 +345,7 @@ def test_tame_all_steps_meet_the_north_star_bar(name, backend):
     assert nargmax >= 0.5 * ntot, (nargmax, ntot)      # the argmax check must not be vacuous
 
 
-@pytest.mark.parametrize("name", ["air_train_T4", "osie_r18_train_T8", "coco_train_T6", "air_tame_train_T16"])
+@pytest.mark.parametrize("name", ["air_train_T4", "osie_r18_train_T8", "coco_train_T6", "air_tame_train_T16", "air_sharp_train_T16"])
 def test_train_step_matches_reference(name):
     from scanpaths_amd.models.loss import supervised_loss
     from scanpaths_amd.optim import FlatAdam
@@ -342,7 +357,7 @@ def test_train_step_matches_reference(name):
     opt.zero_grad()
     pred = _call(model, meta, b)
     report = []
-    tame = meta.get("weight_family") == "tame"
+    tame = str(meta.get("weight_family", "")).startswith("tame")
     tmax = _informative_steps(g, list(pred.keys()), meta["T"])
     for k, v in pred.items():
         bars = _check(name, k, v, g, report, meta["T"], tmax, noise_x=TAME_X if tame else None,
@@ -494,7 +509,7 @@ BENCH_PATH_COUNTERS = ("gateconv_lstm", "gateconv_lstm_hplanes", "lstm_bwd_split
                        "wgrad_multi", "row_sparse_bwd")
 
 
-def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
+def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch, request):
     """the EXACT kernel path of the bench line -- 40x64 map (P % 256 == 0), ResNet-50, 16 decode steps, the cell
     as the epilogue of the h-gate conv (sp_gateconv_lstm_f16x2) on 15 of them, BatchNorm passes that emit split operands / leave
     fp32 tensors unwritten (skip_z, skip_dx), the cell backward writing the split dpre -- held to the fp64 oracle on the tame
@@ -528,22 +543,25 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     assert bench_counts["wgrad_multi"] >= 1, bench_counts          # the T - 1 weight gradients of the h-gate conv in ONE launch (hw2_kernel)
     assert bench_counts["row_sparse_bwd"] == 1, bench_counts       # ... which skips the samples behind their last masked-in step
 
-    # ---- the oracle on the host: fp64 and fp32, train (loss + gradients) and eval -- two worker processes side by side ----------
-    import concurrent.futures as cf
-    import multiprocessing as mp
-    from helpers import oracle_bench_case
+    # ---- the oracle on the host: fp64 and fp32, train (loss + gradients + kink candidates) and eval -- two worker processes, started by
+    #      tests/conftest.py when the session began (this test runs last), or here when the test runs on its own ------------------------
+    from helpers import BENCH_CASE, bench_bn_calibration, start_bench_oracle
+    assert (Hm, Wm, T, NB, seed) == tuple(BENCH_CASE[k] for k in ("Hm", "Wm", "T", "NB", "seed"))
     b = make_batch("AiR", NB, 320, 512, T, seed=seed)
     g, grads, losses = {}, {}, {}
-    threads = max(4, min(48, (os.cpu_count() or 8) // 2))
-    with cf.ProcessPoolExecutor(2, mp_context=mp.get_context("spawn")) as ex:
-        futs = {tag: ex.submit(oracle_bench_case, (dn, seed, Hm, Wm, T, NB, 320, 512, threads))
-                for dn, tag in (("float64", "ref64/"), ("float32", "ref32/"))}
-        for tag, fu in futs.items():
-            outs, gr, ls = fu.result()
-            for k, v in outs.items():
-                g[tag + k] = v
-            grads[tag] = {k: torch.from_numpy(v).double() for k, v in gr.items()}
-            losses[tag] = ls
+    bo = getattr(request.config, "_bench_oracle", None)
+    own = bo is None
+    ex, futs = start_bench_oracle() if own else bo
+    kinks = None
+    for tag, fu in futs.items():
+        outs, gr, ls, kk = fu.result()
+        kinks = kk if kk is not None else kinks
+        for k, v in outs.items():
+            g[tag + k] = v
+        grads[tag] = {k: torch.from_numpy(v).double() for k, v in gr.items()}
+        losses[tag] = ls
+    if own:
+        ex.shutdown()
 
     # ---- the HIP path at 2 images with the bs-32 cost-model decisions --------------------------------------------------------------
     monkeypatch.setattr(F, "COST_M_SCALE", 32.0 / NB)
@@ -571,7 +589,45 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     # with a ReLU-kink event (measured on this very case, profiles/r03_grad_error_concentration.log: sal_conv.weight, 98.2 % of the
     # squared error in output channel 434 on every back-end, the other 510 channels below the fp32 oracle's own error)
     got_g = {k: p.grad for k, p in model.named_parameters() if k in g64}
-    _, kinked, worst, worst_name = _param_grad_check("bench_path_320x512_train_T16", got_g, g64, g32)
+    _, kinked, worst, worst_name = _param_grad_check("bench_path_320x512_train_T16", got_g, g64, g32, kinks=kinks)
+    # ---- the exemption is confined to the oracle's candidate flips: rank-one errors of the SAME size elsewhere must fail --------------
+    # (round 4's rule -- drop the top two singular components of whatever the error is -- would have excused a wrong
+    # per-row scale.)  (a) one output channel of sal_conv.weight that has NO candidate site, scaled by 1 + eps with eps chosen to put
+    # the error at 3 x the parameter's bar; (b) a channel that HAS candidate sites, perturbed along a direction that is not one of its
+    # patches; (c) performance_sal_layer.True.weight perturbed by a rank-one term w3 (x) v with v not a candidate patch.
+    def corrupted(name, delta):
+        g2 = dict(got_g)
+        g2[name] = got_g[name].detach().cpu().double() + delta
+        return g2
+
+    def bar_of(name):
+        ref, r32 = torch.as_tensor(g64[name]).double(), torch.as_tensor(g32[name]).double()
+        top_ = max(float(torch.as_tensor(v).double().norm()) for v in g64.values())
+        return max(10 * float((r32 - ref).norm()), 1e-4 * max(float(ref.norm()), SMALL_NORM * top_))
+
+    gen = torch.Generator().manual_seed(0)
+    w_ref = torch.as_tensor(g64["sal_conv.weight"]).double()
+    cand_rows = set((kinks or {}).get("sal_conv", {}).get("rows", {}))
+    free_c = next(c for c in range(w_ref.shape[0]) if c not in cand_rows and float(w_ref[c].norm()) > 0)
+    d = torch.zeros_like(w_ref)
+    d[free_c] = w_ref[free_c] * (3 * bar_of("sal_conv.weight") / float(w_ref[free_c].norm()))          # a wrong scale of ONE row
+    with pytest.raises(AssertionError, match="sal_conv.weight"):
+        _param_grad_check("negative_row_scale", corrupted("sal_conv.weight", d), g64, g32, kinks=kinks, record=False)
+    if cand_rows:
+        c = sorted(cand_rows)[0]
+        d = torch.zeros_like(w_ref)
+        noise = torch.randn(w_ref[c].shape, generator=gen, dtype=torch.float64)
+        d[c] = noise * (3 * bar_of("sal_conv.weight") / float(noise.norm()))
+        with pytest.raises(AssertionError, match="sal_conv.weight"):
+            _param_grad_check("negative_candidate_row_other_direction", corrupted("sal_conv.weight", d), g64, g32, kinks=kinks, record=False)
+    hname = "performance_sal_layer.True.weight"
+    h_ref = torch.as_tensor(g64[hname]).double()
+    w3 = torch.as_tensor(model.object_head.sal_layer_3.weight.detach().cpu()).double().reshape(-1)
+    v = torch.randn(h_ref[0].numel(), generator=gen, dtype=torch.float64)
+    d = torch.outer(w3, v).reshape(h_ref.shape)
+    d = d * (3 * bar_of(hname) / float(d.norm()))
+    with pytest.raises(AssertionError, match="performance_sal_layer.True.weight"):
+        _param_grad_check("negative_head_rank_one", corrupted(hname, d), g64, g32, kinks=kinks, record=False)
     rows.append({"case": "bench_path_320x512_train_T16", "backend": "f16x2", "key": "loss", "step": -1, "err": abs(float(loss) - l64),
                  "ref32_noise": abs(l32 - l64), "scale": abs(l64), "bar": max(1e-4, 10 * abs(l32 - l64)),
                  "worst_grad_err_over_oracle32": worst, "worst_grad_param": worst_name, "fusion_counts": got_counts,
@@ -580,19 +636,20 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch):
     # eval mode (probabilities; both heads) -- on a FRESH model: the train-mode forward above has updated the BatchNorm running
     # statistics of `model`, the oracle's eval forward uses the initial ones
     del model
-    model = _build(meta, Hm, Wm).eval()
+    model = _build(meta, Hm, Wm)
+    # running statistics that fit the case's inputs (tests/golden/bench_bn_calib.npz: the batch statistics of these two images from one
+    # fp64 oracle pass, tests/golden/make_bn_calibration.py) -- the oracle's eval runs use the same; with the procedural ones the oracle's
+    # own fp32 run left its fp64 run after ~10 steps and rounds 3-4 could only hold the "informative" ones
+    model.load_state_dict({k: torch.from_numpy(v).float() for k, v in bench_bn_calibration().items()}, strict=False)
+    model = model.to(DEV).eval()
     F.reset_fusion_counts()
     with torch.no_grad():
         pe = model(bd["images"], bd["attention_maps"])
     assert F.FUSION_COUNTS["gateconv_lstm"] == T - 1
     eval_steps = T
     for k, v in pe.items():
-        # eval mode at this map size: the procedural running statistics do not normalise as well as the batch statistics of train
-        # mode, and the ORACLE's own fp32 run leaves its fp64 run by more than 1 % of an output's scale after ~12 steps on these
-        # inputs (_check stops there: later steps carry no information about correctness) -- at least half of the steps must be
-        # informative, every informative step must meet the bar
         bars = _check("bench_path_320x512_eval_T16", "eval/" + k, v, g, report, T, None, noise_x=TAME_X, rows=rows)
-        assert len(bars) >= T // 2, (k, len(bars))
+        assert len(bars) == T, (k, len(bars))              # EVERY decode step of eval mode is held to the bar
         eval_steps = min(eval_steps, len(bars))
         if k.endswith("all_actions_prob") and not any(r.get("failed") for r in rows):
             n, tot = _check_argmax(v, g["ref64/eval/" + k], bars)

@@ -191,3 +191,105 @@ def test_eval_mode_backward_matches_oracle():
         if not e <= max(1e-4 * top, 20 * floor):
             bad.append((k, e, floor, float(g64[k].norm())))
     assert not bad, bad[:12]
+
+
+# ---- OSIE / COCO_Search18 forms of the RL step and of validation scoring (SURVEY.md §8 f2 / f3 widened) -----------
+def _task_golden(key):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", f"eval_{key}.npz"))
+
+
+def _flat_table(d):
+    from helpers import EVAL_COLUMNS
+    return np.array([float(d[g][k]) for g, k in EVAL_COLUMNS], dtype=np.float64)
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), (a, b)
+    m = ~np.isnan(b)
+    assert np.abs(a[m] - b[m]).max(initial=0.0) <= tol, np.abs(a[m] - b[m]).max()
+
+
+@pytest.mark.parametrize("key,task", [("osie", "OSIE"), ("coco", "COCO_Search18")])
+def test_single_head_validation_scoring_and_rl_reward_match_the_real_reference(key, task):
+    """evaluation / human_evaluation / pairs_eval (OSIE) / pairs_eval_scanmatch (COCO_Search18) against outputs of the REAL reference
+    functions (tests/golden/eval_<task>.npz from tests/golden/make_golden_eval_tasks.py: /root/reference/OSIE/utils/evaluation.py:11-340,
+    /root/reference/COCO_Search18/utils/evaluation.py:11-352; deterministic MultiMatch stand-in on both sides), scored by the batched
+    device kernels.  ScanMatch and SED enter bit-exact, STDE <= 4 ulp; float64 collections -> 1e-9, pairs_eval's float32 rows -> 1e-6."""
+    from helpers import toy_multimatch, unpack_scanpaths
+    from scanpaths_amd.utils import evaluation as E
+    from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch
+    g = _task_golden(key)
+    gt = unpack_scanpaths(g["ev_gt_fix"], g["ev_gt_len"], g["ev_gt_count"])
+    pred = unpack_scanpaths(g["ev_pred_fix"], g["ev_pred_len"])
+    mean, std, scores = E.evaluation(gt, pred, multimatch=toy_multimatch)
+    _close(_flat_table(mean), g["ev_mean"], 1e-9)
+    _close(_flat_table(std), g["ev_std"], 1e-9)
+    _close(np.array(scores), g["ev_scores"], 1e-9)
+    assert np.array_equal(np.array(scores)[:, 5:8], g["ev_scores"][:, 5:8])                 # ScanMatch x2 and SED: bit-exact
+    for tag in ("hum", "hum2"):
+        fix = unpack_scanpaths(g[tag + "_fix"], g[tag + "_len"], g[tag + "_count"])
+        names = [f"n{i}" for i in range(len(fix))]
+        half = max(1, len(fix) // 2)
+        loader = [{"fix_vectors": fix[:half], "img_names": names[:half]}, {"fix_vectors": fix[half:], "img_names": names[half:]}]
+        hm, hs, hsc = E.human_evaluation_free_viewing(loader, task=task, multimatch=toy_multimatch)
+        _close(_flat_table(hm), g[tag + "_mean"], 1e-9)
+        _close(_flat_table(hs), g[tag + "_std"], 1e-9)
+        _close(np.array([hsc[n] for n in names]), g[tag + "_scores"], 1e-9)
+    cfg = dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), Threshold=3.5)
+    wd, wod = ScanMatch(TempBin=50, **cfg), ScanMatch(**cfg)
+    pgt = unpack_scanpaths(g["pe_gt_fix"], g["pe_gt_len"], g["pe_gt_count"])
+    ppred = unpack_scanpaths(g["pe_pred_fix"], g["pe_pred_len"])
+    rew = E.pairs_eval(pgt, ppred, wd, wod, multimatch=toy_multimatch) if task == "OSIE" else E.pairs_eval_scanmatch(pgt, ppred, wd, wod)
+    _close(rew, g["pe_reward"], 1e-6 if task == "OSIE" else 1e-12)
+    if task == "OSIE":
+        assert np.isnan(rew[2]).all() and rew.shape == (6, 11)                              # the image whose only human scanpath is unscorable
+
+
+@pytest.mark.parametrize("key,task", [("osie", "OSIE"), ("coco", "COCO_Search18")])
+def test_single_head_rl_loss_matches_the_reference_lines(key, task):
+    """reward -> harmonic mean -> per-image baseline -> loss with its gradients, against the reference's own lines (OSIE/train.py:248-258,
+    COCO_Search18/train.py:269-279) executed on seeded tensors by tests/golden/make_golden_eval_tasks.py"""
+    from scanpaths_amd.rl import rl_loss_single_head
+    g = _task_golden(key)
+    a = torch.from_numpy(g["rl_nla"]).float().to(DEV).requires_grad_(True)
+    b = torch.from_numpy(g["rl_nld"]).float().to(DEV).requires_grad_(True)
+    loss, info = rl_loss_single_head(a, b, g["rl_reward"], task)
+    loss.backward()
+    assert np.abs(info["reward_hmean"] - g["rl_hmean"]).max() <= 1e-6
+    for got, want in ((loss, "rl_loss"), (info["loss_actions"], "rl_loss_actions"), (info["loss_duration"], "rl_loss_duration")):
+        assert abs(float(got) - float(g[want])) <= 2e-6 * max(1.0, abs(float(g[want]))), (want, float(got), float(g[want]))
+    assert np.abs(a.grad.cpu().numpy() - g["rl_dnla"]).max() <= 1e-6 and np.abs(b.grad.cpu().numpy() - g["rl_dnld"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("task", ["OSIE", "COCO_Search18"])
+def test_single_head_rl_step_end_to_end(task):
+    """OSIE/train.py:205-262 / COCO_Search18/train.py:219-283 on the HIP path: eval-mode forward with autograd -> sampled scanpaths ->
+    device-scored rewards (pairs_eval incl. MultiMatch, SED, STDE / pairs_eval_scanmatch) -> REINFORCE loss -> clip + Adam"""
+    from helpers import unpack_scanpaths
+    from scanpaths_amd.models.sampling import Sampling
+    from scanpaths_amd.models.scanpath_model import ScanpathModel
+    from scanpaths_amd.optim import FlatAdam
+    from scanpaths_amd.procedural import fill_module
+    from scanpaths_amd.rl import rl_step_single_head
+    from scanpaths_amd.synth import make_batch
+    from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch
+    T, N = 4, 2
+    m = ScanpathModel(task, convLSTM_length=T, arch="resnet18" if task == "OSIE" else "resnet50")
+    fill_module(m, 6)
+    m = m.to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-5, weight_decay=5e-4, clip=12.5, conditional_params=m.has_conditional_params)
+    b = make_batch(task, N, 240, 320, T, seed=6)
+    g = _task_golden("osie" if task == "OSIE" else "coco")
+    gt = unpack_scanpaths(g["pe_gt_fix"], g["pe_gt_len"], g["pe_gt_count"])
+    gt = [gt[3], gt[1]]                                                   # two images with several scorable human scanpaths
+    cfg = dict(Xres=320, Yres=240, Xbin=16, Ybin=12, Offset=(0, 0), Threshold=3.5)
+    before = opt.flat_p.detach().clone()
+    loss, info = rl_step_single_head(m, Sampling(convLSTM_length=T, min_length=3, map_width=40, map_height=30, width=320, height=240, seed=1),
+                                     opt, b["images"].to(DEV), gt, ScanMatch(TempBin=50, **cfg), ScanMatch(**cfg), task,
+                                     attention_maps=b["attention_maps"].to(DEV), tasks=b["tasks"].to(DEV) if b.get("tasks") is not None else None,
+                                     rl_sample_number=3)
+    assert np.isfinite(float(loss)) and torch.isfinite(opt.flat_p).all() and not m.training
+    assert float(info["grad_norm"]) > 0 and not torch.equal(before, opt.flat_p)
+    assert info["reward_hmean"].shape == (3, N) and info["metrics_for_reward"].shape == ((11,) if task == "OSIE" else (2,))
