@@ -89,11 +89,22 @@ def bucketer_overhead(opt, step, sync, steps, bucketed_ms):
     sync()
     opt.step = orig_step
     bk.record = False
-    buckets = [{"bucket": b, "mb": round(nb / 2 ** 20, 1), "launched_ms_before_end_of_backward": round(ev.elapsed_time(end_bwd), 2)}
-               for b, nb, ev in bk.last_ready_events]
+    # what a bucket's all-reduce would take on an 8-GPU xGMI node (7 links x ~77 GB/s each way per GPU): a ring over ONE
+    # link moves 2 (N - 1) / N of the bytes, a direct reduce-scatter + all-gather over all 7 links a seventh of that -- the part of it
+    # that does not fit into the window before the end of backward is exposed
+    def xgmi_ms(nbytes, links):
+        return 2.0 * 7 / 8 * nbytes / (links * 77e9) * 1e3
+    buckets = []
+    for b, nb, ev in bk.last_ready_events:
+        window = ev.elapsed_time(end_bwd)
+        buckets.append({"bucket": b, "mb": round(nb / 2 ** 20, 1), "launched_ms_before_end_of_backward": round(window, 2),
+                        "expected_allreduce_ms_8gpu": {"ring_one_link": round(xgmi_ms(nb, 1), 3), "direct_7_links": round(xgmi_ms(nb, 7), 3)},
+                        "expected_exposed_ms_8gpu": {"ring_one_link": round(max(0.0, xgmi_ms(nb, 1) - window), 3),
+                                                     "direct_7_links": round(max(0.0, xgmi_ms(nb, 7) - window), 3)}})
     plain = 0.5 * (plain_a + plain_b)
     bucketed = 0.5 * (bucketed_ms + bucketed_b)
-    return {"world": 1, "backend": "nccl (RCCL)", "bucket_mb": 32, "n_buckets": len(bk.ranges),
+    return {"world": 1, "backend": "nccl (RCCL)", "bucket_mb": 32, "first_bucket_mb": round((bk.ranges[0][1] - bk.ranges[0][0]) * 4 / 2 ** 20, 1),
+            "n_buckets": len(bk.ranges),
             "plain_ms_per_step": [round(plain_a, 2), round(plain_b, 2)], "bucketed_ms_per_step": [round(bucketed_ms, 2), round(bucketed_b, 2)],
             "ddp_overhead_ms": round(bucketed - plain, 2),
             "bucket_timeline": buckets,

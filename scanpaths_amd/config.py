@@ -108,6 +108,21 @@ def set(**kw) -> None:      # noqa: A001 (deliberately the module's verb)
         h._apply_config()
 
 
+def honour_env_for_tools() -> None:
+    """For tools/ and tests/diagnostics only -- scripts whose PURPOSE is to A/B a switch named on their command line
+    (`SP_SPLIT_SCHEME=f16x1 python3 tools/precision_mode_error.py`, `SP_LIBRARY=timing python3 tools/bench_drt.py`): equivalent to
+    exporting SP_ALLOW_ENV_TUNING=1 before the import.  Call it before the first kernel launch (the library choice is fixed there).
+    Values go through the same checks and loud lines as config.set(); the product path never calls this."""
+    os.environ["SP_ALLOW_ENV_TUNING"] = "1"
+    _load_env()
+    for name in ("scanpaths_amd.functional", "scanpaths_amd.hip"):
+        m = sys.modules.get(name)
+        if m is not None:
+            if name.endswith("hip") and m._lib is not None and (settings["library"] == "timing") != m.TIMING_LIB:
+                raise RuntimeError("scanpaths_amd.config: the library is already loaded; call honour_env_for_tools() before the first launch")
+            m._apply_config()
+
+
 def non_default() -> dict:
     """the switches that differ from the defaults (bench.py tags its JSON line with them)"""
     return {k: v for k, v in settings.items() if v != DEFAULTS[k]}

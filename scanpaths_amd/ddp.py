@@ -49,8 +49,16 @@ class GradBucketer:
     25-50 MB buckets keep each collective bandwidth-bound (>= 0.3 ms) without leaving a long un-overlapped tail (the first
     bucket of the encoder is the last to become ready).  Pure torch.distributed: runs on CPU tensors over gloo in the tests."""
 
-    def __init__(self, flat: torch.Tensor, offsets, numel: int, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, flat: torch.Tensor, offsets, numel: int, bucket_bytes: int = 32 << 20, group=None, first_bucket_bytes=None):
+        """first_bucket_bytes: size at which bucket 0 -- the FIRST parameters in registration order (the encoder's stem and first
+        layers), whose gradients are the LAST to become ready -- is closed; default a quarter of bucket_bytes.  Its all-reduce is
+        launched when backward is all but over and is therefore fully exposed: with equal buckets that was 32.6 MB at the benchmark
+        model (launched 0.03 ms before the end of backward, profiles/r04_bench_bucketer.json); a quarter-size first bucket exposes
+        ~8 MB and lets the bucket behind it (rest of layer 3) start while layers 1 / 2 -- the expensive high-resolution part of the
+        encoder's backward -- are still running."""
         self.flat, self.group = flat, group
+        if first_bucket_bytes is None:
+            first_bucket_bytes = max(1, bucket_bytes // 4)
         n = len(offsets)
         ends = list(offsets[1:]) + [numel]
         self.bucket_of = [0] * n
@@ -59,7 +67,7 @@ class GradBucketer:
         for i in range(n):
             self.bucket_of[i] = len(self.ranges)
             cur = ends[i]
-            if (cur - lo) * flat.element_size() >= bucket_bytes or i == n - 1:
+            if (cur - lo) * flat.element_size() >= (first_bucket_bytes if not self.ranges else bucket_bytes) or i == n - 1:
                 self.ranges.append((lo, cur))
                 lo = cur
         self.members = [0] * len(self.ranges)

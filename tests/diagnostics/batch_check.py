@@ -8,10 +8,8 @@ from scanpaths_amd.models.baseline_attention import baseline
 from scanpaths_amd.procedural import fill_module, procedural_state_dict
 from scanpaths_amd.spec import model_spec
 from scanpaths_amd.synth import make_batch
-if os.environ.get("SP_SPLIT_SCHEME"):
-    F.SPLIT_SCHEME = os.environ["SP_SPLIT_SCHEME"]
-if os.environ.get("SP_NO_SPLIT"):
-    F.USE_BF16X3 = False
+from scanpaths_amd import config as _sp_config
+_sp_config.honour_env_for_tools()      # SP_SPLIT_SCHEME / SP_NO_SPLIT of the command line, through the switchboard's checks
 DEV = torch.device("cuda:0")
 T, B = 1, int(os.environ.get("B", 32))
 m = baseline(convLSTM_length=T, map_width=64, map_height=40); fill_module(m, 4); m = m.to(DEV).eval()

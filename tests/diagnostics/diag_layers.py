@@ -11,8 +11,8 @@ from oracle import scanpath_oracle as O
 from scanpaths_amd import functional as F
 
 name = sys.argv[1] if len(sys.argv) > 1 else "air_eval_T4"
-if os.environ.get("SP_SPLIT_SCHEME"):
-    F.SPLIT_SCHEME = os.environ["SP_SPLIT_SCHEME"]
+from scanpaths_amd import config as _sp_config
+_sp_config.honour_env_for_tools()      # SP_SPLIT_SCHEME / SP_NO_SPLIT of the command line, through the switchboard's checks
 training = "train" in name
 meta, g = load_golden(name)
 b = case_inputs(meta, torch.float32)

@@ -342,6 +342,9 @@ def test_tame_all_steps_meet_the_north_star_bar(name, backend):
           f"argmax exact on {nargmax}/{ntot} decisive positions, {nfull}/{ntot} of all")
     bad = [r for r in rows if r.get("failed")]
     assert not bad, bad[:3]
+    if meta["weight_family"] == "tame_sharp":          # logits of +-5.3: the north-star's 1e-4 as an ABSOLUTE bar on every logit of every step
+        worst_abs = max(r["err"] for r in rows if r["key"] in ("all_actions_prob", "actions"))
+        assert worst_abs <= 1e-4, worst_abs
     assert nargmax >= 0.5 * ntot, (nargmax, ntot)      # the argmax check must not be vacuous
 
 

@@ -8,6 +8,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from scanpaths_amd import config as _sp_config  # noqa: E402
+_sp_config.honour_env_for_tools()      # SP_LIBRARY=timing of the command line
 from scanpaths_amd import functional as F, hip  # noqa: E402
 
 dev = torch.device("cuda:0")

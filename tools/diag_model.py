@@ -8,10 +8,8 @@ from helpers import case_inputs, load_golden, max_err
 from test_model_gpu import _build, _call, DEV
 from scanpaths_amd.models.loss import supervised_loss
 from scanpaths_amd import functional as F
-if os.environ.get("SP_SPLIT_SCHEME"):
-    F.SPLIT_SCHEME = os.environ["SP_SPLIT_SCHEME"]
-if os.environ.get("SP_NO_SPLIT"):
-    F.USE_BF16X3 = False
+from scanpaths_amd import config as _sp_config
+_sp_config.honour_env_for_tools()      # SP_SPLIT_SCHEME / SP_NO_SPLIT of the command line, through the switchboard's checks
 
 def fwd(name):
     meta, g = load_golden(name)

@@ -9,6 +9,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import case_inputs, load_golden  # noqa: E402
+from scanpaths_amd import config as _sp_config  # noqa: E402
+_sp_config.honour_env_for_tools()      # the mode named on the command line (SP_SPLIT_SCHEME=f16x1), through the switchboard's checks
 from scanpaths_amd import functional as F  # noqa: E402
 from scanpaths_amd.models.scanpath_model import ScanpathModel  # noqa: E402
 from scanpaths_amd.procedural import fill_module  # noqa: E402
