@@ -425,6 +425,20 @@ int sp_drt_direct_bwd_weight_rows(const float* dDpre, const float* h, const int*
                                   int nheads, void* workspace, float* dW11, float* dcbsum, const int* row_last, int row_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Skinny fp32 GEMM (round 5): C[M <= 64][N] = relu?(alpha * A[M][K] * op(B) + bias[N]) on fp32 MFMA, the weight matrix streamed once
+ * by ~512 workgroups.  The dense layers the decode loop applies to a handful of rows per step -- spatial_embed / semantic_embed
+ * (nn.Linear, AiR/models/baseline_attention.py:207-208,279-286,319-326) and the contraction of the semantic memory with the rank-1 gate
+ * filters (:40-50) -- and their data gradients.  layout 0: B [N][ldb >= K] (C = A B^T; N % 16 == 0); layout 1: B [K][ldb >= N]
+ * (C = A B; N % 64 == 0, ldc % 4 == 0); K % 16 == 0, lda % 4 == 0, 16-byte aligned pointers.  workspace >= sp_gemm_skinny_workspace
+ * bytes (K slices, summed in slice order: bitwise reproducible).  sp_gemm_skinny_applies: 1 when the shape is supported (else the
+ * caller uses sp_conv_igemm).
+ * ---------------------------------------------------------------------------------------------- */
+int sp_gemm_skinny_applies(int M, int N, int K, int lda, int ldb, int ldc, int layout);
+int64_t sp_gemm_skinny_workspace(int M, int N, int K, int layout);
+int sp_gemm_skinny(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc, int layout,
+                   float alpha, int relu, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Loss (models/loss.py:10-14,27-32; AiR/train.py:192-197) -- value and gradient in one pass.
  * z [B][T][A] logits, gt soft one-hot, masks [B][T]; mask_sums = {sum(action_mask), sum(duration_mask)} on device
  * (all-reduced by the caller under data parallelism so the loss is normalised by the GLOBAL mask sums).

@@ -31,6 +31,21 @@ _KSPLIT_MIN_NKT, _KSPLIT_KT = 8, 4
 
 def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, KH=1, KW=1, stride=1, pad=0, dil=1,
            mode=0, alpha=1.0, beta=0, relu=0, nbatch=1, sX=0, sW=0, sC=0):
+    # a handful of rows against a large weight matrix (the dense layers of the decode loop and their data gradients): the skinny kernel
+    # streams the matrix once over ~512 workgroups (csrc/gemm_skinny.hip; 135-185 us per launch on the 128 x 128-tile kernel below)
+    M_ = N_img * Ho * Wo
+    if (SKINNY_GEMM and KH * KW == 1 and nbatch == 1 and M_ <= 64 and not beta and Hi == Ho and Wi == Wo and stride == 1 and pad == 0
+            and hip.lib().sp_gemm_skinny_applies(M_, Nout, Kc, ldx, ldw, ldc, int(mode))):
+        L = hip.lib()
+        ws = hip.workspace(L.sp_gemm_skinny_workspace(M_, Nout, Kc, int(mode)), X.device, slot=2)
+
+        def launch_sk():
+            check(L.sp_gemm_skinny(ptr(X), ptr(W), ptr(bias), ptr(out), M_, Nout, Kc, ldx, ldw, ldc, int(mode), float(alpha), int(relu),
+                                   ptr(ws), hip.stream()), "sp_gemm_skinny")
+        FUSION_COUNTS["skinny_gemm"] += 1
+        if hip.TIMER is None:
+            return launch_sk()
+        return hip.TIMER.bracket(("skinny_fwd" if mode == 0 else "skinny_dgrad", M_, Nout, Kc, "1x1", 1), 2.0 * M_ * Nout * Kc, launch_sk)
     # split-K when a pure GEMM has too few output tiles to fill 256 CUs (e.g. M = batch rows, K = 13824)
     ksplit, ws = 0, None
     if KH * KW == 1 and nbatch == 1:
@@ -86,7 +101,7 @@ def _apply_config():
                       ("LSTM_BWD_SPLIT", "lstm_bwd_split"), ("RANK1_DSP_SPLIT", "rank1_dsp_split"), ("RANK1_DWC_SPLIT", "rank1_dwc_split"),
                       ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
                       ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single"),
-                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad")):
+                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad"), ("SKINNY_GEMM", "skinny_gemm")):
         g[name] = bool(c[key])
 
 
@@ -97,7 +112,7 @@ _apply_config()
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
-                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0}
+                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0, "skinny_gemm": 0}
 
 
 # ---- parameter gradients written straight into the optimizer's flat gradient buffer -------------------------------------------------

@@ -161,6 +161,9 @@ SIGNATURES = {
     "sp_log_duration": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "sp_rowscale": (_I, [_P, _P, _I, _I, _P, _P]),
     "sp_rows_last": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "sp_gemm_skinny_applies": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "sp_gemm_skinny_workspace": (_L, [_I, _I, _I, _I]),
+    "sp_gemm_skinny": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "sp_scale_by": (_I, [_P, _P, _L, _P, _P]),
     "sp_sumsq_workspace": (_L, [_L]),
     "sp_sum": (_I, [_P, _L, _P, _P, _P]),

@@ -108,10 +108,14 @@ def test_stem_conv_7x7_s2_padded_channels():
 
 
 @pytest.mark.parametrize("layout", ["nk", "kn"])
-@pytest.mark.parametrize("shape", [(5, 1200, 1200), (64, 512, 512), (1, 512, 512), (130, 36, 260)])
+@pytest.mark.parametrize("shape", [(5, 1200, 1200), (64, 512, 512), (1, 512, 512), (130, 36, 260),
+                                   # the dense layers of the decode loop at the benchmark size (csrc/gemm_skinny.hip): spatial_embed,
+                                   # the rank-1 filter contraction and its data gradient's shape, a row count that is no multiple of 16
+                                   (64, 2560, 2560), (32, 512, 13824), (32, 13824, 512), (37, 528, 1216)])
 def test_gemm(layout, shape):
     from scanpaths_amd import functional as F
     M, K, N = shape
+    F.reset_fusion_counts()
     a = _rand(M, K, seed=8)
     b = _rand(N, K, seed=9) if layout == "nk" else _rand(K, N, seed=9)
     bias = _rand(N, seed=10)
@@ -128,6 +132,8 @@ def test_gemm(layout, shape):
     _close(ag.grad, ar.grad, tol, "da")
     _close(bg.grad, br.grad, tol, "db")
     _close(biasg.grad, biasr.grad, tol, "dbias")
+    if M <= 64 and K % 64 == 0 and N % 64 == 0:          # forward AND data gradient on the skinny kernel (one "nk", one "kn")
+        assert F.FUSION_COUNTS["skinny_gemm"] == 2, F.FUSION_COUNTS
 
 
 def test_gemm_batched_kn_relu():
