@@ -508,7 +508,7 @@ def main():
         # N = 2048, K = 4608; the deferred weight gradient hw2_kernel covers all T - 1 applications in one launch)
         hgate = (dom_key[2], dom_key[3]) == (2048, 4608) and dom_key[1] in (81920, 81920 * (args.T - 1))
         if args.batch == 32 and (args.height, args.width) == (320, 512) and kind in PMC_PREFIX and hgate:
-            for fn in ("r04_pmc_hconv.json", "r03_pmc_hconv.json", "r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
+            for fn in ("r05_pmc_hconv.json", "r04_pmc_hconv.json", "r03_pmc_hconv.json", "r02_pmc_hconv.json", "r01_pmc_hconv.json"):      # newest committed PMC passes first
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
                     keys = [k for k in pmc if k.startswith(PMC_PREFIX[kind])]
@@ -535,8 +535,9 @@ def main():
             "traffic_note": (f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{traffic_src}); "
                              "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.88 GB per application "
                              "(weight gradient: dY planes 671 MB + X planes 168 MB + dW 38 MB; the deferred hw2_kernel launch covers T - 1 "
-                             "applications: x (T - 1)) / 1.05 GB (forward; the ConvLSTM-fused forward also reads the x-gates and writes gates, "
-                             "c, h and h's split operand: 2.9 GB)") if traffic else "no committed PMC pass for this kernel/shape",
+                             "applications: x (T - 1)) / 1.05 GB (forward; the ConvLSTM-fused forward also reads the x-gates and c_prev and writes gates, "
+                             "c, h and h's split operand: 2.2 GB = reads 1.05 + writes 1.15; the round-5 epilogue moves them as 64-byte runs "
+                             "per (pixel, gate): fabric-side reads 3.75 GB, writes 1.20 GB)") if traffic else "no committed PMC pass for this kernel/shape",
             "kernel": f"{KERNEL_NAMES.get(kind, kind)}: implicit GEMM M={M} N={N} K={K} ({dom_key[4]} taps) -- the timed GEMM "
                       "kind+shape with the largest total time",
             "achieved_note": "ALGORITHMIC FLOPs (2*M*N*K of the fp32 GEMM the reference computes) / HIP-event launch time on the "
