@@ -47,7 +47,7 @@ def pytest_collection_finish(session):
     items[:] = [it for it in items if it not in late] + late
     if len(items) > 1:                         # (a run of this test alone starts its workers itself)
         from helpers import start_bench_oracle
-        session.config._bench_oracle = start_bench_oracle()
+        session.config._bench_oracle = start_bench_oracle(background=True)
 
 
 def pytest_sessionfinish(session, exitstatus):
