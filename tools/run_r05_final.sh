@@ -1,22 +1,24 @@
 #!/bin/bash
-# Round-4 artifact run (GPU box, repo root): full -m gpu suite, bench lines (headline, dense backward, RCCL world of one), kernel trace,
-# backbone bench, the other BASELINE configurations, gradient-error table, example.  PMC passes: tools/run_r04_pmc.sh.
-O=gpurun_out/r04final3
+# Round-5 artifact run (GPU box, repo root): full -m gpu suite, bench lines (headline with its dense / drop-in legs, --dropin as the line,
+# dense backward, RCCL world of one), kernel trace + gap analysis, backbone bench, the other BASELINE configurations, example.
+# PMC passes: tools/run_r05_pmc.sh; epilogue probes: tools/run_r05_fused.sh.
+O=gpurun_out/r05final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_nocpu.json 2> $O/bench_nocpu.err
-python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --dense-backward > $O/bench_dense.json 2> $O/bench_dense.err
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --dropin > $O/bench_dropin.json 2> $O/bench_dropin.err
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --dense-backward --no-dropin-leg > $O/bench_dense.json 2> $O/bench_dense.err
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --force-bucketer > $O/bench_bucketer.json 2> $O/bench_bucketer.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-leg > $O/bench_prof.json 2> $O/bench_prof.err
-f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summarize_prof.py "${f%_kernel_trace.csv}" $O/r04 > $O/summ_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-leg --no-dropin-leg > $O/bench_prof.json 2> $O/bench_prof.err
+f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summarize_prof.py "${f%_kernel_trace.csv}" $O/r05 > $O/summ_bench.log 2>&1
+python3 tools/trace_gaps.py "$f" > $O/gaps.log 2>&1
 find $O -name "*trace.csv" -delete
 python3 tools/bench_backbone.py > $O/backbone.json 2> $O/backbone.err
 python3 bench.py --steps 10 --warmup 3 --height 240 --width 320 --no-cpu-baseline > $O/bench_240x320.json 2> $O/bench_240x320.err
 python3 bench.py --steps 10 --warmup 3 --task osie --arch resnet18 --T 8 --batch 4 --height 240 --width 320 > $O/bench_osie_r18.json 2> $O/bench_osie_r18.err
 python3 bench.py --steps 10 --warmup 3 --task coco --batch 16 --T 6 --no-cpu-baseline > $O/bench_coco_b16.json 2> $O/bench_coco_b16.err
 python3 bench.py --steps 5 --warmup 2 --mode infer --batch 128 > $O/bench_infer128.json 2> $O/bench_infer128.err
-NROWS=12 CONFIGS=bench_path,bf16x3,fp32 python3 tests/diagnostics/grad_error_table.py 16 > $O/grad_error_table_T16.log 2>&1
 python3 examples/train_synthetic.py > $O/example.log 2>&1; echo "example rc=$?" >> $O/example.log
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 tail -n 4 $O/pytest.log; tail -n 3 $O/example.log; cut -c1-300 $O/backbone.json; cut -c1-260 $O/bench.json
