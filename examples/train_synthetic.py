@@ -19,7 +19,7 @@ from scanpaths_amd.models.sampling import Sampling                              
 from scanpaths_amd.optim import FlatAdam                                          # noqa: E402
 from scanpaths_amd.opts import parse_opt                                          # noqa: E402
 from scanpaths_amd.procedural import fill_module                                  # noqa: E402
-from scanpaths_amd.rl import rl_step                                              # noqa: E402
+from scanpaths_amd.rl import rl_step, rl_step_single_head                         # noqa: E402
 from scanpaths_amd.synth import make_batch                                        # noqa: E402
 from scanpaths_amd.utils.evaltools.scanmatch import ScanMatch                     # noqa: E402
 
@@ -102,6 +102,25 @@ def main():
         for i in range(a.batch):
             rows.append(sm_wd.match_all([ms(f) for f in gt[i]], [ms(fix[i])]).mean())
     print(f"validation: mean ScanMatch (with duration) of sampled vs human scanpaths {float(np.nanmean(rows)):.4f} over {len(rows)} samples")
+
+    # ---- the single-head tasks: one OSIE RL iteration and its validation table (OSIE/train.py:197-262, OSIE/utils/evaluation.py:151-282) ----
+    from scanpaths_amd.models.baseline_attention import baseline_osie
+    from scanpaths_amd.utils.evaluation_osie import evaluation
+    osie = baseline_osie(convLSTM_length=T, arch="resnet18")
+    fill_module(osie, seed=1)
+    osie = osie.to(dev)
+    opt2 = FlatAdam(osie.parameters(), lr=args.lr, weight_decay=5e-4, clip=args.clip)
+    samp2 = Sampling(convLSTM_length=T, min_length=3, map_width=args.map_width, map_height=args.map_height, width=args.width, height=args.height)
+    images = make_batch("OSIE", a.batch, args.height, args.width, T, seed=7)["images"].to(dev)
+    gt, _ = human_scanpaths(g, a.batch)
+    loss, info = rl_step_single_head(osie, samp2, opt2, images, gt, sm_wd, sm_wod, "OSIE", rl_sample_number=2)
+    print(f"OSIE rl iter: loss {float(loss):.5f}  reward hmean {float(info['reward_hmean'].mean()):.4f}  grad norm {float(info['grad_norm']):.3f}")
+    with torch.no_grad():
+        p = osie(images)
+    s = samp2.random_sample(p["all_actions_prob"], p["log_normal_mu"], p["log_normal_sigma2"])
+    fix, _, _ = samp2.generate_scanpath(images, s["selected_actions_probs"], s["durations"], s["selected_actions"])
+    cur, _, _ = evaluation(gt, fix)
+    print("OSIE validation:", {k: {m: round(float(v), 4) for m, v in d.items()} for k, d in cur.items()})
 
 
 if __name__ == "__main__":

@@ -66,7 +66,11 @@ class FlatAdam(torch.optim.Optimizer):
         received no gradient in THIS backward is skipped (no decay, no moment update, no step increment);
       * ``zero_grad(set_to_none=False)`` (the only behaviour of the reference's pinned torch==1.6.0, sp_baseline.yml:116):
         gradients are zeroed, not dropped, so a parameter that has EVER received a gradient keeps being decayed and
-        momentum-stepped with a zero gradient (a COCO head whose category is absent from later batches)."""
+        momentum-stepped with a zero gradient (a COCO head whose category is absent from later batches).
+    After a backward pass that ABORTS (an exception in a hook, out of memory, a non-finite-loss "skip this batch"): call
+    ``zero_grad()`` before the next backward -- it drains the bucketed all-reduces in flight and resets the bookkeeping of the gradients
+    that were written straight into the flat buffer (functional._take_grad_view); a parameter with a user tensor hook
+    (``p.register_hook``) always takes autograd's ordinary path, so the hook sees its gradient."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  clip: float = 0.0, process_group=None, conditional_params: bool = False, bucket_mb: float = 32.0,

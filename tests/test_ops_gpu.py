@@ -1187,3 +1187,40 @@ def test_fused_gateconv_lstm_at_benchmark_size_vs_fp64():
         pass
     for k in res:
         assert res[k][0] <= 1e-6 and res[k][1] <= 8e-6, (k, res[k])
+
+
+def test_rows_last_reads_the_horizon_off_the_output_gradients():
+    """sp_rows_last (functional._OutputGate): last[b] = the last decode step at which ANY element of ANY output gradient of sample b
+    is non-zero -- over both stacked heads, rows of different widths ([.., A] logits, scalar mu / sigma2, [.., P] action maps), with
+    NaN counting as non-zero, -0.0 as zero, a gradient that never arrived (None) as zero, and -1 for a sample without any.  The
+    reference multiplies the zeros these rows imply (AiR/models/loss.py:10-14,27-32); the gate lets the backward kernels skip them."""
+    from scanpaths_amd import functional as F
+    dev = _dev()
+    nst, B, T, A, P = 2, 7, 6, 37, 24
+    g = np.random.Generator(np.random.PCG64(5))
+    z = torch.zeros(nst, B, T, A)
+    mu = torch.zeros(nst, B, T)
+    s2 = torch.zeros(nst, B, T)
+    am = torch.zeros(nst, B, T, P)
+    want = [-1] * B
+    z[1, 0, 2, 36] = 1e-30; want[0] = 2                        # a single tiny element of the second head, last column
+    mu[0, 1, 5] = -2.0; z[0, 1, 1, 0] = 3.0; want[1] = 5       # the scalar output decides
+    am[1, 2, 0, 7] = float("nan"); want[2] = 0                 # NaN is a non-zero gradient
+    z[0, 3, 4, 3] = -0.0; s2[1, 3, 3] = 1.0; want[3] = 3       # -0.0 is zero
+    z[:, 4] = torch.from_numpy(g.standard_normal((nst, T, A)).astype(np.float32)); want[4] = T - 1
+    am[0, 6, 4, 23] = 5.0; want[6] = 4                         # sample 5: nothing at all
+    tok = F.DecodeRows()
+    outs = [t.to(dev).requires_grad_(True) for t in (z * 0, am * 0, mu * 0, s2 * 0)]
+    gated = F.output_gate(tok, outs)
+    torch.autograd.backward([gated[0], gated[1], gated[2], gated[3]], [z.to(dev), am.to(dev), mu.to(dev), s2.to(dev)])
+    assert tok.rc.last.tolist() == want, (tok.rc.last.tolist(), want)
+    for o, ref in zip(outs, (z, am, mu, s2)):                  # the gate is an identity for the gradients themselves
+        assert torch.equal(torch.nan_to_num(o.grad.cpu(), nan=7.0), torch.nan_to_num(ref, nan=7.0))
+    # a gradient that never arrived: only the action maps are consumed (None for the other three)
+    tok2 = F.DecodeRows()
+    outs2 = [t.to(dev).requires_grad_(True) for t in (z * 0, am * 0, mu * 0, s2 * 0)]
+    g2 = F.output_gate(tok2, outs2)
+    am2 = torch.zeros(nst, B, T, P)
+    am2[0, 5, 2, 0] = 1.0
+    (g2[1] * am2.to(dev)).sum().backward()
+    assert tok2.rc.last.tolist() == [-1, -1, -1, -1, -1, 2, -1] and outs2[0].grad is None
