@@ -101,7 +101,7 @@ def _apply_config():
                       ("LSTM_BWD_SPLIT", "lstm_bwd_split"), ("RANK1_DSP_SPLIT", "rank1_dsp_split"), ("RANK1_DWC_SPLIT", "rank1_dwc_split"),
                       ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
                       ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single"),
-                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad"), ("SKINNY_GEMM", "skinny_gemm")):
+                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad"), ("SKINNY_GEMM", "skinny_gemm"), ("ASYNC_DGRAD", "async_dgrad")):
         g[name] = bool(c[key])
 
 
@@ -112,7 +112,7 @@ _apply_config()
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
-                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0, "skinny_gemm": 0}
+                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0, "skinny_gemm": 0, "async_dgrad": 0}
 
 
 # ---- parameter gradients written straight into the optimizer's flat gradient buffer -------------------------------------------------
@@ -622,20 +622,27 @@ class _FanOut(Function):
     identity autograd does not guarantee (a hook that returns a new tensor, an accumulation, a cloning wrapper: ADVICE r3) -- and
     raises if a recorded contribution's gradient never arrived or arrives marked as unwritten without a record."""
     @staticmethod
-    def forward(ctx, x, n, token, step=None):
-        ctx.n, ctx.token, ctx.step = n, token, step
+    def forward(ctx, x, n, token, step=None, events=None):
+        ctx.n, ctx.token, ctx.step, ctx.events = n, token, step, events
         ctx.set_materialize_grads(False)      # an alias nobody consumed contributes None, not a full-size zero tensor to sum
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
+        if ctx.events:
+            # a contribution that was computed on the side stream (the h-gate conv's data gradient, _GateConvLstm.backward): this fan-in is
+            # its first reader -- the current stream waits here, after everything that did not depend on it has been enqueued
+            cur = torch.cuda.current_stream()
+            for ev in ctx.events.values():
+                cur.wait_event(ev)
+            ctx.events.clear()
         tok = ctx.token if ctx.token is not None else {}
         for i in tok:
             if grads[i] is None:
                 raise RuntimeError(f"scanpaths_amd: fan-out alias {i} recorded a split-only gradient but no gradient arrived for it")
         idx = [i for i, g in enumerate(grads) if g is not None]
         if not idx:
-            return None, None, None, None
+            return None, None, None, None, None
         for i in idx:
             if i not in tok and getattr(grads[i], "_sp_skipped", False):
                 raise RuntimeError("scanpaths_amd: a gradient whose fp32 form was left unwritten reached a fan-in without its record")
@@ -658,16 +665,16 @@ class _FanOut(Function):
                                                 rc.B if rc else 0, hip.stream()), "sp_sum_n_mixed_rows")
             if hint is not None:
                 out._sp_amax = hint
-            return out, None, None, None
+            return out, None, None, None, None
         if len(gs) == 1:
-            return gs[0], None, None, None
+            return gs[0], None, None, None, None
         out = torch.empty_like(gs[0])
         n = out.numel()
         if n % 4 or len(gs) > 32:
             acc = gs[0]
             for g in gs[1:]:
                 acc = _add_raw(acc, g)
-            return acc, None, None, None
+            return acc, None, None, None, None
         arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
         hint = _amax_hint(out.device)          # max|sum|: the LSTM cell's backward bounds its split operand with it
         # masked-step sparsity: every term of a tensor that lives at decode step ctx.step (h_t: the two heads' and the next step's
@@ -693,7 +700,7 @@ class _FanOut(Function):
             check(hip.lib().sp_sum_n(arr, len(gs), n, ptr(out), _hint_ptr(hint), hip.stream()), "sp_sum_n")
         if hint is not None:
             out._sp_amax = hint
-        return out, None, None, None
+        return out, None, None, None, None
 
 
 def fanout(x: torch.Tensor, n: int, step=None):
@@ -702,7 +709,11 @@ def fanout(x: torch.Tensor, n: int, step=None):
     their last loss step contribute exact zeros that the fan-in does not read."""
     split_ok = x.numel() % 16 == 0 and n <= 32
     token = {} if split_ok else None
-    outs = _FanOut.apply(x, n, token, step)
+    events = {} if (ASYNC_DGRAD and step is not None and x.is_cuda) else None
+    outs = _FanOut.apply(x, n, token, step, events)
+    if events is not None:
+        for i, o in enumerate(outs):
+            o._sp_fan_ev = (events, i)      # a consumer may compute its gradient on another stream and leave its completion event here
     for attr in ("_sp_cache", "_sp_amax"):
         v = getattr(x, attr, None)
         if v is not None:
@@ -1739,6 +1750,7 @@ class _GateConvLstm(Function):
         # the gate gradient dpre of this step has three consumers: xg's fan-in, the h-gate conv's data and weight gradient.  When all
         # of them read its split form, its fp32 form is never written (_lstm_rank1_backward skip_fp32)
         ctx.fan = getattr(xg, "_sp_fan", None)
+        ctx.h_events = getattr(h_prev, "_sp_fan_ev", None)      # (events dict of h_prev's fan-out, this consumer's index) or None
         ctx.skip_ok = (ctx.fan is not None and _scheme_for(Co) == "f16x2"
                        and (not ctx.needs_input_grad[0] or _b3_pays(N * P, Ci, KH * KW * Co, Co, a_elems=xg.numel(), free_a=True))
                        and (not ctx.needs_input_grad[1] or (keep and _wgrad_scheme(Ci, Co) == "f16x2")))
@@ -1751,6 +1763,31 @@ class _GateConvLstm(Function):
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[4],
                                                    ctx.needs_input_grad[5], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan, step=ctx.step)
         xs = SplitOperand(xs_buf, xs_scale, *ctx.xs_scheme) if xs_buf is not None else None
+        if (ASYNC_DGRAD and ctx.h_events is not None and ctx.needs_input_grad[0] and dpre.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            # The data gradient of the h-gate conv (1.5 TFLOP, 1.3-3.3 ms) has ONE reader, the fan-in of h_{t-1}'s three gradients; the
+            # other results of this node (gradients of the spatial taps and of the contracted filters) feed ~25 small launches -- the
+            # backward of the memory update and of step t - 1's heads, 1.2 ms that cannot fill the chip -- whose results meet the data
+            # gradient only in that same fan-in.  So the GEMM goes to the side stream (it waits for everything enqueued so far: dpre's
+            # planes) and the current stream carries on with the small launches; the fan-in waits for the event left in its `events`.
+            # The weight gradient stays on the current stream: recorded (deferred to one launch over all applications, issued by the
+            # application that runs last in backward) or computed -- it reads what the forward and the cell backwards wrote.
+            main, side = torch.cuda.current_stream(), hip.side_stream(dpre.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                dhp, _ = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, True, False, step=ctx.step)
+                done = torch.cuda.Event()
+                done.record(side)
+            dhp.record_stream(main)                      # allocated under the side stream, read (and freed) on the current one
+            events, idx = ctx.h_events
+            events[idx] = done
+            FUSION_COUNTS["async_dgrad"] += 1
+            dw = None
+            if ctx.needs_input_grad[1]:
+                _, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, False, True, defer_final=ctx.defer_final, step=ctx.step)
+            return dhp, dw, dpre, dcp, dsp, dwc, None, None
         dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                  defer_final=ctx.defer_final, step=ctx.step)
         return dhp, dw, dpre, dcp, dsp, dwc, None, None

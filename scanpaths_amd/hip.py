@@ -234,7 +234,13 @@ def side_stream(device) -> "torch.cuda.Stream":
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _side.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=device)
+        # lowest priority the device offers (this pool's MI355X boxes: range (0, -1), i.e. normal): the side stream carries ONE long GEMM
+        # beside the current stream's chain of small launches (A/B of normal vs high: 233.5 / 233.7 vs 233.6 / 234.6 ms per step)
+        try:
+            lo = max(torch.cuda.Stream.priority_range())
+        except Exception:
+            lo = 0
+        s = torch.cuda.Stream(device=device, priority=lo)
         _side[key] = s
     return s
 
@@ -243,11 +249,12 @@ _ws = {}
 
 
 def workspace(nbytes: int, device, slot: int = 0) -> Optional[torch.Tensor]:
-    """Grow-only scratch buffer per (device, slot); safe because every kernel of a process is enqueued in
-    stream order and a slot is consumed by the launch that requested it before the next request."""
+    """Grow-only scratch buffer per (device, stream, slot); safe because the kernels of one stream run in order and a slot is consumed by
+    the launch that requested it before the next request on that stream (round 5: one data gradient per decode step runs on the side
+    stream beside the current one -- each stream has its own scratch)."""
     if nbytes <= 0:
         return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, slot)
     cur = _ws.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -820,6 +820,41 @@ def test_a_second_consumer_of_the_predictions_makes_the_backward_dense_because_t
     _assert_same_grads(grads[0], grads[1])
 
 
+@pytest.mark.parametrize("task", ["AiR", "COCO_Search18"])
+def test_data_gradient_on_the_side_stream_is_bit_identical_to_the_serial_backward(task, monkeypatch):
+    """config async_dgrad (round 5): the h-gate conv's data gradient of decode step t runs on the side stream beside the ~25 small
+    launches of the memory update's and of step t - 1's heads' backward; its only reader, the fan-in of h_{t-1}'s gradients, waits for the
+    event the node left in the fan-out's `events`.  Same kernels, same operands: loss and every parameter gradient must equal the serial
+    backward (async_dgrad off) bit for bit -- three repetitions (a missing wait or a buffer handed out too early shows as a difference in
+    some run), sparse and dense row contexts, on the benchmark's kernel path (40x64 map, fused cell, deferred hw2 launch).
+    Reference semantics: plain autograd of AiR/models/baseline_attention.py:37-56, 303-336."""
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.models.loss import supervised_loss
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3 or F.THROUGHPUT_MODE:
+        pytest.skip("2xfp16 back-end not active")
+    T = 8
+    meta, b = _sparsity_case(task, T=T)
+    monkeypatch.setattr(F, "COST_M_SCALE", 32.0 / 5)
+    ref = None
+    for sparse in (True, False):
+        monkeypatch.setattr(F, "ROW_SPARSITY", sparse)
+        for rep, use_async in enumerate((False, True, True, True)):
+            monkeypatch.setattr(F, "ASYNC_DGRAD", use_async)
+            model = _build(meta, 40, 64).train()
+            F.reset_fusion_counts()
+            pred = _call(model, meta, b)
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+            loss.backward()
+            torch.cuda.synchronize()
+            assert F.FUSION_COUNTS["async_dgrad"] == (T - 1 if use_async else 0), F.FUSION_COUNTS
+            got = (float(loss), _grads(model))
+            if not use_async:
+                ref = got
+            else:
+                assert got[0] == ref[0]
+                _assert_same_grads(got[1], ref[1])
+
+
 def test_state_dict_roundtrip_and_no_cpu_path():
     from scanpaths_amd.models.baseline_attention import baseline
     m = baseline(convLSTM_length=2)
