@@ -429,7 +429,8 @@ int sp_drt_direct_bwd_weight_rows(const float* dDpre, const float* h, const int*
  * by ~512 workgroups.  The dense layers the decode loop applies to a handful of rows per step -- spatial_embed / semantic_embed
  * (nn.Linear, AiR/models/baseline_attention.py:207-208,279-286,319-326) and the contraction of the semantic memory with the rank-1 gate
  * filters (:40-50) -- and their data gradients.  layout 0: B [N][ldb >= K] (C = A B^T; N % 16 == 0); layout 1: B [K][ldb >= N]
- * (C = A B; N % 64 == 0, ldc % 4 == 0); K % 16 == 0, lda % 4 == 0, 16-byte aligned pointers.  workspace >= sp_gemm_skinny_workspace
+ * (C = A B; N % 64 == 0, ldc % 4 == 0); K % 16 == 0, lda % 4 == 0; A, B and the workspace 16-byte aligned, C and bias too
+ * for layout 1 and whenever K slices are used (the callers' Python side falls back to sp_conv_igemm otherwise).  workspace >= sp_gemm_skinny_workspace
  * bytes (K slices, summed in slice order: bitwise reproducible).  sp_gemm_skinny_applies: 1 when the shape is supported (else the
  * caller uses sp_conv_igemm).
  * ---------------------------------------------------------------------------------------------- */

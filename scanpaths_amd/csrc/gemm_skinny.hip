@@ -187,7 +187,8 @@ extern "C" int sp_gemm_skinny(const float* A, const float* B, const float* bias,
                               int layout, float alpha, int relu, void* workspace, void* stream) {
     if (!A || !B || !C) return SP_ENULL;
     if ((layout != 0 && layout != 1) || !sk_applies(M, N, K, lda, ldb, ldc, layout)) return SP_EINVAL;
-    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)workspace) & 15) return SP_EINVAL;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)workspace) & 15) return SP_EINVAL;
+    if (layout == 1 && (((uintptr_t)C | (uintptr_t)bias) & 15)) return SP_EINVAL;      // float4 stores / bias loads ("nk" touches them by element)
     SkArgs a;
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.part = (float*)workspace;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -195,6 +196,7 @@ extern "C" int sp_gemm_skinny(const float* A, const float* B, const float* bias,
     int cw;
     sk_plan(N, K, layout, cw, a.nsplit, a.kchunk);
     if (a.nsplit > 1 && !workspace) return SP_ENULL;
+    if (a.nsplit > 1 && ((((uintptr_t)C | (uintptr_t)bias) & 15) || ldc % 4)) return SP_EINVAL;      // the slice reduce moves float4
     hipStream_t s = (hipStream_t)stream;
     if (layout == 0) hipLaunchKernelGGL(skinny_kernel<0>, dim3((unsigned)cw, (unsigned)a.nsplit), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(skinny_kernel<1>, dim3((unsigned)cw, (unsigned)a.nsplit), dim3(256), 0, s, a);

@@ -34,8 +34,9 @@ def _igemm(X, W, bias, out, *, N_img, Hi, Wi, Kc, ldx, Ho, Wo, Nout, ldc, ldw, K
     # a handful of rows against a large weight matrix (the dense layers of the decode loop and their data gradients): the skinny kernel
     # streams the matrix once over ~512 workgroups (csrc/gemm_skinny.hip; 135-185 us per launch on the 128 x 128-tile kernel below)
     M_ = N_img * Ho * Wo
+    aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (X, W, out, bias))
     if (SKINNY_GEMM and KH * KW == 1 and nbatch == 1 and M_ <= 64 and not beta and Hi == Ho and Wi == Wo and stride == 1 and pad == 0
-            and hip.lib().sp_gemm_skinny_applies(M_, Nout, Kc, ldx, ldw, ldc, int(mode))):
+            and aligned and ldc % 4 == 0 and hip.lib().sp_gemm_skinny_applies(M_, Nout, Kc, ldx, ldw, ldc, int(mode))):
         L = hip.lib()
         ws = hip.workspace(L.sp_gemm_skinny_workspace(M_, Nout, Kc, int(mode)), X.device, slot=2)
 
