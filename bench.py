@@ -536,8 +536,8 @@ def main():
                              "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.88 GB per application "
                              "(weight gradient: dY planes 671 MB + X planes 168 MB + dW 38 MB; the deferred hw2_kernel launch covers T - 1 "
                              "applications: x (T - 1)) / 1.05 GB (forward; the ConvLSTM-fused forward also reads the x-gates and c_prev and writes gates, "
-                             "c, h and h's split operand: 2.2 GB = reads 1.05 + writes 1.15; measured fabric-side reads 3.06 GB -- the K loop's operand "
-                             "re-reads beyond L2, 2.2 GB, plus the epilogue's 0.86 GB, whose 64-byte-run loads FETCH_SIZE tallies at ~0.85 of "
+                             "c, h and h's split operand: 2.2 GB = reads 1.05 + writes 1.15; measured fabric-side reads 3.04 GB -- the K loop's operand "
+                             "re-reads beyond L2, 2.2 GB, plus the epilogue's 0.84 GB, whose 64-byte-run loads FETCH_SIZE tallies at ~0.85 of "
                              "their bytes instead of 1/2: calibrated with and without them, profiles/r05_fetch_calibration.log -- writes 1.20 GB)") if traffic else "no committed PMC pass for this kernel/shape",
             "kernel": f"{KERNEL_NAMES.get(kind, kind)}: implicit GEMM M={M} N={N} K={K} ({dom_key[4]} taps) -- the timed GEMM "
                       "kind+shape with the largest total time",
