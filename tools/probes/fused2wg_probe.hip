@@ -1,0 +1,453 @@
+// Probe (round 5, VERDICT r4 "next" #2): would TWO resident 4-wave workgroups per CU on 128x128 tiles hide the fused-cell forward's
+// epilogue (0.55-0.6 ms of its 3.6 ms: 160 KB loaded and 224 KB stored per 256x128 tile with the matrix pipe idle, profiles/
+// r05_fused_epilogue_probe.log) behind the other workgroup's K loop -- and what does the smaller tile cost the K loop?
+//   A  one 8-wave workgroup per CU, 256x128 tile, 3-stage ring, ping-pong halves (= h2_kernel's structure; LOADS 6: 4 + 2 LDS-DMA pieces
+//      per lane and K-tile = the ring without halo blocks; LOADS 2: the halo build's steady state)
+//   B  two 4-wave workgroups per CU (launch bounds (256, 2), 64 KB of LDS each), 128x128 tile, 2-stage ring, 4 + 4 pieces per lane and
+//      K-tile, every wave: read fragments -> issue K-tile t + 1 -> 48 MFMAs -> wait -> barrier
+// Both: wave tile 64x64, two-level accumulation, v_mfma_f32_16x16x32_f16 x 3 products, random fp16 operands streamed from a 64 MiB
+// buffer (L2 / MALL resident), EPI 0: no epilogue, EPI 1: the cell epilogue's memory side and gate math as the shipped kernel issues them
+// (per lane 16 + 4 float4 loads, 24 float4 + 8 8-byte stores, 3 sigmoid + 1 tanh per element).  Grid = the h-gate conv's forward launch
+// (M = 81920, N = 2048, K = 4608: 5120 / 10240 tiles x 144 K-tiles).
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/fused2wg_probe.hip -o tools/probes/fused2wg_probe.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__device__ __forceinline__ float sig(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tnh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+struct Epi {
+    const float* xg;      // [M][4][C]
+    const float* cprev;   // [M][C]
+    float* gates;         // [M][4][C]
+    float* c;
+    float* h;
+    uint16_t* planes;     // [M][C/16][2][16]
+    int C;
+};
+
+__device__ __forceinline__ void fill_lds(unsigned char* smem, int bytes, int nthreads) {
+    for (int i = threadIdx.x; i < bytes / 4; i += nthreads) {
+        uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        reinterpret_cast<uint32_t*>(smem)[i] = (h & 0x8fff8fffu) | 0x30003000u;
+    }
+    __syncthreads();
+}
+
+// the shipped epilogue's traffic and math for a wave's 64 pixels x (4 gates x 16 channels): lane = (pixel l16 of row tile i, channel group g4)
+__device__ __forceinline__ void cell_epilogue(const Epi& e, f32x4 (&tot)[4][4], int64_t row0, int ch0, int l16, int g4) {
+    const int C = e.C, chb = ch0 + 4 * g4;
+    float4 xv[4][4], cp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = row0 + 16 * i + l16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const float4*>(e.xg + m * 4 * C + q * C + chb);
+        cp[i] = *reinterpret_cast<const float4*>(e.cprev + m * C + chb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = row0 + 16 * i + l16;
+        float4 gi, gf, go, gg, cn, hn;
+#define CELL(E, R) gi.E = sig(tot[i][0][R] + xv[i][0].E); gf.E = sig(tot[i][1][R] + xv[i][1].E); go.E = sig(tot[i][2][R] + xv[i][2].E); \
+                   gg.E = tnh(tot[i][3][R] + xv[i][3].E); cn.E = gf.E * cp[i].E + gi.E * gg.E; hn.E = go.E * cn.E;
+        CELL(x, 0) CELL(y, 1) CELL(z, 2) CELL(w, 3)
+#undef CELL
+        float* gp = e.gates + m * 4 * C + chb;
+        *reinterpret_cast<float4*>(gp) = gi;
+        *reinterpret_cast<float4*>(gp + C) = gf;
+        *reinterpret_cast<float4*>(gp + 2 * C) = go;
+        *reinterpret_cast<float4*>(gp + 3 * C) = gg;
+        *reinterpret_cast<float4*>(e.c + m * C + chb) = cn;
+        *reinterpret_cast<float4*>(e.h + m * C + chb) = hn;
+        ushort4 pa, pb;
+        pa.x = (uint16_t)__float_as_uint(hn.x); pa.y = (uint16_t)__float_as_uint(hn.y); pa.z = (uint16_t)__float_as_uint(hn.z); pa.w = (uint16_t)__float_as_uint(hn.w);
+        pb.x = (uint16_t)(__float_as_uint(hn.x) >> 16); pb.y = (uint16_t)(__float_as_uint(hn.y) >> 16); pb.z = (uint16_t)(__float_as_uint(hn.z) >> 16); pb.w = (uint16_t)(__float_as_uint(hn.w) >> 16);
+        uint16_t* grp = e.planes + ((m * C + chb) >> 4) * 32 + (chb & 15);
+        *reinterpret_cast<ushort4*>(grp) = pa;
+        *reinterpret_cast<ushort4*>(grp + 16) = pb;
+    }
+}
+
+// ---- A: 8 waves, 256x128, 3-stage ring, ping-pong ---------------------------------------------------------------------------------
+constexpr int A_HA = 256 * 128, A_HB = 128 * 128, A_STAGE = A_HA + A_HB;
+template <int LOADS, int EPI>
+__global__ __launch_bounds__(512, 2) void probeA(Epi e, float* sink, int nkt, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_lds(smem, 3 * A_STAGE, 512);
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    uint32_t gpos = (uint32_t)blockIdx.x * 1572864u;
+    auto issue = [&](int stage_) {
+        unsigned char* st = smem + stage_ * A_STAGE;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) GLDS16(src + ((gpos + j * 8192u + lane_off) & srcmask), st + j * 8192 + lane_off);
+        gpos += 49152u;
+    };
+    auto wait_loads = [&](bool more) {
+        if (more) {
+            if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (LOADS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, g4 = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = A_HA + (wn * 64 + l16) * 128 + pos * 16;
+    }
+    f32x4 acc[4][4], tot[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    f16x8 af[4][2], bf[4][2];
+    auto rd = [&](int stage) {
+        const unsigned char* st = smem + stage * A_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + i * 16 * 128);
+                bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + i * 16 * 128);
+            }
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][1], af[i][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    auto fold = [&](int kt) {
+        if ((kt & 7) == 7)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; }
+    };
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_setprio(1);
+    int stage = 0;
+    auto prev = [](int st_) { return st_ == 0 ? 2 : st_ - 1; };
+    issue(0); issue(1); wait_loads(true); __builtin_amdgcn_s_barrier();
+    if (!late) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            rd(stage);
+            if (kt + 2 < nkt) issue(prev(stage));
+            mm(); fold(kt);
+            wait_loads(kt + 2 < nkt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt > 0) { mm(); fold(kt - 1); }
+            rd(stage);
+            if (kt + 2 < nkt) issue(prev(stage));
+            wait_loads(kt + 2 < nkt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        mm(); fold(nkt - 1);
+    }
+    if (late) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[i][j] = (tot[i][j] + acc[i][j]) * 1e-6f;
+    if constexpr (EPI) {
+        const int tm = blockIdx.x >> 4, tn = blockIdx.x & 15;                  // 320 x 16 tiles of 256 pixels x 32 channels (x 4 gates)
+        cell_epilogue(e, tot, (int64_t)tm * 256 + wm * 64, tn * 32 + wn * 16, l16, g4);
+        return;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
+// ---- B: 4 waves, 128x128, 2-stage ring, two workgroups per CU ----------------------------------------------------------------------
+constexpr int B_HA = 128 * 128, B_STAGE = 2 * B_HA;      // 32 KB per stage
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void probeB(Epi e, float* sink, int nkt, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_lds(smem, 2 * B_STAGE, 256);
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    uint32_t gpos = (uint32_t)blockIdx.x * 786432u;
+    auto issue = [&](int stage_) {
+        unsigned char* st = smem + stage_ * B_STAGE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) GLDS16(src + ((gpos + j * 4096u + lane_off) & srcmask), st + j * 4096 + lane_off);
+        gpos += 32768u;
+    };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, g4 = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = B_HA + (wn * 64 + l16) * 128 + pos * 16;
+    }
+    f32x4 acc[4][4], tot[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    f16x8 af[4][2], bf[4][2];
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned char* st = smem + (kt & 1) * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + i * 16 * 128);
+                bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + i * 16 * 128);
+            }
+        if (kt + 1 < nkt) issue((kt + 1) & 1);      // the other stage: every wave read it before the barrier that ended K-tile kt - 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][1], af[i][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][0], acc[i][j], 0, 0, 0);
+            }
+        if ((kt & 7) == 7)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[i][j] = (tot[i][j] + acc[i][j]) * 1e-6f;
+    if constexpr (EPI) {
+        const int tm = blockIdx.x >> 4, tn = blockIdx.x & 15;                  // 640 x 16 tiles of 128 pixels x 32 channels (x 4 gates)
+        cell_epilogue(e, tot, (int64_t)tm * 128 + wm * 64, tn * 32 + wn * 16, l16, g4);
+        return;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
+// ---- C: as B with HALF K-tiles (64 B per row, 16 KB per stage) in a 4-stage ring: prefetch distance 3 half-tiles, 48 16x16x16 MFMAs per barrier --
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int C_HA = 128 * 64, C_STAGE = 2 * C_HA;       // 16 KB per stage
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void probeC(Epi e, float* sink, int nkt, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_lds(smem, 4 * C_STAGE, 256);
+    const int nht = 2 * nkt;
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    uint32_t gpos = (uint32_t)blockIdx.x * 786432u;
+    auto issue = [&](int stage_) {
+        unsigned char* st = smem + stage_ * C_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) GLDS16(src + ((gpos + j * 4096u + lane_off) & srcmask), st + j * 4096 + lane_off);
+        gpos += 16384u;
+    };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, g4 = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int pos = g4 ^ (l16 >> 2);
+    const int offA = (wm * 64 + l16) * 64 + pos * 16, offB = C_HA + (wn * 64 + l16) * 64 + pos * 16;
+    f32x4 acc[4][4], tot[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    f16x8 af[4], bf[4];
+    issue(0); issue(1); issue(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int ht = 0; ht < nht; ++ht) {
+        const unsigned char* st = smem + (ht & 3) * C_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const f16x8*>(st + offA + i * 16 * 64);
+            bf[i] = *reinterpret_cast<const f16x8*>(st + offB + i * 16 * 64);
+        }
+        if (ht + 3 < nht) issue((ht + 3) & 3);       // the stage every wave read before the barrier that ended half-tile ht - 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x4 ah = __builtin_shufflevector(af[i], af[i], 0, 1, 2, 3), al = __builtin_shufflevector(af[i], af[i], 4, 5, 6, 7);
+                const f16x4 bh = __builtin_shufflevector(bf[j], bf[j], 0, 1, 2, 3), bl = __builtin_shufflevector(bf[j], bf[j], 4, 5, 6, 7);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(bl, ah, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(bh, al, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(bh, ah, acc[i][j], 0, 0, 0);
+            }
+        if ((ht & 15) == 15)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; }
+        if (ht + 3 < nht) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[i][j] = (tot[i][j] + acc[i][j]) * 1e-6f;
+    if constexpr (EPI) {
+        const int tm = blockIdx.x >> 4, tn = blockIdx.x & 15;
+        cell_epilogue(e, tot, (int64_t)tm * 128 + wm * 64, tn * 32 + wn * 16, l16, g4);
+        return;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
+// ---- D: the halo form of the two-workgroup structure: 32 KB pixel region (one 4 KB piece per K-tile = the 33 KB halo block per 9 taps) +
+// a 3-stage ring of 16 KB weight tiles = 80 KB, exactly half a CU's LDS; prefetch distance 2 K-tiles as in A -------------------------------
+constexpr int D_PIX = 32768, D_W = 16384;
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void probeD(Epi e, float* sink, int nkt, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_lds(smem, D_PIX + 3 * D_W, 256);
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    uint32_t gpos = (uint32_t)blockIdx.x * 786432u;
+    auto issue = [&](int kt_) {
+        unsigned char* st = smem + D_PIX + (kt_ % 3) * D_W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) GLDS16(src + ((gpos + j * 4096u + lane_off) & srcmask), st + j * 4096 + lane_off);
+        GLDS16(src + ((gpos + 16384u + lane_off) & srcmask), smem + (kt_ & 7) * 4096 + lane_off);
+        gpos += 20480u;
+    };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, g4 = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = D_PIX + (wn * 64 + l16) * 128 + pos * 16;
+    }
+    f32x4 acc[4][4], tot[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    f16x8 af[4][2], bf[4][2];
+    issue(0); issue(1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int so = (kt % 3) * D_W, po = (kt & 1) * 16384;      // taps slide over the pixel region
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const f16x8*>(smem + po + offA[pl] + i * 16 * 128);
+                bf[i][pl] = *reinterpret_cast<const f16x8*>(smem + so + offB[pl] + i * 16 * 128);
+            }
+        if (kt + 2 < nkt) issue(kt + 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][1], af[i][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][0], acc[i][j], 0, 0, 0);
+            }
+        if ((kt & 7) == 7)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; }
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[i][j] = (tot[i][j] + acc[i][j]) * 1e-6f;
+    if constexpr (EPI) {
+        const int tm = blockIdx.x >> 4, tn = blockIdx.x & 15;
+        cell_epilogue(e, tot, (int64_t)tm * 128 + wm * 64, tn * 32 + wn * 16, l16, g4);
+        return;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
+__global__ void fill_src(uint32_t* p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (h & 0x8fff8fffu) | 0x30003000u;
+    }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+template <typename K>
+static int timeit(const char* name, K kern, dim3 grid, dim3 block, size_t lds, Epi e, float* sink, int nkt, const unsigned char* src, int reps) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL(kern, grid, block, lds, 0, e, sink, nkt, src, 0x3ffffffu);
+    CK(hipDeviceSynchronize());
+    float best = 1e9f, sum = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(kern, grid, block, lds, 0, e, sink, nkt, src, 0x3ffffffu);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best; sum += ms;
+    }
+    printf("%-52s grid %6u x %3u thr  mean %.3f ms  min %.3f ms\n", name, grid.x, block.x, sum / reps, best);
+    return 0;
+}
+
+int main() {
+    const int64_t M = 81920; const int C = 512, nkt = 144, reps = 30;
+    unsigned char* src; float* sink; Epi e; e.C = C;
+    CK(hipMalloc(&src, (64u << 20) + 65536));
+    hipLaunchKernelGGL(fill_src, dim3(2048), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(src), ((64u << 20) + 65536) / 4);   // random fp16 pairs:
+    CK(hipDeviceSynchronize());                              // constant operands lower the switching power and the clock rises (a 0.5 ms artefact)
+    CK(hipMalloc(&sink, 4096));
+    float *xg, *cp, *gates, *c, *h; uint16_t* planes;
+    CK(hipMalloc(&xg, M * 4 * C * 4)); CK(hipMalloc(&cp, M * C * 4)); CK(hipMalloc(&gates, M * 4 * C * 4));
+    CK(hipMalloc(&c, M * C * 4)); CK(hipMalloc(&h, M * C * 4)); CK(hipMalloc(&planes, M * C * 4 + 64));
+    CK(hipMemset(xg, 0, M * 4 * C * 4)); CK(hipMemset(cp, 0, M * C * 4));
+    e.xg = xg; e.cprev = cp; e.gates = gates; e.c = c; e.h = h; e.planes = planes;
+    // three rounds, rotated order: the clock a variant sees depends on what ran before it (DVFS), 30 launches each
+    for (int round = 0; round < 3; ++round)
+        for (int k = 0; k < 12; ++k) {
+            int rc = 0;
+            switch ((k + 5 * round) % 12) {
+            case 0: rc = timeit("A 8 waves 256x128, 6 pieces, no epilogue", probeA<6, 0>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 1: rc = timeit("A 8 waves 256x128, 6 pieces, cell epilogue", probeA<6, 1>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 2: rc = timeit("A 8 waves 256x128, 2 pieces, no epilogue", probeA<2, 0>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 3: rc = timeit("A 8 waves 256x128, 2 pieces, cell epilogue", probeA<2, 1>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 4: rc = timeit("B 2 x 4 waves 128x128, 2 stages, no epilogue", probeB<0>, dim3(10240), dim3(256), 2 * B_STAGE, e, sink, nkt, src, reps); break;
+            case 5: rc = timeit("B 2 x 4 waves 128x128, 2 stages, cell epilogue", probeB<1>, dim3(10240), dim3(256), 2 * B_STAGE, e, sink, nkt, src, reps); break;
+            case 6: rc = timeit("C 2 x 4 waves 128x128, 4 half stages, no epi", probeC<0>, dim3(10240), dim3(256), 4 * C_STAGE, e, sink, nkt, src, reps); break;
+            case 7: rc = timeit("C 2 x 4 waves 128x128, 4 half stages, cell epi", probeC<1>, dim3(10240), dim3(256), 4 * C_STAGE, e, sink, nkt, src, reps); break;
+            case 8: rc = timeit("A 8 waves 256x128, 3 pieces (halo rate), no epi", probeA<3, 0>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 9: rc = timeit("A 8 waves 256x128, 3 pieces (halo rate), cell epi", probeA<3, 1>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 10: rc = timeit("D 2 x 4 waves 128x128, halo rate 5 pieces, no epi", probeD<0>, dim3(10240), dim3(256), D_PIX + 3 * D_W, e, sink, nkt, src, reps); break;
+            case 11: rc = timeit("D 2 x 4 waves 128x128, halo rate 5 pieces, cell epi", probeD<1>, dim3(10240), dim3(256), D_PIX + 3 * D_W, e, sink, nkt, src, reps); break;
+            }
+            if (rc) return 1;
+        }
+    return 0;
+}
