@@ -42,20 +42,23 @@ __device__ __forceinline__ void fill_lds(unsigned char* smem, int bytes, int nth
 // the shipped epilogue's traffic and math for a wave's 64 pixels x (4 gates x 16 channels): lane = (pixel l16 of row tile i, channel group g4)
 __device__ __forceinline__ void cell_epilogue(const Epi& e, f32x4 (&tot)[4][4], int64_t row0, int ch0, int l16, int g4) {
     const int C = e.C, chb = ch0 + 4 * g4;
-    float4 xv[4][4], cp[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = row0 + 16 * i + l16;
+    for (int half = 0; half < 2; ++half) {        // two halves, as the shipped kernel: 10 float4 loads in flight per lane
+    float4 xv[2][4], cp[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const float4*>(e.xg + m * 4 * C + q * C + chb);
-        cp[i] = *reinterpret_cast<const float4*>(e.cprev + m * C + chb);
+    for (int ii = 0; ii < 2; ++ii) {
+        const int64_t m = row0 + 16 * (2 * half + ii) + l16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[ii][q] = *reinterpret_cast<const float4*>(e.xg + m * 4 * C + q * C + chb);
+        cp[ii] = *reinterpret_cast<const float4*>(e.cprev + m * C + chb);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * half + ii;
         const int64_t m = row0 + 16 * i + l16;
         float4 gi, gf, go, gg, cn, hn;
-#define CELL(E, R) gi.E = sig(tot[i][0][R] + xv[i][0].E); gf.E = sig(tot[i][1][R] + xv[i][1].E); go.E = sig(tot[i][2][R] + xv[i][2].E); \
-                   gg.E = tnh(tot[i][3][R] + xv[i][3].E); cn.E = gf.E * cp[i].E + gi.E * gg.E; hn.E = go.E * cn.E;
+#define CELL(E, R) gi.E = sig(tot[i][0][R] + xv[ii][0].E); gf.E = sig(tot[i][1][R] + xv[ii][1].E); go.E = sig(tot[i][2][R] + xv[ii][2].E); \
+                   gg.E = tnh(tot[i][3][R] + xv[ii][3].E); cn.E = gf.E * cp[ii].E + gi.E * gg.E; hn.E = go.E * cn.E;
         CELL(x, 0) CELL(y, 1) CELL(z, 2) CELL(w, 3)
 #undef CELL
         float* gp = e.gates + m * 4 * C + chb;
@@ -71,6 +74,7 @@ __device__ __forceinline__ void cell_epilogue(const Epi& e, f32x4 (&tot)[4][4], 
         uint16_t* grp = e.planes + ((m * C + chb) >> 4) * 32 + (chb & 15);
         *reinterpret_cast<ushort4*>(grp) = pa;
         *reinterpret_cast<ushort4*>(grp + 16) = pb;
+    }
     }
 }
 
@@ -176,6 +180,117 @@ __global__ __launch_bounds__(512, 2) void probeA(Epi e, float* sink, int nkt, co
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += tot[i][j][r];
     if (s == 123.456f) sink[threadIdx.x] = s;
 }
+
+// ---- P: A as a PERSISTENT kernel (one workgroup per CU walks 20 tiles): tile i + 1's first PRE K-tiles are issued before tile i's epilogue ----
+template <int LOADS, int PRE>
+__global__ __launch_bounds__(512, 2) void probeP(Epi e, float* sink, int nkt, const unsigned char* src, uint32_t srcmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_lds(smem, 3 * A_STAGE, 512);
+    const uint32_t lane_off = (uint32_t)(threadIdx.x * 16);
+    uint32_t gpos = (uint32_t)blockIdx.x * 1572864u;
+    auto issue = [&](int stage_) {
+        unsigned char* st = smem + stage_ * A_STAGE;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) GLDS16(src + ((gpos + j * 8192u + lane_off) & srcmask), st + j * 8192 + lane_off);
+        gpos += 49152u;
+    };
+    auto wait_loads = [&](bool more) {
+        if (more) {
+            if constexpr (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (LOADS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, g4 = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int rot = (l16 >> 1) & 7;
+    int offA[2], offB[2];
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pos = ((g4 >> 1) * 4 + pl * 2 + (g4 & 1)) ^ rot;
+        offA[pl] = (wm * 64 + l16) * 128 + pos * 16;
+        offB[pl] = A_HA + (wn * 64 + l16) * 128 + pos * 16;
+    }
+    f32x4 acc[4][4], tot[4][4];
+    f16x8 af[4][2], bf[4][2];
+    auto rd = [&](int stage) {
+        const unsigned char* st = smem + stage * A_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const f16x8*>(st + offA[pl] + i * 16 * 128);
+                bf[i][pl] = *reinterpret_cast<const f16x8*>(st + offB[pl] + i * 16 * 128);
+            }
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][1], af[i][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][0], af[i][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    auto fold = [&](int kt) {
+        if ((kt & 7) == 7)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f; }
+    };
+    const bool late = wave >= 4;
+    int stage = 0;
+    auto prev = [](int st_) { return st_ == 0 ? 2 : st_ - 1; };
+    auto nxt = [](int st_) { return st_ == 2 ? 0 : st_ + 1; };
+    const int ntiles = 5120;
+    issue(0); issue(1); if (PRE == 3) issue(2);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    if (PRE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else wait_loads(tile == (int)blockIdx.x);
+    // later tiles: the ring's first stages were issued BEFORE the previous tile's epilogue, whose own loads returned after them
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_setprio(1);
+    if (!late) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            rd(stage);
+            if (kt + 2 < nkt && !(PRE == 3 && kt == 0)) issue(prev(stage));
+            mm(); fold(kt);
+            if (!(PRE == 3 && kt == 0)) wait_loads(kt + 2 < nkt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt > 0) { mm(); fold(kt - 1); }
+            rd(stage);
+            if (kt + 2 < nkt && !(PRE == 3 && kt == 0)) issue(prev(stage));
+            if (!(PRE == 3 && kt == 0)) wait_loads(kt + 2 < nkt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        mm(); fold(nkt - 1);
+    }
+    if (late) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[i][j] = (tot[i][j] + acc[i][j]) * 1e-6f;
+    if (tile + (int)gridDim.x < ntiles) {      // the next tile's first K-tiles start their way into the (now free) ring before this tile's epilogue
+        issue(stage); issue(nxt(stage)); if (PRE == 3) issue(prev(stage));
+    }
+    {
+        int t2 = tile;
+        asm volatile("" : "+s"(t2));               // keep the epilogue's address arithmetic out of the K loop's live ranges
+        const int tm = t2 >> 4, tn = t2 & 15;
+        cell_epilogue(e, tot, (int64_t)tm * 256 + wm * 64, tn * 32 + wn * 16, l16, g4);
+    }
+    }
+}
+
 
 // ---- B: 4 waves, 128x128, 2-stage ring, two workgroups per CU ----------------------------------------------------------------------
 constexpr int B_HA = 128 * 128, B_STAGE = 2 * B_HA;      // 32 KB per stage
@@ -431,9 +546,9 @@ int main() {
     e.xg = xg; e.cprev = cp; e.gates = gates; e.c = c; e.h = h; e.planes = planes;
     // three rounds, rotated order: the clock a variant sees depends on what ran before it (DVFS), 30 launches each
     for (int round = 0; round < 3; ++round)
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 14; ++k) {
             int rc = 0;
-            switch ((k + 5 * round) % 12) {
+            switch ((k + 5 * round) % 14) {
             case 0: rc = timeit("A 8 waves 256x128, 6 pieces, no epilogue", probeA<6, 0>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
             case 1: rc = timeit("A 8 waves 256x128, 6 pieces, cell epilogue", probeA<6, 1>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
             case 2: rc = timeit("A 8 waves 256x128, 2 pieces, no epilogue", probeA<2, 0>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
@@ -446,6 +561,8 @@ int main() {
             case 9: rc = timeit("A 8 waves 256x128, 3 pieces (halo rate), cell epi", probeA<3, 1>, dim3(5120), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
             case 10: rc = timeit("D 2 x 4 waves 128x128, halo rate 5 pieces, no epi", probeD<0>, dim3(10240), dim3(256), D_PIX + 3 * D_W, e, sink, nkt, src, reps); break;
             case 11: rc = timeit("D 2 x 4 waves 128x128, halo rate 5 pieces, cell epi", probeD<1>, dim3(10240), dim3(256), D_PIX + 3 * D_W, e, sink, nkt, src, reps); break;
+            case 12: rc = timeit("P persistent A, 3 pieces, 2 K-tiles ahead, cell epi", probeP<3, 2>, dim3(256), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
+            case 13: rc = timeit("P persistent A, 3 pieces, 3 K-tiles ahead, cell epi", probeP<3, 3>, dim3(256), dim3(512), 3 * A_STAGE, e, sink, nkt, src, reps); break;
             }
             if (rc) return 1;
         }
