@@ -9,11 +9,16 @@
 //   layout 0 ("nk", B [N][K]): 16 columns; lane (l16, g4) loads float4 B[n0 + l16][k0 + 4 g4 ..] and float4 A[16 i + l16][k0 + 4 g4 ..]
 //            per 16-k block and issues 4 MFMAs per row tile (element e of both: the same k permutation on both sides, the sum is
 //            order-free) -- D[row 4 g4 + r][col l16];
-//   layout 1 ("kn", B [K][N]): 64 columns; per 16-k block four float4 B[k0 + 4 g4 + e][n0 + 4 l16 ..] (256 contiguous bytes per k row)
-//            against the same A fragments; column tile c of the MFMA holds output column n0 + 4 l16 + c, so a lane ends up with four
-//            consecutive columns (float4 stores).
+//   layout 1 ("kn", B [K][N]): 32 columns; per 16-k block four float2 B[k0 + 4 g4 + e][n0 + 2 l16 ..] (128 contiguous bytes per k row)
+//            against the same A fragments; column tile c of the MFMA holds output column n0 + 2 l16 + c, so a lane ends up with two
+//            consecutive columns (float2 stores).
 // The 4 waves of a workgroup take the 16-k blocks of the slice round-robin and are summed through LDS in wave order; K slices
 // (gridDim.y) leave partial [z][M][N] tiles that a second kernel sums in slice order: bitwise reproducible, no atomics.
+// FOOTPRINT: both layouts stay under 80 VGPRs and 4 KB of LDS on purpose.  In backward these GEMMs sit in the chain of small launches
+// that runs BESIDE the h-gate conv's data gradient (functional._GateConvLstm.backward): that kernel holds 2 x 216 of a SIMD's 512
+// registers and 148 of the CU's 160 KB of LDS for 0.6 ms per tile, and a workgroup that fits into the remainder starts at once while one
+// that does not waits for a tile to end (the 64-column build of layout 1 -- 128 VGPRs, 16 KB -- took 0.4-0.6 ms per launch there,
+// profiles/r05_async_dgrad_window.log, against 15 us alone).
 #include "common.h"
 #include <algorithm>
 
@@ -34,12 +39,12 @@ struct SkArgs {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void skinny_kernel(SkArgs p) {
-    constexpr int NCT = LAYOUT == 0 ? 1 : 4;                  // column tiles per wave
-    __shared__ __attribute__((aligned(16))) float red[4][NCT][64][4];
+__global__ __launch_bounds__(256, 6) void skinny_kernel(SkArgs p) {      // 6 waves per SIMD: VGPRs + AGPRs <= 80 (see FOOTPRINT above)
+    constexpr int NCT = LAYOUT == 0 ? 1 : 2;                  // column tiles per wave
+    __shared__ __attribute__((aligned(16))) float red[4][64][4];      // one column tile at a time
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l16 = lane & 15, g4 = lane >> 4;
-    const int n0 = blockIdx.x * (LAYOUT == 0 ? 16 : 64);
+    const int n0 = blockIdx.x * (LAYOUT == 0 ? 16 : 32);
     const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
     const int mt = (p.M + 15) >> 4;                           // row tiles in use (scalar)
     f32x4 acc[4][NCT];
@@ -66,20 +71,19 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkArgs p) {
                     for (int e = 0; e < 4; ++e) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], be[e], acc[i][0], 0, 0, 0);
                 }
         } else {
-            float4 b4[4];
+            float2 b2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                b4[e] = (n0 + 4 * l16 < p.N) ? ld4(p.B + (int64_t)(k0 + 4 * g4 + e) * p.ldb + n0 + 4 * l16) : z4;
+                b2[e] = (n0 + 2 * l16 < p.N) ? *reinterpret_cast<const float2*>(p.B + (int64_t)(k0 + 4 * g4 + e) * p.ldb + n0 + 2 * l16)
+                                             : make_float2(0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < mt) {
                     const float ae[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], b4[e].x, acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], b4[e].y, acc[i][1], 0, 0, 0);
-                        acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], b4[e].z, acc[i][2], 0, 0, 0);
-                        acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], b4[e].w, acc[i][3], 0, 0, 0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], b2[e].x, acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], b2[e].y, acc[i][1], 0, 0, 0);
                     }
                 }
         }
@@ -91,23 +95,23 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                             // (mt is uniform: the barriers below are taken by all or by none)
         if (i >= mt) break;
-        __syncthreads();
+        float v[NCT][4];
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-            *reinterpret_cast<float4*>(red[wave][c][lane]) = make_float4(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
-        __syncthreads();
-        if (wave == 0) {
-            float v[NCT][4];
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                float4 s = *reinterpret_cast<const float4*>(red[0][c][lane]);
+        for (int c = 0; c < NCT; ++c) {
+            __syncthreads();
+            *reinterpret_cast<float4*>(red[wave][lane]) = make_float4(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
+            __syncthreads();
+            if (wave == 0) {
+                float4 s = *reinterpret_cast<const float4*>(red[0][lane]);
 #pragma unroll
                 for (int w = 1; w < 4; ++w) {
-                    const float4 x = *reinterpret_cast<const float4*>(red[w][c][lane]);
+                    const float4 x = *reinterpret_cast<const float4*>(red[w][lane]);
                     s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
                 }
                 v[c][0] = s.x; v[c][1] = s.y; v[c][2] = s.z; v[c][3] = s.w;
             }
+        }
+        if (wave == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * i + 4 * g4 + r;
@@ -123,15 +127,15 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkArgs p) {
                         dst[(int64_t)row * ldd + n] = x;
                     }
                 } else {
-                    const int n = n0 + 4 * l16;
+                    const int n = n0 + 2 * l16;
                     if (n < p.N) {
-                        float4 x = make_float4(v[0][r], v[1][r], v[2][r], v[3][r]);
+                        float2 x = make_float2(v[0][r], v[1][r]);
                         if (fin) {
-                            const float4 bv = p.bias ? ld4(p.bias + n) : z4;
-                            x.x = p.alpha * x.x + bv.x; x.y = p.alpha * x.y + bv.y; x.z = p.alpha * x.z + bv.z; x.w = p.alpha * x.w + bv.w;
-                            if (p.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                            const float2 bv = p.bias ? *reinterpret_cast<const float2*>(p.bias + n) : make_float2(0.f, 0.f);
+                            x.x = p.alpha * x.x + bv.x; x.y = p.alpha * x.y + bv.y;
+                            if (p.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); }
                         }
-                        *reinterpret_cast<float4*>(dst + (int64_t)row * ldd + n) = x;
+                        *reinterpret_cast<float2*>(dst + (int64_t)row * ldd + n) = x;
                     }
                 }
             }
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, i
 
 // K slices so that the launch has ~512 workgroups; a slice is a multiple of 64 k (16 per wave)
 void sk_plan(int N, int K, int layout, int& col_wgs, int& nsplit, int& kchunk) {
-    col_wgs = (int)sp_cdiv(N, layout == 0 ? 16 : 64);
+    col_wgs = (int)sp_cdiv(N, layout == 0 ? 16 : 32);
     const int want = std::max(1, std::min(512 / std::max(col_wgs, 1), K / 64));
     kchunk = (int)(sp_cdiv(sp_cdiv(K, want), 64) * 64);
     nsplit = (int)sp_cdiv(K, kchunk);

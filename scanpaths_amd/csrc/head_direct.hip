@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ 
 // dh[b][q][c] (+)= sum over the sites whose window covers q, over the head slots.  A thread owns (pixel q, channel quad c4) for a
 // GROUP of up to four samples: the up to 9 sites x nsel filter rows it needs are the same for every sample that uses the same
 // source heads, so they are read once per group (the kernel is bound by these L2 reads: 18 float4 of W11 per float4 of dh).
-__global__ __launch_bounds__(256) void drt_bwd_data_kernel(const float* __restrict__ dD, const float* __restrict__ W11,
+// (launch bounds: 6 waves per SIMD = at most 80 VGPRs, and drt_bwd_weight_kernel's 10 KB of LDS: both then fit beside a resident
+// workgroup of the h-gate conv's data gradient -- 2 x 216 registers, 148 KB -- that runs on the side stream during these launches)
+__global__ __launch_bounds__(256, 6) void drt_bwd_data_kernel(const float* __restrict__ dD, const float* __restrict__ W11,
                                                            const int* __restrict__ hmap, int B, int C4, int nsel, int ncls,
                                                            AxisCls ay, AxisCls ax, int accumulate, float* __restrict__ dh) {
     const int Hm = ay.len, Wm = ax.len, P = Hm * Wm, S = ay.n * ax.n;
@@ -301,7 +303,7 @@ constexpr int DRT_MAXS = MAXSITE * MAXSITE;
 __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __restrict__ dD, const float* __restrict__ h, int B,
                                                              int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
                                                              float* __restrict__ slab, const int* __restrict__ row_last, int row_step) {
-    __shared__ int s_pix[DRT_MAXS];
+    __shared__ unsigned short s_pix[DRT_MAXS];          // (a map has < 65536 pixels: make_axis caps a side at 5 * MAXSITE)
     __shared__ float s_g0[DRT_MAXS], s_g1[DRT_MAXS];
     __shared__ int s_cnt[2];
     const int v = blockIdx.x % NV, cls = blockIdx.x / NV, b = blockIdx.y, i0 = blockIdx.z * 2;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __rest
         __syncthreads();
         const int pos = n + (wave ? s_cnt[0] : 0) + __popcll(m & ((1ull << lane) - 1ull));
         if (valid) {
-            s_pix[pos] = qy * Wm + qx;
+            s_pix[pos] = (unsigned short)(qy * Wm + qx);
             s_g0[pos] = g0[s];
             s_g1[pos] = g1[s];
         }
