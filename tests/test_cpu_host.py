@@ -394,3 +394,58 @@ def test_direct_gradient_writes_step_aside_for_user_tensor_hooks():
     assert F._grad_slot(p) is None
     h.remove()
     assert F._grad_slot(p) is not None
+
+
+def _device_kernel_footprints(so_path):
+    """{mangled kernel name: (vgprs + agprs, static LDS bytes)} read from the AMDGPU code objects embedded in the shared library"""
+    import struct
+    import subprocess
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not found")
+    data = open(so_path, "rb").read()
+    out, pos = {}, 0
+    while True:
+        i = data.find(b"\x7fELF", pos)
+        if i < 0:
+            break
+        pos = i + 4
+        if data[i + 4] != 2 or struct.unpack_from("<H", data, i + 18)[0] != 224:      # ELF64, EM_AMDGPU
+            continue
+        shoff = struct.unpack_from("<Q", data, i + 40)[0]
+        shentsize, shnum = struct.unpack_from("<HH", data, i + 58)
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(data[i:i + shoff + shentsize * shnum])
+            f.flush()
+            notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            agpr = int(blk.split()[0])
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+            lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+            out[name] = (vgpr + agpr, lds)
+    return out
+
+
+def test_backward_chain_kernels_fit_beside_a_resident_data_gradient_workgroup():
+    """The two-stream backward runs the small launches of the recurrence while the h-gate conv's data gradient holds
+    every CU with 2 x 216 registers per SIMD and 148 KB of LDS; a launch starts beside it only with <= 80 VGPRs + AGPRs per wave and
+    <= 11 KB of LDS per workgroup (tools/probes/coresidency_probe.hip, profiles/r05_coresidency_probe.log), otherwise it waits 0.6 ms
+    for a tile to end.  The kernels of that chain are built to the limits: hold them there (register pressure moves with every edit)."""
+    from scanpaths_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    fp = _device_kernel_footprints(hip.LIB_PATH)
+    gemm = [v for k, v in fp.items() if "h2_kernelILi1ELi3ELb1ELb0ELb1ELi0EE" in k]
+    assert gemm and gemm[0][0] <= 216, gemm            # the resident: more registers here shrink what is left for everybody else
+    chain = ("skinny_kernelILi0E", "skinny_kernelILi1E", "skinny_reduce_kernel", "listatt_bwd_kernel", "sempool_bwd_kernel",
+             "mulrelu_bwd_kernel", "head_bwd_kernel", "drt_bwd_data_kernel", "drt_bwd_weight_kernel", "drt_slab_reduce_kernel",
+             "drt_dcbsum_kernel", "sal_gather_bwd_kernel", "colsum_partial", "colsum_final", "sum_n_kernel", "add_kernel",
+             "col2im1_kernel", "colamax_partial_kernel", "colamax_final_kernel", "split2_cols_kernel")
+    for want in chain:
+        hits = {k: v for k, v in fp.items() if want in k}
+        assert hits, want
+        for k, (regs, lds) in hits.items():
+            assert regs <= 80 and lds <= 11 * 1024, (k, regs, lds)
