@@ -78,6 +78,7 @@ def bucketer_overhead(opt, step, sync, steps, bucketed_ms):
     opt._bucketer = bk
     # one instrumented step: events at every bucket launch (compute stream) and at the end of backward
     bk.record = True
+    bk.host_launch_ms = bk.host_wait_ms = 0.0
     end_bwd = torch.cuda.Event(enable_timing=True)
     orig_step = opt.step
 
@@ -107,6 +108,10 @@ def bucketer_overhead(opt, step, sync, steps, bucketed_ms):
             "n_buckets": len(bk.ranges),
             "plain_ms_per_step": [round(plain_a, 2), round(plain_b, 2)], "bucketed_ms_per_step": [round(bucketed_ms, 2), round(bucketed_b, 2)],
             "ddp_overhead_ms": round(bucketed - plain, 2),
+            # where the overhead of a world of one goes: host time of the instrumented step inside the collectives' launches (on the autograd
+            # thread, i.e. in front of the ~2300 kernel launches the backward still has to enqueue) and inside handle.wait(); the rest is
+            # RCCL's own identity kernels / stream hand-offs on the device
+            "host_ms_in_allreduce_launches": round(bk.host_launch_ms, 3), "host_ms_in_handle_waits": round(bk.host_wait_ms, 3),
             "bucket_timeline": buckets,
             "note": "order: bucketed (the timed region of this line), plain, bucketed, plain -- same process, same box; identity all-reduce "
                     "(world 1): launch / hook / stream hand-off cost only, no xGMI traffic; no scaling curve has been measured"}
@@ -141,11 +146,17 @@ def parse():
     ap.add_argument("--force-bucketer", action="store_true",
                     help="1-GPU half of the scaling evidence: run the data-parallel machinery in an RCCL world of ONE (post-accumulate hooks, "
                          "32 MB buckets, async all-reduce on RCCL's stream) and report its cost next to the plain step (JSON key 'ddp')")
-    ap.add_argument("--cpu-threads", type=int, default=32,
-                    help="threads for the CPU baseline (oneDNN convs stop scaling / thrash beyond ~32 on the 256-thread host)")
-    ap.add_argument("--cpu-batch", type=int, default=2, help="images per CPU-baseline step (BASELINE.md §4 names 4; 2 keeps "
-                                                             "the default run short -- every step is MEASURED at the full T)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads for the CPU baseline; 0 = the best count of the recorded sweep over {32, 64, 128} on this pool's host "
+                         "(profiles/r06_cpu_thread_sweep.json, written by --cpu-sweep), 32 when no sweep is committed")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="images per CPU-baseline step (BASELINE.md §4: bs 4; every step is MEASURED "
+                                                             "at the full T, nothing is extrapolated)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up step (BASELINE.md §4: 3, median)")
+    ap.add_argument("--cpu-sweep", action="store_true",
+                    help="run ONLY the CPU-baseline thread sweep (32 / 64 / 128 threads, 1 warm-up + 1 timed step each at --cpu-batch images), "
+                         "print it as one JSON line and exit -- the line is committed as profiles/r06_cpu_thread_sweep.json")
+    ap.add_argument("--no-length-leg", action="store_true",
+                    help="do not time the step on the second scanpath-length law (L ~ U{T/2..T}) after the timed region")
     return ap.parse_args()
 
 
@@ -182,7 +193,9 @@ def cpu_baseline(args):
     from scanpaths_amd.spec import is_buffer, model_spec
     from scanpaths_amd.synth import make_batch
     hi = host_info()
-    cores = min(args.cpu_threads or os.cpu_count(), os.cpu_count())
+    sweep = cpu_sweep_record()
+    want = args.cpu_threads or (sweep or {}).get("best_threads") or 32
+    cores = min(want, os.cpu_count())
     torch.set_num_threads(cores)
     task = {"air": "AiR", "osie": "OSIE", "coco": "COCO_Search18"}[args.task]
     Hm, Wm = args.height // 8, args.width // 8
@@ -219,7 +232,35 @@ def cpu_baseline(args):
                       f"(fwd {med[1]:.1f} s, bwd {med[2]:.1f} s, clip+Adam {med[3]:.2f} s); all steps: "
                       + ", ".join(f"{r[0]:.1f}" for r in rows),
             "s_per_step": round(med[0], 2), "fwd_s": round(med[1], 2), "bwd_s": round(med[2], 2), "opt_s": round(med[3], 3),
-            "threads_used": cores, "host": hi}
+            "threads_used": cores, "host": hi,
+            "thread_choice": ("--cpu-threads" if args.cpu_threads else
+                              (f"best of the recorded sweep {sweep['images_per_s_by_threads']} on {sweep.get('host', {}).get('model', '?')} "
+                               "(profiles/r06_cpu_thread_sweep.json)" if sweep else "32 (no sweep committed)"))}
+
+
+def cpu_sweep_record():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r06_cpu_thread_sweep.json")))
+    except Exception:
+        return None
+
+
+def cpu_sweep(args):
+    """one-off: the CPU leg at 32 / 64 / 128 threads (1 warm-up + 1 timed step each), so that the thread count of the reported baseline
+    is the best this host offers and the claim is a recorded measurement (VERDICT r5 weak #8)"""
+    import copy
+    res = {}
+    for th in (32, 64, 128):
+        if th > (os.cpu_count() or 1):
+            continue
+        a = copy.copy(args)
+        a.cpu_threads, a.cpu_steps = th, 1
+        r = cpu_baseline(a)
+        res[str(th)] = round(r["value"], 4)
+        print(f"bench.py --cpu-sweep: {th} threads -> {r['value']:.4f} img/s ({r['s_per_step']} s/step)", file=sys.stderr)
+    best = max(res, key=lambda k: res[k])
+    return {"images_per_s_by_threads": res, "best_threads": int(best), "images": args.cpu_batch, "workload": f"{args.task} {args.height}x{args.width} T={args.T} {args.arch}",
+            "protocol": "oracle train step (fwd+loss+bwd+clip+Adam), 1 warm-up + 1 timed step per thread count", "host": host_info()}
 
 
 def build_model(args, dev):
@@ -306,6 +347,9 @@ def launch_ranks(args) -> int:
 
 def main():
     args = parse()
+    if args.cpu_sweep:
+        print(json.dumps(cpu_sweep(args)))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -374,7 +418,10 @@ def main():
                        reference_zero_grad=model.has_conditional_params,     # COCO heads: the reference's torch-1.6 zero-fill semantics
                        force_bucketer=args.force_bucketer)
 
+        cur = {"b": b}          # (the length-law leg after the timed region swaps the batch)
+
         def step():
+            b = cur["b"]
             opt.zero_grad()
             pred = call_model(model, args, b, True)
             mask_sums = None
@@ -405,6 +452,28 @@ def main():
                                                      pred[pre + "log_normal_sigma2"])
             return last["durations"].sum()
 
+    dist_info = None
+    if world > 1:
+        # self-verification of the multi-GPU line (the first SCALE run must prove the collective saw N ranks): an all-reduce of ones,
+        # the devices the ranks sit on, the RCCL version
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        torch.distributed.all_reduce(one)
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            ver = f"unavailable ({type(e).__name__})"
+        dist_info = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                     "allreduce_of_ones": float(one.item()), "allreduce_self_test_ok": float(one.item()) == float(world),
+                     "rccl_version": ver, "ranks": gathered,
+                     "distinct_devices": len({(g["device_index"], g["uuid"], g["pci_bus_id"]) for g in gathered})}
+        if not dist_info["allreduce_self_test_ok"]:
+            raise SystemExit(f"bench.py: all-reduce self-test failed: sum of ones over {world} ranks = {one.item()}")
+
     for _ in range(args.warmup):
         step()
 
@@ -422,7 +491,14 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
+    if world > 1 and args.mode == "train":
+        # after W + K optimiser steps every rank must hold the same parameters (same reduced gradients, same Adam state): a drifted
+        # replica means a collective was skipped or mis-ordered on some rank
+        from scanpaths_amd.ddp import assert_replicas_identical
+        assert_replicas_identical(opt.flat_p)
+        dist_info["replicas_identical_after_timed_region"] = True
     sparsity, dropin = None, None
+    length_leg = None
     act_frac = None
     if args.mode == "train":
         # what the gate derived from the gradient of the last step: last[b] per sample -> the live fraction of (sample, step) pairs of steps 1..T-1
@@ -453,6 +529,27 @@ def main():
                             "(tests/test_model_gpu.py::test_masked_step_sparsity...); forward, loss, clip and Adam are unchanged; synthetic "
                             "scanpath lengths are uniform in 1..T (SURVEY.md 8d), real length distributions skip less or more; "
                             "`--dense-backward` makes the dense form the line"}
+    if args.mode == "train" and world == 1 and sparse_on and not args.dropin and not args.no_length_leg and not args.force_bucketer:
+        # sensitivity of the line to the synthetic length law (the sparsity of the backward pass is the only thing that depends on it):
+        # the same step on L ~ U{ceil(T/2)..T} -- every other tensor of the batch is identical -- same process, after the timed region
+        b2 = {k: v.to(dev) for k, v in make_batch(task, args.batch, args.height, args.width, args.T, seed=0, rank=rank,
+                                                  length_law="uniform_halfT_T").items()}
+        cur["b"] = b2
+        step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        l_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        rows_tok = getattr(model, "last_decode_rows", None)
+        l_frac = None
+        if rows_tok is not None and rows_tok.rc is not None and args.T > 1:
+            l_frac = float((rows_tok.rc.last.view(-1, 1) >= torch.arange(1, args.T, device=dev).view(1, -1)).float().mean())
+        cur["b"] = b
+        length_leg = {"length_law": "L ~ U{ceil(T/2)..T} (every other draw of the batch unchanged)", "ms_per_step": round(l_ms, 2),
+                      "images_per_s": round(args.batch * 1e3 / l_ms, 3),
+                      "active_fraction_of_sample_steps": round(l_frac, 4) if l_frac is not None else None}
     if args.mode == "train" and world == 1 and not args.dropin and not args.no_dropin_leg and not args.force_bucketer:
         # the reference's literal call sequence on a second, identically initialised model (the first one's parameters live in FlatAdam's
         # flat buffers): same process, same box, after the timed region
@@ -601,6 +698,18 @@ def main():
                       # only under SP_ALLOW_ENV_TUNING=1): {} for the headline line
                       "non_default_switches": sp_config.non_default()},
            "roofline": roofline}
+    if sparsity is not None:
+        # the same line's dense figure at top level: what the step costs when the zeros behind every sample's last masked-in step are
+        # multiplied like the reference does; `value` is the step on SURVEY 8(d)'s length law L ~ U{1..T} with those zeros skipped
+        out["value_dense"] = sparsity["dense_backward_images_per_s"]
+        out["ms_per_step_dense"] = sparsity["dense_backward_ms_per_step"]
+        out["value_note"] = ("value: masked-step sparsity of the backward pass on (exact, bit-identical gradients; derived from the gradient, "
+                             "no switch), scanpath lengths L ~ U{1..T}; value_dense: same process, dense backward; length_law_sensitivity: "
+                             "same process, L ~ U{ceil(T/2)..T}; cpu_baseline: the oracle computes the dense backward")
+    if length_leg is not None:
+        out["length_law_sensitivity"] = length_leg
+    if dist_info is not None:
+        out["distributed"] = dist_info
     if sparsity is not None:
         out["backward_sparsity"] = sparsity
     elif args.mode == "train":

@@ -197,7 +197,9 @@ int sp_conv_wgrad_f16x1(const sp_wgrad_desc* d, const void* Xsplit, const float*
  * ConvLSTM cell :88-118 as restated in SURVEY.md §8a; replaces sp_conv_igemm_f16x2 + sp_lstm_rank1_fwd):
  *   pre = conv(h_prev, Wh) + xg + [spcol x wc] (i, f, o gates);  gates = sigmoid(i, f, o), tanh(g);  c = f*c_prev + i*g;  h = o*c
  * d: mode 0, stride 1, Kc = C, Nout = 4C (gate-major weight rows i, f, o, g), Ho x Wo = Hi x Wi = P pixels, P % 256 == 0, KP <= 32.
- * xg / gates [B*P][4C], c_prev / c_out / h_out [B*P][C], spcol [B*P][KP], wc [B][3C][KP]; h_amax may be NULL. */
+ * xg / gates [B*P][4C], c_prev / c_out / h_out [B*P][C], spcol [B*P][KP], wc [B][3C][KP]; h_amax may be NULL.
+ * Alignment: C % 32 == 0 and xg, c_prev, gates, c_out, h_out (and w_scale when d->w_scale_rows) 16-byte aligned -- the cell epilogue
+ * reads and writes 4 consecutive channels per lane as one 16-byte access; SP_EINVAL otherwise. */
 int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hsplit, const float* h_scale, const void* Wsplit, const float* w_scale,
                            const float* xg, const float* c_prev, const float* spcol, const float* wc, int P, int KP, float* gates,
                            float* c_out, float* h_out, unsigned* h_amax,

@@ -69,24 +69,30 @@ def encoder(sd, images, arch="resnet50", training=False, bn_new=None, pfx="resne
         for bi in range(nblocks):
             p = f"{pfx}{seq}.{bi}."
             s = first_stride if bi == 0 else 1
-            idn = x
-            if kind == "bottleneck":
-                o = F.conv2d(x, sd[p + "conv1.weight"], None, stride=s)
-                o = F.relu(_bn(sd, p + "bn1", o, training, bn_new))
-                o = F.conv2d(o, sd[p + "conv2.weight"], None, stride=1, padding=dil, dilation=dil)
-                o = F.relu(_bn(sd, p + "bn2", o, training, bn_new))
-                o = F.conv2d(o, sd[p + "conv3.weight"], None)
-                o = _bn(sd, p + "bn3", o, training, bn_new)
-            else:
-                o = F.conv2d(x, sd[p + "conv1.weight"], None, stride=s, padding=1)
-                o = F.relu(_bn(sd, p + "bn1", o, training, bn_new))
-                o = F.conv2d(o, sd[p + "conv2.weight"], None, stride=1, padding=dil, dilation=dil)
-                o = _bn(sd, p + "bn2", o, training, bn_new)
-            if (p + "downsample.0.weight") in sd:
-                idn = F.conv2d(x, sd[p + "downsample.0.weight"], None, stride=s)
-                idn = _bn(sd, p + "downsample.1", idn, training, bn_new)
-            x = F.relu(o + idn)
+            x = residual_block(sd, p, x, kind, s, dil, training, bn_new)
     return x
+
+
+def residual_block(sd, p, x, kind, s, dil, training, bn_new=None):
+    """one residual block with state_dict prefix p: Bottleneck.forward resnet.py:73-93 (stride on conv1, :61) / BasicBlock.forward
+    :36-54, conv2 dilated as dilate_resnet leaves it (baseline_attention.py:232-238); pinned per module by tests/golden/modules.npz"""
+    idn = x
+    if kind == "bottleneck":
+        o = F.conv2d(x, sd[p + "conv1.weight"], None, stride=s)
+        o = F.relu(_bn(sd, p + "bn1", o, training, bn_new))
+        o = F.conv2d(o, sd[p + "conv2.weight"], None, stride=1, padding=dil, dilation=dil)
+        o = F.relu(_bn(sd, p + "bn2", o, training, bn_new))
+        o = F.conv2d(o, sd[p + "conv3.weight"], None)
+        o = _bn(sd, p + "bn3", o, training, bn_new)
+    else:
+        o = F.conv2d(x, sd[p + "conv1.weight"], None, stride=s, padding=1)
+        o = F.relu(_bn(sd, p + "bn1", o, training, bn_new))
+        o = F.conv2d(o, sd[p + "conv2.weight"], None, stride=1, padding=dil, dilation=dil)
+        o = _bn(sd, p + "bn2", o, training, bn_new)
+    if (p + "downsample.0.weight") in sd:
+        idn = F.conv2d(x, sd[p + "downsample.0.weight"], None, stride=s)
+        idn = _bn(sd, p + "downsample.1", idn, training, bn_new)
+    return F.relu(o + idn)
 
 
 # --------------------------------------------------------------------------------------------

@@ -2130,6 +2130,10 @@ extern "C" int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hs, con
     if (d->Nout != 4 * d->Kc || d->Ho != d->Hi || d->Wo != d->Wi || d->KH * d->KW < 2 || d->KH * d->KW > 32) return SP_EINVAL;
     if (P != d->Ho * d->Wo || P % HBM || KP < 1 || KP > 32) return SP_EINVAL;
     if (((uintptr_t)Hs | (uintptr_t)Ws) & 15) return SP_EINVAL;
+    // the register-direct cell epilogue reads the x-gates, c_prev and the per-row weight scales and writes gates / c / h as 16-byte
+    // accesses per lane (4 consecutive channels; C % 32 == 0 keeps every row 16-byte aligned once the base is)
+    if (((uintptr_t)xg | (uintptr_t)c_prev | (uintptr_t)gates | (uintptr_t)c_out | (uintptr_t)h_out) & 15) return SP_EINVAL;
+    if (d->w_scale_rows && ((uintptr_t)w_scale & 15)) return SP_EINVAL;
     H2Args a{};
     a.X = (const uint16_t*)Hs; a.W = (const uint16_t*)Ws; a.bias = nullptr; a.C = nullptr;
     a.sx = h_scale; a.sw = w_scale; a.sw_rows = d->w_scale_rows ? 1 : 0;

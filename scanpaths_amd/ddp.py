@@ -64,10 +64,18 @@ class GradBucketer:
         self.bucket_of = [0] * n
         self.ranges = []                 # (lo, hi) element ranges, in parameter order
         lo, cur = 0, 0
+        es = flat.element_size()
         for i in range(n):
+            target = first_bucket_bytes if not self.ranges else bucket_bytes
+            # a large parameter behind a half-full bucket starts its own bucket instead of overshooting the target by more than a quarter
+            # (spatial_embed.weight at the 40x64 map is 26 MB: behind 26 MB of other parameters it made a 52 MB bucket)
+            if offsets[i] > lo and (offsets[i] - lo) * es >= target // 2 and (ends[i] - lo) * es > target + target // 4:
+                self.ranges.append((lo, offsets[i]))
+                lo = offsets[i]
+                target = bucket_bytes
             self.bucket_of[i] = len(self.ranges)
             cur = ends[i]
-            if (cur - lo) * flat.element_size() >= (first_bucket_bytes if not self.ranges else bucket_bytes) or i == n - 1:
+            if (cur - lo) * es >= target or i == n - 1:
                 self.ranges.append((lo, cur))
                 lo = cur
         self.members = [0] * len(self.ranges)
@@ -84,6 +92,8 @@ class GradBucketer:
 
     last_ready_events = []
     record = False      # bench.py --force-bucketer: time stamp of every bucket launch on the compute stream (bucket timeline)
+    host_launch_ms = 0.0      # (record only) host milliseconds spent inside dist.all_reduce(async_op=True) calls since the last reset_host_ms()
+    host_wait_ms = 0.0        # (record only) host milliseconds spent in handle.wait() (stream hand-off back to the compute stream)
 
     def _launch_ready(self, force: bool = False):
         while self.next_b >= 0 and (force or self.pending[self.next_b] == 0):
@@ -92,7 +102,12 @@ class GradBucketer:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 self.ready_events.append((self.next_b, (hi - lo) * self.flat.element_size(), ev))
-            self.handles.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+                import time
+                t0 = time.perf_counter()
+                self.handles.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+                self.host_launch_ms += (time.perf_counter() - t0) * 1e3      # host time inside the collective's launch (autograd thread)
+            else:
+                self.handles.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
             self.next_b -= 1
 
     def mark_ready(self, i: int):
@@ -117,8 +132,13 @@ class GradBucketer:
     def drain(self):
         """wait for every collective in flight and start a new round (FlatAdam.zero_grad after a backward whose step() was skipped:
         the flat gradient buffer must not be cleared under an all-reduce, and the next backward must find fresh counters)"""
+        if self.record:
+            import time
+            t0 = time.perf_counter()
         for h in self.handles:
             h.wait()
+        if self.record:
+            self.host_wait_ms += (time.perf_counter() - t0) * 1e3
         events = self.ready_events
         self.reset()
         self.last_ready_events = events

@@ -314,6 +314,18 @@ def _amax_hint(device) -> Optional[torch.Tensor]:
     return hint
 
 
+def _reserve_hints(device, n: int) -> None:
+    """make sure the next n slots come from a pool that exists already (created, i.e. zero-filled, under the CURRENT stream): called
+    before work is enqueued on another stream that may draw slots, so that no pool is ever created there"""
+    if not _amax_hint_active():
+        return
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _HINT_POOL.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if pool is None or pool[1] + n > pool[0].shape[0] or (pool[2] and not capturing):
+        _HINT_POOL[key] = [torch.zeros((2048, 2), dtype=torch.float32, device=device), 0, capturing]
+
+
 _ONES = {}
 
 
@@ -1774,14 +1786,36 @@ class _GateConvLstm(Function):
             # The weight gradient stays on the current stream: recorded (deferred to one launch over all applications, issued by the
             # application that runs last in backward) or computed -- it reads what the forward and the cell backwards wrote.
             main, side = torch.cuda.current_stream(), hip.side_stream(dpre.device)
+            # process-global cached objects the side call may draw (single-use scale slots of the hint pool, the constant 1.0) are
+            # created HERE, under the current stream: a pool zero-filled under the side stream would race the current stream's atomicMax
+            # into its slots
+            _reserve_hints(dpre.device, 8)
+            _one(dpre.device)
             ready = torch.cuda.Event()
             ready.record(main)
+            cached_before = set(ctx.wcache) if isinstance(ctx.wcache, dict) else set()
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 dhp, _ = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, True, False, step=ctx.step)
                 done = torch.cuda.Event()
                 done.record(side)
             dhp.record_stream(main)                      # allocated under the side stream, read (and freed) on the current one
+            # ... and the other way round: what the GEMM READS was allocated under the current stream and is freed there -- by autograd, as
+            # soon as this node returns, unless another consumer happens to hold it (xg's fan-in, the deferred weight gradient).  The
+            # caching allocator must not hand those blocks to a current-stream kernel while the 1.3-3.3 ms GEMM is still reading them.
+            rc_ = rows_ctx(ctx.step, h_prev.shape[0])
+            planes = (getattr(dpre, "_sp_cache", None) or {}).get("f16x2")
+            for t_ in (dpre, h_prev, wp, planes.buf if planes is not None else None, planes.scale if planes is not None else None,
+                       rc_.last if rc_ is not None else None):
+                if t_ is not None and t_.is_cuda:
+                    t_.record_stream(side)
+            if isinstance(ctx.wcache, dict):             # a weight operand first built under the side stream may later meet the current one
+                for k_ in set(ctx.wcache) - cached_before:
+                    op_ = ctx.wcache[k_]
+                    if isinstance(op_, SplitOperand):
+                        for t_ in (op_.buf, op_.scale):
+                            if t_ is not None:
+                                t_.record_stream(main)
             events, idx = ctx.h_events
             events[idx] = done
             FUSION_COUNTS["async_dgrad"] += 1

@@ -230,7 +230,9 @@ _side = {}
 
 
 def side_stream(device) -> "torch.cuda.Stream":
-    """one extra HIP stream per device for work nobody waits for until the end of backward (deferred weight gradients)"""
+    """one extra HIP stream per device: in the backward recurrence it carries the h-gate conv's data gradient of decode step t
+    (functional._GateConvLstm.backward) beside the current stream's chain of small launches; the fan-in of h_{t-1}'s gradients
+    (functional._FanOut.backward) waits for the event that launch leaves behind.  Deferred weight gradients run on the CURRENT stream."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _side.get(key)
     if s is None:
@@ -279,6 +281,12 @@ class KernelTimer:
         s.record()
         launch()
         e.record()
+        # a launch enqueued on the side stream runs BESIDE the current stream's small launches: its time includes that contention and is
+        # not comparable with a stand-alone launch of the same kernel -- the key says so ("+side"), bench.py reports it as `beside_chain`
+        cur = torch.cuda.current_stream()
+        sd = _side.get(cur.device.index if cur.device.index is not None else torch.cuda.current_device())
+        if sd is not None and cur.cuda_stream == sd.cuda_stream and isinstance(key, tuple) and key and isinstance(key[0], str):
+            key = (key[0] + "+side",) + tuple(key[1:])
         self.pending.append((key, flops, s, e))
 
     def summary(self):

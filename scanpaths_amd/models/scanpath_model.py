@@ -182,6 +182,19 @@ class ScanpathModel(nn.Module):
         self.last_decode_rows = None          # functional.DecodeRows of the latest decode() with autograd on (see decode)
         self.init_weights()
 
+    # ---- nn.DataParallel (AiR/train.py:169-170; AiR/opts.py:26 makes gpu_ids=[0, 1] the reference's DEFAULT) -------------------------
+    def _replicate_for_data_parallel(self):
+        """torch.nn.parallel.replicate() calls this once per replica when nn.DataParallel runs a forward on MORE than one device.
+        Refused: this model's parameters are views of FlatAdam's flat buffers (optim.py), its kernels write leaf gradients in place and
+        draw scratch from per-process workspaces (hip.workspace) -- thread-per-device replicas inside one process would share all of
+        it.  One process per GPU is the supported form (ddp.py).  A DataParallel wrapper over ONE device never replicates and works."""
+        raise RuntimeError(
+            "scanpaths_amd: this model cannot be replicated by nn.DataParallel (its parameters are views of the optimiser's flat "
+            "buffers and its HIP kernels use per-process workspaces).  Pass a single id in --gpu_ids (the reference's default is "
+            "[0, 1], AiR/opts.py:26), or run one process per GPU: `python -m torch.distributed.run --nproc-per-node N "
+            "--master-addr 127.0.0.1 train.py` with scanpaths_amd.ddp (shard_batch, global_mask_normaliser, broadcast_module_state_) "
+            "and scanpaths_amd.optim.FlatAdam -- see INTEGRATION.md, 'multi-GPU'.")
+
     # ---- init: resnet.py:112-118 (He normal, BN 1/0); mmcv xavier_init (normal) for convs, normal_init(std=0.01) for
     #      Linear (baseline_attention.py:58-65,90-97,126-133,176-185,495-504) ----
     def init_weights(self):
@@ -308,6 +321,48 @@ class ScanpathModel(nn.Module):
         return u_sem, u_spa
 
     # ------------------------------------------------------------------------------------------------
+    def _heads_prepare(self, B, Hm, Wm, dev, tasks=None):
+        """Per-forward operands of predict_head (baseline_attention.py:149-174) behind the 5x5 head convs (:306-309; COCO: the
+        per-sample head selected by task id, ...multihead.py:285-288), composed once: the saliency tap GEMM's weight, the 11x11 composite
+        duration windows per border class, composed biases, the slot -> source-head map."""
+        S = len(self.streams)
+        if self.task == "AiR":
+            head_convs = [self.performance_sal_layer["True"], self.performance_sal_layer["False"]]   # good, poor
+        elif self.task == "OSIE":
+            head_convs = [self.performance_sal_layer]
+        else:
+            head_convs = None
+        nh = S
+        if head_convs is not None:
+            G, cb = self._compose_heads(head_convs)
+            cbt = None
+            nsrc, per_sample = len(head_convs), False
+            hmap = torch.arange(nh, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
+        else:       # COCO: per-sample head selected by task id (...multihead.py:285-288); only the tasks present are composed
+            tl = [int(t) for t in tasks.tolist()]            # host sync, as the reference's int(tasks[index])
+            uniq = sorted(set(tl))
+            G, cbt = self._compose_heads([self.object_sal_layer[self.int2object[t]] for t in uniq])
+            slot = torch.tensor([uniq.index(t) for t in tl], device=dev)
+            cb = cbt.index_select(0, slot).view(B, 1, HC)
+            nsrc, per_sample = len(uniq), True
+            hmap = slot.to(torch.int32).view(B, 1).contiguous()
+        # the composed 5x5 head is never run as a dense conv (csrc/head_direct.hip): the two saliency maps per head come from a
+        # 1x1 "tap partial" GEMM + 25-tap gather, the duration sites from composite 11x11 stride-5 windows per border class
+        Gp = G.permute(0, 2, 3, 1).reshape(nsrc, HC, 25, 512)
+        R = (nsrc * 50 + 63) // 64 * 64
+        Wsal = torch.cat([Gp[:, :2].reshape(nsrc * 50, 512), torch.zeros(R - nsrc * 50, 512, device=dev)], 0).view(R, 512, 1, 1)
+        W11, cbsum = F.compose11(G, cbt if per_sample else cb, nsrc, HC, (Hm, Wm))
+        return dict(nh=nh, nsrc=nsrc, per_sample=per_sample, hmap=hmap, Wsal=Wsal, W11=W11, cbsum=cbsum, cb=cb,
+                    w2=self.object_head.drt_layer_2.weight, b2=self.object_head.drt_layer_2.bias)
+
+    def _heads_step(self, hp, h_sal, h_drt, Wsal, W11, cbsum, cb, w2, b2, step=None):
+        """predict_head on one hidden state (two aliases of it: the saliency path and the duration path each return a gradient):
+        -> logits [nh,B,1+P], amap [nh,B,P], mu [nh,B], sigma2 [nh,B]"""
+        Z2 = F.sal_gather(F.conv2d(h_sal, Wsal, None, pad=0, step=step), hp["hmap"], hp["nh"], hp["nsrc"], step=step)
+        Dpre = F.drt_direct(h_drt, W11, cbsum, hp["hmap"], hp["nh"], step=step)
+        return F.head_finish(Z2, cb, w2, b2, hp["nh"], HC, not self.training, per_sample=hp["per_sample"], dpre=Dpre)
+
+    # ------------------------------------------------------------------------------------------------
     def decode(self, enc, attention_maps, tasks=None):
         """T steps of the attentive ConvLSTM; returns per-head stacks
         logits [nh,B,T,A], mu [nh,B,T], sigma2 [nh,B,T], amap [nh,B,T,P]."""
@@ -339,33 +394,9 @@ class ScanpathModel(nn.Module):
         KP = (9 * S + 3) // 4 * 4
         mvf = F.channel_mean(vfs.pop()).view(B * P)
         u_sem, u_spa = self._attention_vectors()
-        # heads
-        if self.task == "AiR":
-            head_convs = [self.performance_sal_layer["True"], self.performance_sal_layer["False"]]   # good, poor
-        elif self.task == "OSIE":
-            head_convs = [self.performance_sal_layer]
-        else:
-            head_convs = None
-        nh = S
-        if head_convs is not None:
-            G, cb = self._compose_heads(head_convs)
-            nsrc, per_sample = len(head_convs), False
-            hmap = torch.arange(nh, dtype=torch.int32, device=dev).repeat(B, 1).contiguous()
-        else:       # COCO: per-sample head selected by task id (...multihead.py:285-288); only the tasks present are composed
-            tl = [int(t) for t in tasks.tolist()]            # host sync, as the reference's int(tasks[index])
-            uniq = sorted(set(tl))
-            G, cbt = self._compose_heads([self.object_sal_layer[self.int2object[t]] for t in uniq])
-            slot = torch.tensor([uniq.index(t) for t in tl], device=dev)
-            cb = cbt.index_select(0, slot).view(B, 1, HC)
-            nsrc, per_sample = len(uniq), True
-            hmap = slot.to(torch.int32).view(B, 1).contiguous()
-        # the composed 5x5 head is never run as a dense conv (csrc/head_direct.hip): the two saliency maps per head come from a
-        # 1x1 "tap partial" GEMM + 25-tap gather, the duration sites from composite 11x11 stride-5 windows per border class
-        Gp = G.permute(0, 2, 3, 1).reshape(nsrc, HC, 25, 512)
-        R = (nsrc * 50 + 63) // 64 * 64
-        Wsal = torch.cat([Gp[:, :2].reshape(nsrc * 50, 512), torch.zeros(R - nsrc * 50, 512, device=dev)], 0).view(R, 512, 1, 1)
-        W11, cbsum = F.compose11(G, cbt if per_sample else cb, nsrc, HC, (Hm, Wm))
-        w2, b2 = self.object_head.drt_layer_2.weight, self.object_head.drt_layer_2.bias
+        hp = self._heads_prepare(B, Hm, Wm, dev, tasks)
+        nh, nsrc, per_sample, hmap = hp["nh"], hp["nsrc"], hp["per_sample"], hp["hmap"]
+        Wsal, W11, cbsum, cb, w2, b2 = hp["Wsal"], hp["W11"], hp["cbsum"], hp["cb"], hp["w2"], hp["b2"]
         # masked-step sparsity of the backward pass: every step-tagged op below carries this decode's token; the gate at the end of
         # this function fills it from the gradient that reaches the outputs (functional._OutputGate) -- no caller promise involved
         rows = F.DecodeRows() if grad_on_outer else None
@@ -413,7 +444,7 @@ class ScanpathModel(nn.Module):
         zpad = torch.zeros(B, 3 * 512, KP - 9 * S, device=dev) if KP > 9 * S else None
         wh_cache = {}          # split forms of the h-gate weight, shared by the T applications (and their backward)
         if torch.is_grad_enabled() and Wh.requires_grad:
-            wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight-gradient GEMMs run on a side stream, summed in place
+            wh_cache["defer"] = F.DeferredWgrad()      # its T - 1 weight gradients: ONE launch on the current stream at the end of backward
         Xg_t = F.fanout(Xg, T) if (T > 1 and Xg.requires_grad) else (Xg,) * T      # one gradient fan-in pass instead of T-1 adds
         for t_ in range(T):
             t = at(t_)          # (an int that also names this decode: the backward kernels of step t find the row context through it)
@@ -431,10 +462,8 @@ class ScanpathModel(nn.Module):
             # (step=t: under the masked-step sparsity of the backward pass the gradients of step t's heads are exact zeros for the samples
             # whose last loss step is earlier -- their backward kernels and h's fan-in skip those samples, functional.rows_ctx)
             h_sal, h_drt, h = (tuple(F.fanout(h, nuse, step=t)) + (None,))[:3] if h.requires_grad else (h, h, h)
-            Z2 = F.sal_gather(F.conv2d(h_sal, Wsals.pop(), None, pad=0, step=t), hmap, nh, nsrc, step=t)
-            Dpre = F.drt_direct(h_drt, W11s.pop(), cbsums.pop(), hmap, nh, step=t)
-            logits, amap, mu, s2 = F.head_finish(Z2, cbs.pop(), w2s.pop(), b2s.pop(), nh, HC, not self.training,
-                                                 per_sample=per_sample, dpre=Dpre)
+            logits, amap, mu, s2 = self._heads_step(hp, h_sal, h_drt, Wsals.pop(), W11s.pop(), cbsums.pop(), cbs.pop(), w2s.pop(),
+                                                    b2s.pop(), step=t)
             outs["logits"].append(logits)
             outs["amap"].append(amap)
             outs["mu"].append(mu)

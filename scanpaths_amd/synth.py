@@ -19,9 +19,16 @@ import numpy as np
 import torch
 
 
+LENGTH_LAWS = ("uniform_1_T", "uniform_halfT_T", "full_T")
+
+
 def make_batch(task: str, batch: int, height: int, width: int, T: int, seed: int = 0,
-               rank: int = 0) -> Dict[str, torch.Tensor]:
+               rank: int = 0, length_law: str = "uniform_1_T") -> Dict[str, torch.Tensor]:
+    """length_law: distribution of the scanpath length L (the only thing the masked-step sparsity of the backward pass depends on).
+    "uniform_1_T" = SURVEY.md 8(d)'s contract, L ~ U{1..T}; "uniform_halfT_T" (L ~ U{ceil(T/2)..T}) and "full_T" (L = T) are bench.py's
+    sensitivity legs -- every other draw is identical for the same (seed, rank)."""
     assert task in ("AiR", "OSIE", "COCO_Search18")
+    assert length_law in LENGTH_LAWS, length_law
     rng = np.random.Generator(np.random.PCG64(seed * 1000003 + rank))
     Hm, Wm = height // 8, width // 8
     P = Hm * Wm
@@ -34,6 +41,11 @@ def make_batch(task: str, batch: int, height: int, width: int, T: int, seed: int
     out["performances"] = torch.from_numpy(rng.random(batch) < 0.5)
     out["tasks"] = torch.from_numpy(rng.integers(0, 18, size=batch, dtype=np.int64))
     L = rng.integers(1, T + 1, size=batch)
+    if length_law == "uniform_halfT_T":      # (drawn from the same stream position: the other tensors do not change with the law)
+        lo = (T + 1) // 2
+        L = lo + (L - 1) * (T - lo + 1) // T
+    elif length_law == "full_T":
+        L = np.full(batch, T)
     cells = rng.integers(0, P, size=(batch, T))
     scan = np.zeros((batch, T, A), dtype=np.float32)
     amask = np.zeros((batch, T), dtype=np.float32)

@@ -100,6 +100,30 @@ def test_no_cpu_path():
         F.conv2d(torch.zeros(1, 4, 4, 32), torch.zeros(32, 32, 3, 3), None, pad=1)
 
 
+def test_data_parallel_replication_is_refused_with_directions():
+    """The reference wraps the model in nn.DataParallel whenever len(gpu_ids) > 1 (AiR/train.py:169-170) and gpu_ids defaults to
+    [0, 1] (AiR/opts.py:26, mirrored by scanpaths_amd.opts).  Here replication inside one process is refused by the hook
+    torch.nn.parallel.replicate() calls per replica, with a message that names the supported forms; the wrapper itself (which a
+    single-device DataParallel never replicates through) constructs and keeps the reference's attribute access `model.module`."""
+    from scanpaths_amd.models.baseline_attention import baseline
+    from scanpaths_amd.opts import parse_opt
+    assert parse_opt("AiR", []).gpu_ids == [0, 1]                   # the reference's default: the wrap IS the default code path
+    m = baseline(convLSTM_length=1)
+    with pytest.raises(RuntimeError) as ei:
+        m._replicate_for_data_parallel()
+    msg = str(ei.value)
+    for needle in ("nn.DataParallel", "--gpu_ids", "torch.distributed.run", "scanpaths_amd.ddp", "FlatAdam", "INTEGRATION.md"):
+        assert needle in msg, (needle, msg)
+    # replicate() reaches the hook for the ROOT module first: the refusal comes before any replica exists.  torch's own modules
+    # keep their default hook (only the model root refuses), so sub-modules stay usable inside other containers.
+    assert type(m.sal_conv)._replicate_for_data_parallel is torch.nn.Module._replicate_for_data_parallel
+    import inspect
+    from torch.nn.parallel import replicate          # (the call site this hook belongs to exists in the installed torch)
+    assert "_replicate_for_data_parallel()" in inspect.getsource(replicate)
+    w = torch.nn.DataParallel(m, device_ids=None) if not torch.cuda.is_available() else torch.nn.DataParallel(m, device_ids=[0])
+    assert w.module is m
+
+
 def test_opts_flag_surface():
     from scanpaths_amd.opts import parse_opt
     a = parse_opt("AiR", [])
