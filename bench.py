@@ -724,9 +724,17 @@ def main():
         out["metric"] = metric + " [--force-bucketer: RCCL world of one, NOT the headline line]"
     if world == 1 and not args.no_cpu_baseline and args.mode == "train":
         out["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_bucketer:
         torch.distributed.destroy_process_group()
+    # RCCL writes a version banner to the C stdout buffer at initialisation; flushed at process exit it would land BEHIND the JSON line of
+    # a redirected run.  Flush it now: the JSON line is the last thing this process prints.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

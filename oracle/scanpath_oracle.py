@@ -178,14 +178,25 @@ def sal_conv_key_in(sd):
 
 
 def forward(sd, task, images, attention_maps=None, performances=None, tasks=None, *, training, T=16,
-            arch="resnet50", bn_new=None, tap=None) -> Dict[str, torch.Tensor]:
+            arch="resnet50", bn_new=None, tap=None, decode_samples=None, enc_out=None) -> Dict[str, torch.Tensor]:
     """baseline.forward -> training_process / inference.
     AiR: baseline_attention.py:253-493; OSIE: OSIE/models/baseline_attention.py:239-396;
     COCO: COCO_Search18/models/baseline_attention_multihead.py:246-406.
     tap (tests only, a dict): receives the inputs / pre-activations of the ReLUs whose parameters the gradient tests examine for
-    mask flips -- "enc", "sal_conv_pre", per decode step t "h"[t] and, per (head name, t), "sal3_pre" / "drt1_pre"."""
-    n = images.shape[0]
+    mask flips -- "enc", "sal_conv_pre", per decode step t "h"[t] and, per (head name, t), "sal3_pre" / "drt1_pre".
+    decode_samples (tests only, a list of sample indices): the encoder -- the only place where samples meet, through the train-mode
+    BatchNorm statistics -- runs on the WHOLE batch, everything behind it (per-sample in the reference: no BatchNorm, per-sample
+    memories) only on these samples; outputs then have len(decode_samples) rows.  Lets a full-batch check afford the fp64 decoder."""
     x = encoder(sd, images, arch, training, bn_new)
+    if enc_out is not None:                 # (tests only, a dict: receives the encoder output of the whole batch)
+        enc_out["enc"] = x.detach()
+    if decode_samples is not None:
+        idx = torch.as_tensor(list(decode_samples), dtype=torch.long)
+        x, images = x[idx], images[idx]
+        attention_maps = attention_maps[idx] if attention_maps is not None else None
+        performances = performances[idx] if performances is not None else None
+        tasks = tasks[idx] if tasks is not None else None
+    n = images.shape[0]
     vf_pre = _conv(sd, "sal_conv", x, padding=1)
     if tap is not None:
         tap["enc"], tap["sal_conv_pre"] = x.detach(), vf_pre.detach()

@@ -27,6 +27,7 @@ def pytest_collection_modifyitems(config, items):
 
 
 BENCH_PATH_TEST = "test_bench_path_at_320x512_T16_matches_oracle_on_every_step"
+FULL_BATCH_TEST = "test_full_batch_train_forward_at_bs32_320x512_matches_the_oracle"
 
 
 @pytest.hookimpl(trylast=True)
@@ -35,8 +36,9 @@ def pytest_collection_finish(session):
     is part of a GPU session, its oracle runs are started NOW in two worker processes and the test itself is moved to the end of the
     session, so that the host work overlaps with the other GPU tests (VERDICT r4 next #9: the suite at 751 s of the driver's 1200 s)."""
     items = session.items
-    late = [it for it in items if it.name == BENCH_PATH_TEST and not any(m.name == "skip" for m in it.iter_markers())]
-    if not late or session.config.option.collectonly:
+    live = lambda nm: [it for it in items if it.name == nm and not any(m.name == "skip" for m in it.iter_markers())]
+    late, full = live(BENCH_PATH_TEST), live(FULL_BATCH_TEST)
+    if not (late or full) or session.config.option.collectonly:
         return
     try:
         import torch
@@ -44,13 +46,19 @@ def pytest_collection_finish(session):
             return
     except Exception:
         return
-    items[:] = [it for it in items if it not in late] + late
-    if len(items) > 1:                         # (a run of this test alone starts its workers itself)
-        from helpers import start_bench_oracle
-        session.config._bench_oracle = start_bench_oracle(background=True)
+    # the full-batch leg's oracle (fp32 on 32 samples, fp64 encoder + 4 decoded samples: 2-4 minutes of host work) runs beside the
+    # bench-path one; its test comes second to last
+    items[:] = [it for it in items if it not in late and it not in full] + full + late
+    if len(items) > 1:                         # (a run of one of these tests alone starts its workers itself)
+        from helpers import start_bench_oracle, start_full_oracle
+        if late:
+            session.config._bench_oracle = start_bench_oracle(background=True)
+        if full:
+            session.config._full_oracle = start_full_oracle(background=True)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    bo = getattr(session.config, "_bench_oracle", None)
-    if bo is not None:
-        bo[0].shutdown(wait=False, cancel_futures=True)
+    for attr in ("_bench_oracle", "_full_oracle"):
+        bo = getattr(session.config, attr, None)
+        if bo is not None:
+            bo[0].shutdown(wait=False, cancel_futures=True)

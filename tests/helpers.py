@@ -184,3 +184,45 @@ def oracle_bench_case(args):
     grads = {k: v.grad.numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}
     kinks = kink_candidates(sd, tap) if tap is not None else None
     return out, grads, float(loss.detach()), kinks
+
+
+# ---- full-batch parity leg: BASELINE.json config 2's per-GPU workload itself, bs 32 at 320x512, T = 16 -------------
+FULL_CASE = dict(Hm=40, Wm=64, T=16, NB=32, seed=23, H=320, W=512, fp64_samples=(0, 9, 22, 31))
+
+
+def start_full_oracle(background=False):
+    """Two spawned worker processes with the host-side oracle of the full-batch case, TRAIN-mode forward + loss under no_grad:
+      ref32/  fp32, all 32 samples (the reference's own arithmetic at the timed configuration)
+      ref64/  fp64: the encoder on the WHOLE batch (its BatchNorm statistics are where the batch size enters), the decoder -- per-sample
+              in the reference, and 95 % of the literal FLOPs -- on FULL_CASE["fp64_samples"] (oracle.forward decode_samples)
+    Returns (executor, {tag: future}).  ~2-4 minutes of CPU work in the background of the GPU session."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 8
+    threads = max(4, min(32, ncpu // 6)) if background else max(4, min(64, ncpu // 3))
+    ex = cf.ProcessPoolExecutor(2, mp_context=mp.get_context("spawn"))
+    futs = {tag: ex.submit(oracle_full_case, (dn, threads)) for dn, tag in (("float64", "ref64/"), ("float32", "ref32/"))}
+    return ex, futs
+
+
+def oracle_full_case(args):
+    """(runs in a spawned worker process) -> ({output key: float64 array}, loss over the rows computed, encoder output of sample 0)"""
+    import torch
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.synth import make_batch
+    dtname, threads = args
+    torch.set_num_threads(threads)
+    dt = getattr(torch, dtname)
+    c = FULL_CASE
+    b = make_batch("AiR", c["NB"], c["H"], c["W"], c["T"], seed=c["seed"])
+    sd = oracle_state("AiR", "resnet50", c["seed"], c["Hm"], c["Wm"], dtype=dt, family="tame")
+    bd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in b.items()}
+    sub = list(c["fp64_samples"]) if dtname == "float64" else None
+    eo = {}
+    with torch.no_grad():
+        tr = O.forward(sd, "AiR", bd["images"], bd["attention_maps"], bd["performances"], training=True, T=c["T"], enc_out=eo,
+                       decode_samples=sub)
+        rows = {k: (v[sub] if sub is not None else v) for k, v in bd.items() if k in ("scanpaths", "durations", "action_masks", "duration_masks")}
+        loss, la, ld = O.supervised_loss(tr, rows)
+    enc = eo["enc"]
+    return ({k: v.double().numpy() for k, v in tr.items()}, (float(loss), float(la), float(ld)), enc[0].double().numpy())
