@@ -486,8 +486,11 @@ def main():
     hip.TIMER = hip.KernelTimer(min_flops=2e11 * args.batch / 32)    # bracket only the dominant GEMM launches with HIP events
     sync()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        th = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - th          # host time to ENQUEUE the step (no synchronisation inside): how far the host runs ahead
     sync()
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
@@ -693,6 +696,7 @@ def main():
                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
                       "loss": round(float(loss.detach()), 5) if args.mode == "train" else None,
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                      "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
                       "arithmetic": arith,
                       # switches that differ from the package defaults (scanpaths_amd.config; environment variables are honoured
                       # only under SP_ALLOW_ENV_TUNING=1): {} for the headline line

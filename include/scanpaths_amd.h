@@ -28,7 +28,7 @@ extern "C" {
 #define SP_EINVAL (-1)   /* unsupported shape / alignment */
 #define SP_ENULL (-2)    /* required pointer is NULL */
 
-#define SP_ABI_VERSION 2
+#define SP_ABI_VERSION 3
 int sp_abi_version(void);
 
 /* The ONE piece of process-wide state in the product library: sp_set_tuning("amax_reset", 1) tells the launchers that the caller
@@ -352,6 +352,9 @@ int sp_lstm_pointwise_bwd_rows(const float* dh, const float* dc, const float* ga
  * spatial attention score map (:111-124) as small GEMMs. */
 int sp_im2col3x3_1ch(const float* maps, int R, int H, int W, int koff, int ldk, float* col, void* stream);
 int sp_col2im3x3_1ch(const float* dcol, int R, int H, int W, int koff, int ldk, float* dmaps, void* stream);
+/* all S streams in ONE launch: maps [S][R][H][W] -> col [R][H*W][ldk] (columns >= 9 S written as zeros), and the adjoint dmaps [S][R][H][W] */
+int sp_im2col3x3_multi(const float* maps, int S, int R, int H, int W, int ldk, float* col, void* stream);
+int sp_col2im3x3_multi(const float* dcol, int S, int R, int H, int W, int ldk, float* dmaps, void* stream);
 
 /* attention over a growing memory list (semantic_att :77-88 / spatial_att :111-124 after removing the terms that are
  * constant along the softmax axis): score[t][r] = <L[t][r][:], u>; a = softmax_t; mem[r][:] = sum_t a[t][r]*L[t][r][:]
@@ -393,6 +396,21 @@ int sp_head_finish_bwd(const float* dlogits, const float* damap /* nullable, [nh
                        float* ddpre /* nullable out, gradient of dpre; tap columns of dZ / dcb are then not produced */, int zc,
                        void* stream);
 
+/* The two halves of the epilogue separately (round 6).  parts: bit 0 = the saliency half (terminate logit, action map, softmax: what the next
+ * memory update of the decode loop reads, AiR/models/baseline_attention.py:160-166,311-336), bit 1 = the duration half (mu, sigma2, :155-159:
+ * read by nothing inside the recurrence).  The decode loop runs parts = 1 per step and parts = 2 ONCE behind the loop over T x nheads virtual
+ * heads (head (t, i) of B rows; dpre = the sites of all steps from one sp_drt_direct_fwd launch over T x B rows).  Arguments of the half that
+ * is not asked for may be NULL; parts = 3 is sp_head_finish_fwd / _bwd.  parts = 1 writes dcb[0], dcb[1] (others zero), parts = 2 writes
+ * dcb[51] (others zero).  live (nullable, parts & 2): live[hd * B + b] = 1 iff slot hd of row b received a non-zero dmu or dsigma2 -- the
+ * duration sites' backward (sp_drt_direct_bwd_*_live) skips the others: their site gradients are exact zeros. */
+int sp_head_finish_parts_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb, int cb_per_sample,
+                             const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu, float* sigma2, float* drt,
+                             const float* dpre, int zc, int parts, void* stream);
+int sp_head_finish_parts_bwd(const float* dlogits, const float* damap, const float* dmu, const float* dsigma2, const float* logits,
+                             const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz, int nheads, int HC,
+                             const float* w2, int softmax, float* dZ, float* dcb_partial, float* dw2_partial, float* db2_partial,
+                             float* ddpre, int zc, int parts, int* live, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * predict_head without the dense 5x5 GEMM (models/baseline_attention.py:149-158), csrc/head_direct.hip.
  * G physical [nheads*HC][5][5][C] composed head filters (row hd*HC+0/1: sal_layer_2/3 o 5x5, rows +2..+50: the 49 taps of
@@ -419,6 +437,14 @@ int sp_drt_direct_fwd(const float* h, const float* W11, const float* cbsum, cons
                       int nsel, float* Dpre, void* stream);
 int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
                            int accumulate, float* dh, void* stream);
+/* ... with the (row, head slot) pairs whose gradient is exactly zero skipped (bit-identical sums): live (nullable) [nsel][B] from
+ * sp_head_finish_parts_bwd; row_last (nullable): row b -- decode step b / rowB of sample b % rowB when one launch covers several steps, rowB = B
+ * for a per-step launch -- is dead when row_last[b % rowB] < row_step + b / rowB (B % rowB == 0).  Dead rows of dh are written as zeros. */
+int sp_drt_direct_bwd_data_live(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
+                                int accumulate, float* dh, const int* live, const int* row_last, int row_step, int rowB, void* stream);
+int sp_drt_direct_bwd_weight_live(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C, int nsel, int nheads,
+                                  void* workspace, float* dW11, float* dcbsum, const int* live, const int* row_last, int row_step, int rowB,
+                                  void* stream);
 int64_t sp_drt_direct_bwd_weight_workspace(int B, int Hm, int Wm, int C, int nsel);
 int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C, int nsel,
                              int nheads, void* workspace, float* dW11, float* dcbsum, void* stream);

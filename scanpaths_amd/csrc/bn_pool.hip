@@ -645,6 +645,32 @@ __global__ __launch_bounds__(FIN_C * FIN_L) void colsum_final(const double* part
     out[c] = (beta ? out[c] : 0.f) + (float)s;
 }
 
+// Few rows (the decode loop's bias / vector gradients: M = batch or streams x batch rows, 228 partial + final launch pairs per training
+// step): ONE launch -- a thread owns four columns and adds the M rows in row order in fp64 (as the two-stage form accumulates: the
+// fp32 result is the correctly rounded sum either way), four row loads in flight.
+constexpr int COLSUM_SMALL_M = 128;
+__global__ __launch_bounds__(64) void colsum_small_kernel(const float* __restrict__ x, int M, int C, int ld, float* __restrict__ out, int beta) {
+    const int c = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4;
+    if (c >= C) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = 0;
+    for (; r + 3 < M; r += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(x + (int64_t)r * ld + c), v1 = *reinterpret_cast<const float4*>(x + (int64_t)(r + 1) * ld + c);
+        const float4 v2 = *reinterpret_cast<const float4*>(x + (int64_t)(r + 2) * ld + c), v3 = *reinterpret_cast<const float4*>(x + (int64_t)(r + 3) * ld + c);
+        a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
+        a0 += (double)v1.x; a1 += (double)v1.y; a2 += (double)v1.z; a3 += (double)v1.w;
+        a0 += (double)v2.x; a1 += (double)v2.y; a2 += (double)v2.z; a3 += (double)v2.w;
+        a0 += (double)v3.x; a1 += (double)v3.y; a2 += (double)v3.z; a3 += (double)v3.w;
+    }
+    for (; r < M; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)r * ld + c);
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    float4 o = beta ? *reinterpret_cast<const float4*>(out + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x += (float)a0; o.y += (float)a1; o.z += (float)a2; o.w += (float)a3;
+    *reinterpret_cast<float4*>(out + c) = o;
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* x, int64_t M, int C, float scale, float* out) {
     const int lane = threadIdx.x & 63;
@@ -1062,6 +1088,11 @@ extern "C" int sp_colsum(const float* x, int64_t M, int C, int ld, float* out, i
     if (!x || !out || !workspace) return SP_ENULL;
     if (C % 4 || ld % 4 || M <= 0) return SP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (M <= COLSUM_SMALL_M && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((unsigned)sp_cdiv(C, 256)), dim3(64), 0, s, x, (int)M, C, ld, out, beta);
+        SP_LAUNCH_CHECK();
+        return SP_OK;
+    }
     const int G = pick_G(M, C);
     hipLaunchKernelGGL(colsum_partial, dim3((unsigned)sp_cdiv(C, CB), G), dim3(256), 0, s, x, M, C, ld, G, (double*)workspace);
     SP_LAUNCH_CHECK();

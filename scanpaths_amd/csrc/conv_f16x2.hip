@@ -1015,6 +1015,11 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     }
     const float sx_dev = p.sx_vec ? 1.f : p.sx[0], sy_dev = p.sy_vec ? 1.f : p.sy[0];      // requested first, used by the epilogue (see h2_kernel)
     const int co0 = tmi * 256, n0 = tn * 128;
+    // Narrow weight gradients (Co <= 128 on the 256-row tile: the encoder's layer-1 / layer-2 convs): the waves whose 64 output rows lie
+    // beyond Co multiplied zero blocks.  They now skip their fragment reads and MFMAs (scalar branch; their accumulators stay zero and are
+    // never stored).  Waves w and w + 4 share a SIMD and w >> 1 is the row group, so with Co <= 128 every SIMD keeps ONE multiplying wave
+    // instead of two: the matrix time of the tile halves (round 6; the idle waves still issue their LDS-DMA pieces and join the barriers).
+    const bool rows_live = co0 + wm * 64 < p.Co;
     if (p.batched && p.row_last != nullptr && p.row_last[split] < p.row_step) {      // (scalar) this sample's dY is exactly zero
         if (!p.beta) {
             float* o = p.out + (int64_t)split * p.slab_stride;
@@ -1174,6 +1179,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
     f16x8 af[2][2][2], bf[2][2][2];      // [kk][i][plane]
     auto read_group = [&](int stage_, int kk) {
         const unsigned char* st = smem + stage_ * HWSTAGE;
+        if (!rows_live) return;
         if constexpr (!do_lds) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1207,6 +1213,7 @@ __global__ __launch_bounds__(512, 2) void hw_kernel(HWArgs p) {
                 }
             return;
         }
+        if (!rows_live) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll

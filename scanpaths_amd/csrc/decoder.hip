@@ -420,6 +420,43 @@ __global__ __launch_bounds__(256) void im2col1_kernel(const float* maps, int R, 
         col[(((int64_t)r * H + y) * W + x) * ldk + koff + tap] = v;
     }
 }
+// all S streams in one launch: maps [S][R][H][W] -> col [R][H*W][ldk], stream s in columns [9 s, 9 s + 9), columns >= 9 S zero (the decode
+// loop ran a zero-fill and one launch per stream per step); and its adjoint dmaps [S][R][H][W]
+__global__ __launch_bounds__(256) void im2col1_multi_kernel(const float* __restrict__ maps, int S, int R, int H, int W, int ldk, float* __restrict__ col) {
+    const int64_t total = (int64_t)R * H * W * ldk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ldk);
+        int64_t q = i / ldk;
+        const int x = (int)(q % W); q /= W;
+        const int y = (int)(q % H);
+        const int r = (int)(q / H);
+        float v = 0.f;
+        if (k < 9 * S) {
+            const int s = k / 9, tap = k - 9 * s;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = maps[(((int64_t)s * R + r) * H + yy) * W + xx];
+        }
+        col[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void col2im1_multi_kernel(const float* __restrict__ dcol, int S, int R, int H, int W, int ldk, float* __restrict__ dmaps) {
+    const int64_t total = (int64_t)S * R * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t q = i;
+        const int x = (int)(q % W); q /= W;
+        const int y = (int)(q % H); q /= H;
+        const int r = (int)(q % R);
+        const int s = (int)(q / R);
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {          // same order as col2im1_kernel: identical sums
+            const int y0 = y - (tap / 3 - 1), x0 = x - (tap % 3 - 1);
+            if ((unsigned)y0 < (unsigned)H && (unsigned)x0 < (unsigned)W)
+                acc += dcol[(((int64_t)r * H + y0) * W + x0) * ldk + 9 * s + tap];
+        }
+        dmaps[i] = acc;
+    }
+}
 __global__ __launch_bounds__(256) void col2im1_kernel(const float* dcol, int R, int H, int W, int koff, int ldk, float* dmaps) {
     const int64_t total = (int64_t)R * H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -565,7 +602,10 @@ constexpr int MAXS = 256;   // dh*dw upper bound
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, int Hm, int Wm, int ldz, int HC,
                                                        const float* cb, int cb_per_sample, const float* w2,
                                                        const float* b2, int softmax, float* logits, float* amap, float* mu, float* sigma2, float* drt,
-                                                       int dh, int dw, const float* dpre, int zc) {
+                                                       int dh, int dw, const float* dpre, int zc, int parts) {
+    // parts: bit 0 = the saliency part (terminate logit, action map, softmax), bit 1 = the duration part (mu, sigma2).  The decode loop
+    // evaluates bit 0 per step (the action map feeds the next memory update) and bit 1 ONCE for all T steps behind the loop (B = T x
+    // batch rows: nothing of the recurrence depends on it), see models/scanpath_model.py decode()
     __shared__ float sh4[4];
     __shared__ float sdrt[MAXS];
     const int hd = blockIdx.y, b = blockIdx.x;
@@ -574,6 +614,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, in
     const float* c = cb + (cb_per_sample ? ((int64_t)b * gridDim.y + hd) : (int64_t)hd) * HC;
     float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
     float* am = amap + ((int64_t)hd * B + b) * P;
+    if (parts & 1) {
     // terminate logit + action map
     float s0 = 0.f;
     for (int p = threadIdx.x; p < P; p += 256) {
@@ -585,6 +626,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, in
     s0 = block_sum_256(s0, sh4);
     const float yterm = s0 / (float)P + c[0];
     if (threadIdx.x == 0) lg[0] = yterm;
+    }
+    if (parts & 2) {
     // duration branch
     for (int s = threadIdx.x; s < S; s += 256) {
         const int sy = s / dw, sx = s % dw;
@@ -617,7 +660,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* Z, int B, in
         mu[hd * B + b] = t0 + b2[0];
         sigma2[hd * B + b] = expf(t1 + b2[1]);
     }
-    if (softmax) {
+    }
+    if (softmax && (parts & 1)) {
         __syncthreads();   // lg[] written by this block is visible to it after the barrier
         float mx = -INFINITY;
         for (int a = threadIdx.x; a <= P; a += 256) mx = fmaxf(mx, lg[a]);
@@ -647,31 +691,60 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
                                                        const float* drt, int B, int Hm, int Wm, int ldz, int HC,
                                                        const float* w2, int softmax, float* dZ, float* dcb_partial,
                                                        float* dw2_partial, float* db2_partial, int dh, int dw, float* ddpre,
-                                                       int zc) {
+                                                       int zc, int parts, int* live) {
+    // parts: as head_fwd_kernel.  parts == 1: dZ and dcb[0], dcb[1] (the other dcb entries zero), no duration gradients; parts == 2:
+    // ddpre, the dw2 / db2 partials and dcb[IDX_BD] (the other entries zero), no dZ.  live (nullable, parts & 2): live[hd * B + b] = does this
+    // (head slot, row) receive ANY duration gradient -- an exact test on dmu / dsigma2 -- so that the duration sites' backward kernels can
+    // skip the slots whose ddpre is exactly zero (rows behind their last loss step, AiR's unselected head, the step right at a scanpath's end)
     __shared__ float sh4[4];
     __shared__ double sh4d[4];
     __shared__ float sdd[MAXS];
     const int hd = blockIdx.y, b = blockIdx.x, nh = gridDim.y;
     const int P = Hm * Wm, S = dh * dw;
+    float* dcb = dcb_partial + ((int64_t)b * nh + hd) * HC;
+    if (!(parts & 1)) {          // the duration part alone (one launch for all T decode steps: B = T x batch rows)
+        const float dt0 = dmu[hd * B + b];
+        const float dt1 = dsigma2[hd * B + b] * sigma2[hd * B + b];
+        if (live && threadIdx.x == 0) live[hd * B + b] = (dt0 != 0.f || dt1 != 0.f) ? 1 : 0;
+        double sumdd = 0.0;
+        float* pw = dw2_partial + (((int64_t)b * nh + hd) * 2) * S;
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const float dv = drt[((int64_t)hd * B + b) * S + s];
+            const float dd = dv > 0.f ? dt0 * w2[s] + dt1 * w2[S + s] : 0.f;
+            ddpre[((int64_t)hd * B + b) * S + s] = dd;
+            sumdd += (double)dd;
+            pw[s] = dt0 * dv;
+            pw[S + s] = dt1 * dv;
+        }
+        sumdd = block_sum_256_d(sumdd, sh4d);
+        if (threadIdx.x == 0) {
+            db2_partial[((int64_t)b * nh + hd) * 2 + 0] = dt0;
+            db2_partial[((int64_t)b * nh + hd) * 2 + 1] = dt1;
+        }
+        for (int j = threadIdx.x; j < HC; j += 256) dcb[j] = j == IDX_BD ? (float)sumdd : 0.f;
+        return;
+    }
     const float* dl = dlogits + ((int64_t)hd * B + b) * (P + 1);
     const float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
     const float* am = amap + ((int64_t)hd * B + b) * P;
     float* dz = dZ + (int64_t)b * P * ldz + hd * zc;
-    float* dcb = dcb_partial + ((int64_t)b * nh + hd) * HC;
     float dot = 0.f;
     if (softmax) {
         for (int a = threadIdx.x; a <= P; a += 256) dot += lg[a] * dl[a];
         dot = block_sum_256(dot, sh4);
     }
     const float d0 = softmax ? lg[0] * (dl[0] - dot) : dl[0];
-    // duration branch gradients
-    const float dt0 = dmu[hd * B + b];
-    const float dt1 = dsigma2[hd * B + b] * sigma2[hd * B + b];
+    // duration branch gradients (parts & 2)
+    const bool dur = (parts & 2) != 0;
+    const float dt0 = dur ? dmu[hd * B + b] : 0.f;
+    const float dt1 = dur ? dsigma2[hd * B + b] * sigma2[hd * B + b] : 0.f;
+    if (dur && live && threadIdx.x == 0) live[hd * B + b] = (dt0 != 0.f || dt1 != 0.f) ? 1 : 0;
     double sumdd = 0.0;                  // fp64: per-site terms of either sign (drt_layer_1.bias, round 4 per-parameter bars)
     for (int s = threadIdx.x; s < S; s += 256) {
-        const float dv = drt[((int64_t)hd * B + b) * S + s];
+        const float dv = dur ? drt[((int64_t)hd * B + b) * S + s] : 0.f;
         const float dd = dv > 0.f ? dt0 * w2[s] + dt1 * w2[S + s] : 0.f;
         sdd[s] = dd;
+        if (!dur) continue;
         if (ddpre) ddpre[((int64_t)hd * B + b) * S + s] = dd;
         sumdd += (double)dd;
         float* pw = dw2_partial + (((int64_t)b * nh + hd) * 2) * S;
@@ -680,8 +753,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
     }
     sumdd = block_sum_256_d(sumdd, sh4d);   // also a barrier: sdd visible
     if (threadIdx.x == 0) {
-        db2_partial[((int64_t)b * nh + hd) * 2 + 0] = dt0;
-        db2_partial[((int64_t)b * nh + hd) * 2 + 1] = dt1;
+        if (dur) {
+            db2_partial[((int64_t)b * nh + hd) * 2 + 0] = dt0;
+            db2_partial[((int64_t)b * nh + hd) * 2 + 1] = dt1;
+        }
         dcb[0] = d0;
         dcb[IDX_BD] = (float)sumdd;
     }
@@ -689,7 +764,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
     if (threadIdx.x < NTAP) {
         const int ky = threadIdx.x / 7, kx = threadIdx.x % 7;
         double s = 0.0;
-        if (!ddpre)
+        if (!ddpre && dur)
         for (int sy = 0; sy < dh; ++sy) {
             if ((unsigned)(5 * sy - 2 + ky) >= (unsigned)Hm) continue;
             for (int sx = 0; sx < dw; ++sx)
@@ -712,7 +787,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
             if (damap) g += damap[((int64_t)hd * B + b) * P + p];
             v = am[p] > 0.f ? g : 0.f;
             s1 += (double)v;
-        } else if (j < 2 + NTAP && !ddpre) {
+        } else if (j < 2 + NTAP && !ddpre && dur) {
             const int tap = j - 2, ky = tap / 7, kx = tap % 7;
             const int py = p / Wm, px = p % Wm;
             const int ty = py + 2 - ky, tx = px + 2 - kx;
@@ -846,6 +921,21 @@ extern "C" int sp_im2col3x3_1ch(const float* maps, int R, int H, int W, int koff
     return SP_OK;
 }
 
+extern "C" int sp_im2col3x3_multi(const float* maps, int S, int R, int H, int W, int ldk, float* col, void* stream) {
+    if (!maps || !col) return SP_ENULL;
+    if (S < 1 || 9 * S > ldk) return SP_EINVAL;
+    hipLaunchKernelGGL(im2col1_multi_kernel, dim3(ew_blocks((int64_t)R * H * W * ldk)), dim3(256), 0, (hipStream_t)stream, maps, S, R, H, W, ldk, col);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+extern "C" int sp_col2im3x3_multi(const float* dcol, int S, int R, int H, int W, int ldk, float* dmaps, void* stream) {
+    if (!dcol || !dmaps) return SP_ENULL;
+    if (S < 1 || 9 * S > ldk) return SP_EINVAL;
+    hipLaunchKernelGGL(col2im1_multi_kernel, dim3(ew_blocks((int64_t)S * R * H * W)), dim3(256), 0, (hipStream_t)stream, dcol, S, R, H, W, ldk, dmaps);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
+
 extern "C" int sp_col2im3x3_1ch(const float* dcol, int R, int H, int W, int koff, int ldk, float* dmaps, void* stream) {
     if (!dcol || !dmaps) return SP_ENULL;
     if (koff + 9 > ldk) return SP_EINVAL;
@@ -907,34 +997,56 @@ extern "C" int sp_select_rows_bwd(const float* dout, const unsigned char* sel, i
     return SP_OK;
 }
 
-extern "C" int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
-                                  int cb_per_sample, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
-                                  float* sigma2, float* drt, const float* dpre, int zc, void* stream) {
-    if (!Z || !cb || !w2 || !b2 || !logits || !amap || !mu || !sigma2 || !drt) return SP_ENULL;
+extern "C" int sp_head_finish_parts_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
+                                        int cb_per_sample, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
+                                        float* sigma2, float* drt, const float* dpre, int zc, int parts, void* stream) {
+    if (parts < 1 || parts > 3 || B < 1 || nheads < 1) return SP_EINVAL;
+    if (!cb) return SP_ENULL;
+    if ((parts & 1) && (!Z || !logits || !amap)) return SP_ENULL;
+    if ((parts & 2) && (!w2 || !b2 || !mu || !sigma2 || !drt)) return SP_ENULL;
+    if (parts == 2 && !dpre) return SP_ENULL;          // without Z the duration sites come from sp_drt_direct_fwd
     const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
     if (zc <= 0) zc = HC;
-    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1 || zc < 2 || (!dpre && zc < 2 + NTAP) || nheads * zc > ldz) return SP_EINVAL;
+    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1 || zc < 2 || ((parts & 2) && !dpre && zc < 2 + NTAP) || ((parts & 1) && nheads * zc > ldz))
+        return SP_EINVAL;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, Z, B, Hm, Wm, ldz, HC, cb,
                        cb_per_sample, w2, b2,
-                       softmax, logits, amap, mu, sigma2, drt, dh, dw, dpre, zc);
+                       softmax, logits, amap, mu, sigma2, drt, dh, dw, dpre, zc, parts);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
+extern "C" int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz, int nheads, int HC, const float* cb,
+                                  int cb_per_sample, const float* w2, const float* b2, int softmax, float* logits, float* amap, float* mu,
+                                  float* sigma2, float* drt, const float* dpre, int zc, void* stream) {
+    return sp_head_finish_parts_fwd(Z, B, Hm, Wm, ldz, nheads, HC, cb, cb_per_sample, w2, b2, softmax, logits, amap, mu, sigma2, drt, dpre, zc, 3,
+                                    stream);
+}
 
+extern "C" int sp_head_finish_parts_bwd(const float* dlogits, const float* damap, const float* dmu, const float* dsigma2,
+                                        const float* logits,
+                                        const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
+                                        int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
+                                        float* dw2_partial, float* db2_partial, float* ddpre, int zc, int parts, int* live, void* stream) {
+    if (parts < 1 || parts > 3 || B < 1 || nheads < 1) return SP_EINVAL;
+    if (!dcb_partial) return SP_ENULL;
+    if ((parts & 1) && (!dlogits || !logits || !amap || !dZ)) return SP_ENULL;
+    if ((parts & 2) && (!dmu || !dsigma2 || !sigma2 || !drt || !w2 || !dw2_partial || !db2_partial)) return SP_ENULL;
+    if (parts == 2 && !ddpre) return SP_ENULL;
+    const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
+    if (zc <= 0) zc = HC;
+    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1 || zc < 2 || ((parts & 2) && !ddpre && zc < 2 + NTAP) || ((parts & 1) && nheads * zc > ldz))
+        return SP_EINVAL;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, dlogits, damap, dmu, dsigma2, logits,
+                       amap,
+                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw, ddpre, zc, parts, live);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
+}
 extern "C" int sp_head_finish_bwd(const float* dlogits, const float* damap, const float* dmu, const float* dsigma2,
                                   const float* logits,
                                   const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
                                   int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
                                   float* dw2_partial, float* db2_partial, float* ddpre, int zc, void* stream) {
-    if (!dlogits || !dmu || !dsigma2 || !logits || !amap || !sigma2 || !drt || !w2 || !dZ || !dcb_partial || !dw2_partial ||
-        !db2_partial)
-        return SP_ENULL;
-    const int dh = (Hm + 4 - 7) / 5 + 1, dw = (Wm + 4 - 7) / 5 + 1;
-    if (zc <= 0) zc = HC;
-    if (HC < 52 || dh * dw > MAXS || dh < 1 || dw < 1 || zc < 2 || (!ddpre && zc < 2 + NTAP) || nheads * zc > ldz) return SP_EINVAL;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, dlogits, damap, dmu, dsigma2, logits,
-                       amap,
-                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw, ddpre, zc);
-    SP_LAUNCH_CHECK();
-    return SP_OK;
+    return sp_head_finish_parts_bwd(dlogits, damap, dmu, dsigma2, logits, amap, sigma2, drt, B, Hm, Wm, ldz, nheads, HC, w2, softmax, dZ,
+                                    dcb_partial, dw2_partial, db2_partial, ddpre, zc, 3, nullptr, stream);
 }

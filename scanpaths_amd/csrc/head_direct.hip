@@ -166,6 +166,12 @@ __global__ __launch_bounds__(256) void sal_gather_bwd_kernel(const float* __rest
 // group instead of once per sample -- the kernel is bound by those L2 reads.  Per (sample, slot) the sum order is that of the round-2 kernel for INTERIOR sites only: the
 // loop runs over the in-map rectangle of taps, so at border sites a thread's partial sums cover other elements (same value to rounding).
 constexpr int DRT_GB = 4;
+// acc + <a, w> as ONE fixed chain of fused multiply-adds: with the compiler free to fuse (or not) every a * b + c of the unrolled group loop
+// on its own, a row's sum depended -- in the last bit -- on its POSITION in the group of four (found when round 6 evaluated the sites of all
+// decode steps in one launch: rows that changed position differed by one ulp from the per-step launches)
+__device__ __forceinline__ float drt_dot4(const f32x4& a, const f32x4& w, float acc) {
+    return __builtin_fmaf(a[3], w[3], __builtin_fmaf(a[2], w[2], __builtin_fmaf(a[1], w[1], __builtin_fmaf(a[0], w[0], acc))));
+}
 __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ h, const float* __restrict__ W11,
                                                       const float* __restrict__ cbsum, const int* __restrict__ hmap, int B,
                                                       int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
@@ -210,20 +216,20 @@ __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ 
         if (same) {
             const f32x4 w = W4c[src0[0] * wstride + idx];
 #pragma unroll
-            for (int j = 0; j < DRT_GB; ++j) acc0[j] += a[j][0] * w[0] + a[j][1] * w[1] + a[j][2] * w[2] + a[j][3] * w[3];
+            for (int j = 0; j < DRT_GB; ++j) acc0[j] = drt_dot4(a[j], w, acc0[j]);
             if (two) {
                 const f32x4 u = W4c[src1[0] * wstride + idx];
 #pragma unroll
-                for (int j = 0; j < DRT_GB; ++j) acc1[j] += a[j][0] * u[0] + a[j][1] * u[1] + a[j][2] * u[2] + a[j][3] * u[3];
+                for (int j = 0; j < DRT_GB; ++j) acc1[j] = drt_dot4(a[j], u, acc1[j]);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < DRT_GB; ++j) {
                 const f32x4 w = W4c[src0[j] * wstride + idx];
-                acc0[j] += a[j][0] * w[0] + a[j][1] * w[1] + a[j][2] * w[2] + a[j][3] * w[3];
+                acc0[j] = drt_dot4(a[j], w, acc0[j]);
                 if (two) {
                     const f32x4 u = W4c[src1[j] * wstride + idx];
-                    acc1[j] += a[j][0] * u[0] + a[j][1] * u[1] + a[j][2] * u[2] + a[j][3] * u[3];
+                    acc1[j] = drt_dot4(a[j], u, acc1[j]);
                 }
             }
         }
@@ -240,6 +246,17 @@ __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ 
     }
 }
 
+// Which (row, head slot) pairs carry an exactly-zero duration gradient (round 6: the duration branch of ALL T decode steps is evaluated in
+// one launch behind the decode loop, B = T x batch "virtual" rows, row b = decode step b / rowB of sample b % rowB):
+//   row_last (nullable): the sample's last decode step with any loss gradient (functional._OutputGate) -- row b is DEAD when
+//                        row_last[b % rowB] < row_step + b / rowB (per-step launches: rowB = B, i.e. the old row_last[b] < row_step);
+//   live (nullable):     live[i * B + b] = 0 when slot i of row b received dmu == 0 and dsigma2 == 0 exactly (sp_head_finish_parts_bwd):
+//                        AiR's unselected head, the step right at a scanpath's end (action mask on, duration mask off).
+// Skipping them leaves every sum bit-identical (their terms are exact zeros; the reduce order of the others does not change).
+__device__ __forceinline__ bool drt_row_dead(const int* __restrict__ row_last, int row_step, int rowB, int b) {
+    return row_last != nullptr && row_last[b % rowB] < row_step + b / rowB;
+}
+
 // dh[b][q][c] (+)= sum over the sites whose window covers q, over the head slots.  A thread owns (pixel q, channel quad c4) for a
 // GROUP of up to four samples: the up to 9 sites x nsel filter rows it needs are the same for every sample that uses the same
 // source heads, so they are read once per group (the kernel is bound by these L2 reads: 18 float4 of W11 per float4 of dh).
@@ -247,7 +264,9 @@ __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ 
 // workgroup of the h-gate conv's data gradient -- 2 x 216 registers, 148 KB -- that runs on the side stream during these launches)
 __global__ __launch_bounds__(256, 6) void drt_bwd_data_kernel(const float* __restrict__ dD, const float* __restrict__ W11,
                                                            const int* __restrict__ hmap, int B, int C4, int nsel, int ncls,
-                                                           AxisCls ay, AxisCls ax, int accumulate, float* __restrict__ dh) {
+                                                           AxisCls ay, AxisCls ax, int accumulate, float* __restrict__ dh,
+                                                           const int* __restrict__ live, const int* __restrict__ row_last, int row_step,
+                                                           int rowB) {
     const int Hm = ay.len, Wm = ax.len, P = Hm * Wm, S = ay.n * ax.n;
     const f32x4* W4 = reinterpret_cast<const f32x4*>(W11);
     f32x4* O4 = reinterpret_cast<f32x4*>(dh);
@@ -262,18 +281,29 @@ __global__ __launch_bounds__(256, 6) void drt_bwd_data_kernel(const float* __res
         f32x4 acc[DRT_GB];
 #pragma unroll
         for (int j = 0; j < DRT_GB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (row, slot) pairs of this group with an exactly-zero gradient (drt_row_dead / live above): bit (i * DRT_GB + j) of `on`
+        unsigned on = 0;
+        for (int i = 0; i < nsel && i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < DRT_GB; ++j)
+                if (j < nb && !drt_row_dead(row_last, row_step, rowB, b0 + j) && (!live || live[(int64_t)i * B + b0 + j])) on |= 1u << (i * DRT_GB + j);
+        const bool flagged = (live != nullptr || row_last != nullptr) && nsel <= 8;
         const int sy_lo = qy >= 6 ? (qy - 6 + 4) / 5 : 0, sy_hi = min(ay.n - 1, (qy + 4) / 5);
         const int sx_lo = qx >= 6 ? (qx - 6 + 4) / 5 : 0, sx_hi = min(ax.n - 1, (qx + 4) / 5);
+        if (!flagged || on)
         for (int sy = sy_lo; sy <= sy_hi; ++sy)
             for (int sx = sx_lo; sx <= sx_hi; ++sx) {
                 const int v = (qy - 5 * sy + 4) * 11 + (qx - 5 * sx + 4);
                 const int cls = ay.cls[sy] * ax.ncls + ax.cls[sx];
                 for (int i = 0; i < nsel; ++i) {
+                    const unsigned oni = flagged ? (on >> (i * DRT_GB)) & ((1u << DRT_GB) - 1u) : ~0u;
+                    if (!oni) continue;                     // no row of the group has a gradient in this slot: the filter row is not read
                     const int src0 = hmap[b0 * nsel + i];
                     f32x4 w0 = W4[(((int64_t)src0 * ncls + cls) * NV + v) * C4 + c4];
 #pragma unroll
                     for (int j = 0; j < DRT_GB; ++j) {
                         if (j >= nb) break;
+                        if (!((oni >> j) & 1u)) continue;
                         const int b = b0 + j;
                         const float g = dD[((int64_t)i * B + b) * S + sy * ax.n + sx];
                         const int src = hmap[b * nsel + i];
@@ -302,12 +332,19 @@ __global__ __launch_bounds__(256, 6) void drt_bwd_data_kernel(const float* __res
 constexpr int DRT_MAXS = MAXSITE * MAXSITE;
 __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __restrict__ dD, const float* __restrict__ h, int B,
                                                              int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
-                                                             float* __restrict__ slab, const int* __restrict__ row_last, int row_step) {
+                                                             float* __restrict__ slab, const int* __restrict__ row_last, int row_step,
+                                                             const int* __restrict__ live, int rowB) {
     __shared__ unsigned short s_pix[DRT_MAXS];          // (a map has < 65536 pixels: make_axis caps a side at 5 * MAXSITE)
     __shared__ float s_g0[DRT_MAXS], s_g1[DRT_MAXS];
     __shared__ int s_cnt[2];
     const int v = blockIdx.x % NV, cls = blockIdx.x / NV, b = blockIdx.y, i0 = blockIdx.z * 2;
     const bool two = i0 + 1 < nsel;
+    // slots with an exactly-zero gradient (drt_row_dead / live, see drt_bwd_data_kernel): their slabs are neither computed nor written --
+    // drt_slab_reduce_kernel applies the same test and does not read them (block-uniform)
+    const bool rdead = drt_row_dead(row_last, row_step, rowB, b);
+    const bool on0 = !rdead && (!live || live[(int64_t)i0 * B + b]);
+    const bool on1 = two && !rdead && (!live || live[(int64_t)(i0 + 1) * B + b]);
+    if (!on0 && !on1) return;
     const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;
     const int vy = v / 11, vx = v % 11;
     const f32x4* H4 = reinterpret_cast<const f32x4*>(h) + (int64_t)b * Hm * Wm * C4;
@@ -316,13 +353,6 @@ __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __rest
     f32x4* O40 = reinterpret_cast<f32x4*>(slab) + ((((int64_t)b * nsel + i0) * ncls + cls) * NV + v) * C4;
     f32x4* O41 = O40 + (int64_t)ncls * NV * C4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (row_last && row_last[b] < row_step) {      // row sparsity: dD of this sample is exactly zero -> zero slab, nothing read (block-uniform)
-        for (int c4 = tid; c4 < C4; c4 += blockDim.x) {
-            O40[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (two) O41[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        return;
-    }
     int n = 0;
     for (int s0 = 0; s0 < S; s0 += 128) {
         const int s = s0 + tid;
@@ -354,15 +384,16 @@ __global__ __launch_bounds__(128) void drt_bwd_weight_kernel(const float* __rest
                     acc1 += s_g1[k + u] * a[u];
                 }
         }
-        O40[c4] = acc0;
-        if (two) O41[c4] = acc1;
+        if (on0) O40[c4] = acc0;
+        if (on1) O41[c4] = acc1;
     }
 }
 
 // dW11[k] = sum of the slabs whose source head is k, in (b, i) order.  one thread per float4 of dW11.
 __global__ __launch_bounds__(256) void drt_slab_reduce_kernel(const float* __restrict__ slab, const int* __restrict__ hmap,
                                                               int B, int nsel, int nheads, int64_t per_head4,
-                                                              float* __restrict__ dW11) {
+                                                              float* __restrict__ dW11, const int* __restrict__ row_last, int row_step,
+                                                              const int* __restrict__ live, int rowB) {
     const f32x4* S4 = reinterpret_cast<const f32x4*>(slab);
     f32x4* O4 = reinterpret_cast<f32x4*>(dW11);
     const int64_t n = (int64_t)nheads * per_head4;
@@ -370,8 +401,12 @@ __global__ __launch_bounds__(256) void drt_slab_reduce_kernel(const float* __res
         const int k = (int)(t / per_head4);
         const int64_t r = t % per_head4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int bi = 0; bi < B * nsel; ++bi)
-            if (hmap[bi] == k) acc += S4[(int64_t)bi * per_head4 + r];
+        for (int bi = 0; bi < B * nsel; ++bi) {
+            if (hmap[bi] != k) continue;
+            const int b = bi / nsel, i = bi - b * nsel;
+            if (drt_row_dead(row_last, row_step, rowB, b) || (live && !live[(int64_t)i * B + b])) continue;      // slab not written: an exact zero
+            acc += S4[(int64_t)bi * per_head4 + r];
+        }
         O4[t] = acc;
     }
 }
@@ -466,15 +501,21 @@ extern "C" int sp_drt_direct_fwd(const float* h, const float* W11, const float* 
     return SP_OK;
 }
 
-extern "C" int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C,
-                                      int nsel, int accumulate, float* dh, void* stream) {
+extern "C" int sp_drt_direct_bwd_data_live(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C,
+                                           int nsel, int accumulate, float* dh, const int* live, const int* row_last, int row_step, int rowB,
+                                           void* stream) {
     if (!dDpre || !W11 || !hmap || !dh) return SP_ENULL;
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
+    if (row_last && (rowB < 1 || B % rowB)) return SP_EINVAL;          // B = (decode steps) x rowB virtual rows
     hipLaunchKernelGGL(drt_bwd_data_kernel, dim3(ew_grid((int64_t)((B + DRT_GB - 1) / DRT_GB) * Hm * Wm * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       dDpre, W11, hmap, B, C / 4, nsel, ay.ncls * ax.ncls, ay, ax, accumulate, dh);
+                       dDpre, W11, hmap, B, C / 4, nsel, ay.ncls * ax.ncls, ay, ax, accumulate, dh, live, row_last, row_step, row_last ? rowB : B);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+extern "C" int sp_drt_direct_bwd_data(const float* dDpre, const float* W11, const int* hmap, int B, int Hm, int Wm, int C,
+                                      int nsel, int accumulate, float* dh, void* stream) {
+    return sp_drt_direct_bwd_data_live(dDpre, W11, hmap, B, Hm, Wm, C, nsel, accumulate, dh, nullptr, nullptr, 0, B, stream);
 }
 
 extern "C" int64_t sp_drt_direct_bwd_weight_workspace(int B, int Hm, int Wm, int C, int nsel) {
@@ -483,24 +524,31 @@ extern "C" int64_t sp_drt_direct_bwd_weight_workspace(int B, int Hm, int Wm, int
     return (int64_t)B * nsel * ay.ncls * ax.ncls * NV * C * (int64_t)sizeof(float);
 }
 
-extern "C" int sp_drt_direct_bwd_weight_rows(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
-                                             int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, const int* row_last,
-                                             int row_step, void* stream) {
+extern "C" int sp_drt_direct_bwd_weight_live(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
+                                             int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, const int* live,
+                                             const int* row_last, int row_step, int rowB, void* stream) {
     if (!dDpre || !h || !hmap || !workspace || !dW11 || !dcbsum) return SP_ENULL;
     AxisCls ay, ax;
     if (C % 4 || B < 1 || nsel < 1 || nheads < 1 || !make_axis(Hm, ay) || !make_axis(Wm, ax)) return SP_EINVAL;
+    if (row_last && (rowB < 1 || B % rowB)) return SP_EINVAL;
+    if (!row_last) rowB = B;
     const int ncls = ay.ncls * ax.ncls;
     hipLaunchKernelGGL(drt_bwd_weight_kernel, dim3(NV * ncls, B, (nsel + 1) / 2), dim3(128), 0, (hipStream_t)stream, dDpre, h, B, C / 4,
-                       nsel, ncls, ay, ax, (float*)workspace, row_last, row_step);
+                       nsel, ncls, ay, ax, (float*)workspace, row_last, row_step, live, rowB);
     SP_LAUNCH_CHECK();
     const int64_t per_head4 = (int64_t)ncls * NV * (C / 4);
     hipLaunchKernelGGL(drt_slab_reduce_kernel, dim3(ew_grid(nheads * per_head4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, hmap, B, nsel, nheads, per_head4, dW11);
+                       (const float*)workspace, hmap, B, nsel, nheads, per_head4, dW11, row_last, row_step, live, rowB);
     SP_LAUNCH_CHECK();
     hipLaunchKernelGGL(drt_dcbsum_kernel, dim3(ncls, nheads), dim3(64), 0, (hipStream_t)stream, dDpre, hmap, B, nsel, ay, ax,
                        dcbsum);
     SP_LAUNCH_CHECK();
     return SP_OK;
+}
+extern "C" int sp_drt_direct_bwd_weight_rows(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
+                                             int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, const int* row_last,
+                                             int row_step, void* stream) {
+    return sp_drt_direct_bwd_weight_live(dDpre, h, hmap, B, Hm, Wm, C, nsel, nheads, workspace, dW11, dcbsum, nullptr, row_last, row_step, B, stream);
 }
 extern "C" int sp_drt_direct_bwd_weight(const float* dDpre, const float* h, const int* hmap, int B, int Hm, int Wm, int C,
                                         int nsel, int nheads, void* workspace, float* dW11, float* dcbsum, void* stream) {

@@ -102,7 +102,8 @@ def _apply_config():
                       ("LSTM_BWD_SPLIT", "lstm_bwd_split"), ("RANK1_DSP_SPLIT", "rank1_dsp_split"), ("RANK1_DWC_SPLIT", "rank1_dwc_split"),
                       ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
                       ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single"),
-                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad"), ("SKINNY_GEMM", "skinny_gemm"), ("ASYNC_DGRAD", "async_dgrad")):
+                      ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad"), ("SKINNY_GEMM", "skinny_gemm"), ("ASYNC_DGRAD", "async_dgrad"),
+                      ("DRT_BATCHED", "drt_batched")):
         g[name] = bool(c[key])
 
 
@@ -113,7 +114,8 @@ _apply_config()
 FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm": 0, "gateconv_lstm_hplanes": 0,
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
-                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0, "skinny_gemm": 0, "async_dgrad": 0}
+                 "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0, "skinny_gemm": 0, "async_dgrad": 0,
+                 "drt_fwd_batched": 0}
 
 
 # ---- parameter gradients written straight into the optimizer's flat gradient buffer -------------------------------------------------
@@ -1548,7 +1550,8 @@ class _LstmCellRank1(Function):
          pre[b,p,n] = xg + hg + sum_k spcol[b,p,k] * wc[b,n,k]   (n < 3C: the i/f/o gates)
     xg / hg [B,Hm,Wm,4C] (hg may be None at step 0), spcol [B,P,KP], wc [B,3C,KP]."""
     @staticmethod
-    def forward(ctx, xg, hg, c_prev, spcol, wc, step=None):
+    def forward(ctx, xg, hg, c_prev, spcol, wc, step=None, hslot=None):
+        # hslot: (DrtBatch, t) -- the hidden state is written into slot t of the batch's [T, B, Hm, Wm, C] buffer (see DrtBatch)
         ctx.step = step
         xg = xg.contiguous()
         hg = hg.contiguous() if hg is not None else None
@@ -1562,7 +1565,7 @@ class _LstmCellRank1(Function):
         shp = xg.shape[:-1] + (Cc,)
         gates = torch.empty_like(xg)
         c = torch.empty(shp, dtype=torch.float32, device=xg.device)
-        h = torch.empty(shp, dtype=torch.float32, device=xg.device)
+        h = torch.empty(shp, dtype=torch.float32, device=xg.device) if hslot is None else hslot[0].hbuf(hslot[1], c)
         hint = _amax_hint(xg.device)
         check(hip.lib().sp_lstm_rank1_fwd(ptr(xg), ptr(hg), ptr(c_prev), ptr(spcol), ptr(wc), B, P, Cc, KP, ptr(gates), ptr(c),
                                           ptr(h), _hint_ptr(hint), hip.stream()), "sp_lstm_rank1_fwd")
@@ -1583,7 +1586,7 @@ class _LstmCellRank1(Function):
         dpre, dcp, dsp, dwc = _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, ctx.needs_input_grad[3],
                                                    ctx.needs_input_grad[4], ctx.cbounds, skip_fp32=ctx.skip_ok, fan=ctx.fan, step=ctx.step)
         has_hg, has_c = ctx.has
-        return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc, None
+        return dpre, (dpre if has_hg else None), (dcp if has_c else None), dsp, dwc, None, None
 
 
 def _cell_bounds(c_prev, c):
@@ -1689,8 +1692,8 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     return dpre, dcp, dsp, dwc
 
 
-def lstm_cell_rank1(xg, hg, c_prev, spcol, wc, step=None):
-    return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc, step)
+def lstm_cell_rank1(xg, hg, c_prev, spcol, wc, step=None, hslot=None):
+    return _LstmCellRank1.apply(xg, hg, c_prev, spcol, wc, step, hslot)
 
 
 
@@ -1712,7 +1715,7 @@ class _GateConvLstm(Function):
     (sp_gateconv_lstm_f16x2), so the [B,Hm,Wm,4C] h-gate tensor is never materialised.  Backward = _LstmCellRank1's followed by
     _Conv2d's (same kernels as the unfused pair)."""
     @staticmethod
-    def forward(ctx, h_prev, w_h, xg, c_prev, spcol, wc, wcache, step=None):
+    def forward(ctx, h_prev, w_h, xg, c_prev, spcol, wc, wcache, step=None, hslot=None):
         ctx.step = step
         h_prev, xg, c_prev = h_prev.contiguous(), xg.contiguous(), c_prev.contiguous()
         spcol, wc = spcol.contiguous(), wc.contiguous()
@@ -1727,7 +1730,7 @@ class _GateConvLstm(Function):
             raise RuntimeError("scanpaths_amd: the fused gate conv expects the hidden state's operand with a per-tensor scale")
         gates = torch.empty_like(xg)
         c = torch.empty_like(c_prev)
-        h = torch.empty_like(c_prev)
+        h = torch.empty_like(c_prev) if hslot is None else hslot[0].hbuf(hslot[1], c_prev)          # (DrtBatch, t): see _LstmCellRank1
         hint = _amax_hint(xg.device)
         d = ConvDesc(N, H, W_, Ci, Ci, H, W_, Co, Co, KH, KW, 1, 1, 1, 0, KH * KW * Ci, 1.0, 0, 0, 1, 0, 0, 0, 0, None)
         d.w_scale_rows = int(wsplit.kind == "rows")
@@ -1822,14 +1825,14 @@ class _GateConvLstm(Function):
             dw = None
             if ctx.needs_input_grad[1]:
                 _, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, False, True, defer_final=ctx.defer_final, step=ctx.step)
-            return dhp, dw, dpre, dcp, dsp, dwc, None, None
+            return dhp, dw, dpre, dcp, dsp, dwc, None, None, None
         dhp, dw = _conv_backward(h_prev, wp, dpre, xs, 1, 1, 1, ctx.wcache, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                  defer_final=ctx.defer_final, step=ctx.step)
-        return dhp, dw, dpre, dcp, dsp, dwc, None, None
+        return dhp, dw, dpre, dcp, dsp, dwc, None, None, None
 
 
-def gateconv_lstm(h_prev, w_h, xg, c_prev, spcol, wc, wcache=None, step=None):
-    return _GateConvLstm.apply(h_prev, w_h, xg, c_prev, spcol, wc, wcache, step)
+def gateconv_lstm(h_prev, w_h, xg, c_prev, spcol, wc, wcache=None, step=None, hslot=None):
+    return _GateConvLstm.apply(h_prev, w_h, xg, c_prev, spcol, wc, wcache, step, hslot)
 
 
 class _Im2col(Function):
@@ -1838,9 +1841,8 @@ class _Im2col(Function):
     def forward(ctx, maps, KP):
         maps = maps.contiguous()
         S, R, H, W_ = maps.shape
-        col = torch.zeros((R, H * W_, KP), dtype=torch.float32, device=maps.device)
-        for s in range(S):
-            check(hip.lib().sp_im2col3x3_1ch(ptr(maps[s]), R, H, W_, 9 * s, KP, ptr(col), hip.stream()), "sp_im2col3x3_1ch")
+        col = torch.empty((R, H * W_, KP), dtype=torch.float32, device=maps.device)
+        check(hip.lib().sp_im2col3x3_multi(ptr(maps), S, R, H, W_, KP, ptr(col), hip.stream()), "sp_im2col3x3_multi")      # one launch, zero padding columns included
         ctx.shape = (S, R, H, W_, KP)
         return col
 
@@ -1849,8 +1851,7 @@ class _Im2col(Function):
         S, R, H, W_, KP = ctx.shape
         dcol = dcol.contiguous()
         dm = torch.empty((S, R, H, W_), dtype=torch.float32, device=dcol.device)
-        for s in range(S):
-            check(hip.lib().sp_col2im3x3_1ch(ptr(dcol), R, H, W_, 9 * s, KP, ptr(dm[s]), hip.stream()), "sp_col2im3x3_1ch")
+        check(hip.lib().sp_col2im3x3_multi(ptr(dcol), S, R, H, W_, KP, ptr(dm), hip.stream()), "sp_col2im3x3_multi")
         return dm, None
 
 
@@ -2071,6 +2072,45 @@ def head_finish(Z, cb, w2, b2, nheads, HC, softmax, per_sample=False, dpre=None)
     return _HeadFinish.apply(Z, cb, w2, b2, nheads, HC, softmax, per_sample, dpre)
 
 
+class _HeadSal(Function):
+    """The saliency part of predict_head alone (sp_head_finish_parts_*, parts = 1): Z2 [B,Hm,Wm,nh*2] -> logits [nh,B,1+P], amap [nh,B,P].
+    The decode loop evaluates it per step -- the action map feeds the next memory update -- while the duration part (mu, sigma2), which
+    nothing in the recurrence reads, is evaluated once for all T steps behind the loop (drt_heads_batched)."""
+    @staticmethod
+    def forward(ctx, Z, cb, nheads, HC, softmax, per_sample):
+        Z = Z.contiguous()
+        cb = cb.contiguous()
+        B, Hm, Wm, ldz = Z.shape
+        P = Hm * Wm
+        logits = torch.empty((nheads, B, P + 1), dtype=torch.float32, device=Z.device)
+        amap = torch.empty((nheads, B, P), dtype=torch.float32, device=Z.device)
+        check(hip.lib().sp_head_finish_parts_fwd(ptr(Z), B, Hm, Wm, ldz, nheads, HC, ptr(cb), int(per_sample), None, None, int(softmax),
+                                                 ptr(logits), ptr(amap), None, None, None, None, 2, 1, hip.stream()), "sp_head_finish_parts_fwd")
+        ctx.cfg = (B, Hm, Wm, ldz, nheads, HC, softmax, per_sample, tuple(cb.shape))
+        ctx.save_for_backward(logits, amap)
+        return logits, amap
+
+    @staticmethod
+    def backward(ctx, dlogits, damap):
+        B, Hm, Wm, ldz, nheads, HC, softmax, per_sample, cbshape = ctx.cfg
+        logits, amap = ctx.saved_tensors
+        dlogits = dlogits.contiguous() if dlogits is not None else torch.zeros_like(logits)
+        damap = damap.contiguous() if damap is not None else None
+        dZ = torch.empty((B, Hm, Wm, ldz), dtype=torch.float32, device=logits.device)
+        if ldz != nheads * 2:
+            dZ.zero_()
+        dcbp = torch.empty((B, nheads * HC), dtype=torch.float32, device=logits.device)
+        check(hip.lib().sp_head_finish_parts_bwd(ptr(dlogits), ptr(damap), None, None, ptr(logits), ptr(amap), None, None, B, Hm, Wm, ldz,
+                                                 nheads, HC, None, int(softmax), ptr(dZ), ptr(dcbp), None, None, None, 2, 1, None,
+                                                 hip.stream()), "sp_head_finish_parts_bwd")
+        dcb = dcbp.view(cbshape) if per_sample else _colsum_any(dcbp, nheads * HC).view(nheads, HC)
+        return dZ, dcb, None, None, None, None
+
+
+def head_sal(Z, cb, nheads, HC, softmax, per_sample=False):
+    return _HeadSal.apply(Z, cb, nheads, HC, softmax, per_sample)
+
+
 # ---- predict_head without the dense 5x5 GEMM (csrc/head_direct.hip) ---------------------------------------------
 def head_num_classes(Hm: int, Wm: int) -> int:
     n = hip.lib().sp_head_num_classes(Hm, Wm)
@@ -2143,16 +2183,22 @@ def sal_gather(T, hmap, nsel, nsrc, step=None):
 class _DrtDirect(Function):
     """h [B,Hm,Wm,C], W11 [nheads,ncls,121,C], cbsum [nheads,ncls] -> Dpre [nsel,B,dh*dw]"""
     @staticmethod
-    def forward(ctx, h, W11, cbsum, hmap, nsel, step=None):
-        ctx.step = step
+    def forward(ctx, h, W11, cbsum, hmap, nsel, step=None, batch=None):
+        # batch (DrtBatch): the forward values of ALL decode steps are computed in one launch behind the loop (drt_heads_batched): this
+        # node then only reserves the step's output and keeps what its backward -- which stays a per-step launch inside the backward
+        # recurrence, beside the h-gate conv's data gradient -- needs
+        ctx.step, ctx.batch = step, batch
         h = h.contiguous()
         W11 = W11.contiguous()
         cbsum = cbsum.contiguous()
         B, Hm, Wm, C_ = h.shape
         S = ((Hm + 4 - 7) // 5 + 1) * ((Wm + 4 - 7) // 5 + 1)
-        Dpre = torch.empty((nsel, B, S), dtype=torch.float32, device=h.device)
-        check(hip.lib().sp_drt_direct_fwd(ptr(h), ptr(W11), ptr(cbsum), ptr(hmap), B, Hm, Wm, C_, nsel, ptr(Dpre), hip.stream()),
-              "sp_drt_direct_fwd")
+        if batch is None:
+            Dpre = torch.empty((nsel, B, S), dtype=torch.float32, device=h.device)
+            check(hip.lib().sp_drt_direct_fwd(ptr(h), ptr(W11), ptr(cbsum), ptr(hmap), B, Hm, Wm, C_, nsel, ptr(Dpre), hip.stream()),
+                  "sp_drt_direct_fwd")
+        else:
+            ctx.slot, Dpre = batch.add(h, W11, cbsum, hmap, nsel, S)          # this step's slice of the batch's [T, nsel, B, S] buffer
         ctx.cfg = (B, Hm, Wm, C_, nsel, W11.shape[0], tuple(W11.shape), tuple(cbsum.shape))
         ctx.save_for_backward(h, W11, hmap)
         return Dpre
@@ -2164,23 +2210,136 @@ class _DrtDirect(Function):
         dD = dD.contiguous()
         L = hip.lib()
         dh = dW = dcs = None
+        rc = rows_ctx(ctx.step, B)      # samples behind their last loss step: exactly-zero dD -> nothing computed for them, h not read
+        # (slot, sample) pairs whose duration gradient is exactly zero -- AiR's unselected head, the step at a scanpath's end -- as the
+        # batched duration backward found them (drt_heads_batched): skipped like the dead samples, bit-identical sums
+        live = ctx.batch.live_of(ctx.slot) if (ctx.batch is not None and ROW_SPARSITY) else None
+        rl, rs = (ptr(rc.last), int(ctx.step)) if rc is not None else (None, 0)
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(h)
-            check(L.sp_drt_direct_bwd_data(ptr(dD), ptr(W11), ptr(hmap), B, Hm, Wm, C_, nsel, 0, ptr(dh), hip.stream()),
-                  "sp_drt_direct_bwd_data")
+            check(L.sp_drt_direct_bwd_data_live(ptr(dD), ptr(W11), ptr(hmap), B, Hm, Wm, C_, nsel, 0, ptr(dh), ptr(live), rl, rs, B,
+                                                hip.stream()), "sp_drt_direct_bwd_data_live")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dW = torch.empty(wshape, dtype=torch.float32, device=h.device)
             dcs = torch.empty(cshape, dtype=torch.float32, device=h.device)
             ws = hip.workspace(L.sp_drt_direct_bwd_weight_workspace(B, Hm, Wm, C_, nsel), h.device, slot=0)
-            rc = rows_ctx(ctx.step, B)      # samples behind their last loss step: exactly-zero dD -> zero slabs, h not read
-            check(L.sp_drt_direct_bwd_weight_rows(ptr(dD), ptr(h), ptr(hmap), B, Hm, Wm, C_, nsel, nheads, ptr(ws), ptr(dW), ptr(dcs),
-                                                  ptr(rc.last) if rc is not None else None, int(ctx.step) if rc is not None else 0,
-                                                  hip.stream()), "sp_drt_direct_bwd_weight_rows")
-        return dh, dW, dcs, None, None, None
+            check(L.sp_drt_direct_bwd_weight_live(ptr(dD), ptr(h), ptr(hmap), B, Hm, Wm, C_, nsel, nheads, ptr(ws), ptr(dW), ptr(dcs),
+                                                  ptr(live), rl, rs, B, hip.stream()), "sp_drt_direct_bwd_weight_live")
+        return dh, dW, dcs, None, None, None, None
 
 
-def drt_direct(h, W11, cbsum, hmap, nsel, step=None):
-    return _DrtDirect.apply(h, W11, cbsum, hmap, nsel, step)
+def drt_direct(h, W11, cbsum, hmap, nsel, step=None, batch=None):
+    return _DrtDirect.apply(h, W11, cbsum, hmap, nsel, step, batch)
+
+
+class DrtBatch:
+    """The duration sites of ALL decode steps in one forward launch (round 6).  Nothing in the recurrence reads the duration branch of
+    predict_head (AiR/models/baseline_attention.py:155-159: mu and sigma2 only leave the model), but per step its window kernel stood in
+    the serial gap between two fused h-gate launches (112 us of 468, L2-bound).  The decode loop's drt_direct(..., batch=this) nodes only
+    register their operands; drt_heads_batched() then runs sp_drt_direct_fwd ONCE over the T x B hidden states -- contiguous when the cell
+    kernels wrote them into hbuf() -- and the duration part of the head epilogue once over T x nheads virtual heads.  Backward: the batched
+    node turns d(mu), d(sigma2) into the site gradients of every step (one launch) and into `live` flags; the per-step nodes' data / weight
+    gradient launches stay where they were, inside the backward recurrence beside the h-gate conv's data gradient."""
+
+    def __init__(self, T):
+        self.T, self.items, self.live, self.buf, self.D = T, [], None, None, None
+
+    def hbuf(self, t, like):
+        """the slot of decode step t in ONE [T, B, Hm, Wm, C] buffer for the hidden states (cell kernels write h_t there)"""
+        if self.buf is None:
+            self.buf = torch.empty((self.T,) + tuple(like.shape), dtype=torch.float32, device=like.device)
+        return self.buf[t]
+
+    def add(self, h, W11, cbsum, hmap, nsel, S):
+        """register decode step len(items); returns (slot, its [nsel, B, S] slice of the site buffer drt_heads_batched fills)"""
+        if self.D is None:
+            self.D = torch.empty((self.T, nsel, h.shape[0], S), dtype=torch.float32, device=h.device)
+        slot = len(self.items)
+        if slot >= self.T:
+            raise RuntimeError("scanpaths_amd: DrtBatch got more decode steps than it was built for")
+        self.items.append((h, W11, cbsum, hmap, nsel))
+        return slot, self.D[slot]
+
+    def live_of(self, slot):
+        return None if self.live is None else self.live[slot]
+
+
+class _DrtHeadsBatched(Function):
+    """placeholders Dpre_t [nsel,B,S] of the T per-step drt_direct nodes (graph edges; their contents are produced HERE) + cb, w2, b2 ->
+    mu, sigma2 [nsel, B, T]"""
+    @staticmethod
+    def forward(ctx, batch, cb, w2, b2, HC, per_sample, *dpres):
+        items = batch.items
+        Tn = len(items)
+        assert Tn == len(dpres) and Tn >= 1
+        h0, W11, cbsum, hmap, nsel = items[0]
+        B, Hm, Wm, C_ = h0.shape
+        S = dpres[0].shape[-1]
+        dev = h0.device
+        L = hip.lib()
+        hs = [it[0] for it in items]
+        nb = h0.numel() * 4
+        contiguous = all(h.is_contiguous() and h.data_ptr() == hs[0].data_ptr() + t * nb for t, h in enumerate(hs))
+        same_w = all(it[1].data_ptr() == W11.data_ptr() and it[2].data_ptr() == cbsum.data_ptr() for it in items)
+        D = batch.D[:Tn]          # [T, nsel, B, S]: the per-step nodes' outputs are its slices
+        if contiguous and same_w and Tn > 1:
+            Dall = torch.empty((nsel, Tn * B, S), dtype=torch.float32, device=dev)
+            hm = hmap.repeat(Tn, 1).contiguous()
+            check(L.sp_drt_direct_fwd(ptr(hs[0]), ptr(W11), ptr(cbsum), ptr(hm), Tn * B, Hm, Wm, C_, nsel, ptr(Dall), hip.stream()),
+                  "sp_drt_direct_fwd (batched)")
+            D.copy_(Dall.view(nsel, Tn, B, S).permute(1, 0, 2, 3))
+            FUSION_COUNTS["drt_fwd_batched"] += 1
+        else:          # (hidden states that were not written into DrtBatch.hbuf: one launch per step, still behind the loop)
+            for t, (h, w11, cs, hm_, _) in enumerate(items):
+                check(L.sp_drt_direct_fwd(ptr(h.contiguous()), ptr(w11), ptr(cs), ptr(hm_), B, Hm, Wm, C_, nsel, ptr(D[t]), hip.stream()),
+                      "sp_drt_direct_fwd")
+        cb = cb.contiguous()
+        w2c = w2.detach().contiguous()
+        b2 = b2.contiguous()
+        NH = Tn * nsel          # virtual heads (t, i): head (t, i) uses cb[.., i], shared w2 / b2
+        cb_all = (cb.view(B, nsel, HC).repeat(1, Tn, 1) if per_sample else cb.view(nsel, HC).repeat(Tn, 1)).contiguous()
+        mu = torch.empty((NH, B), dtype=torch.float32, device=dev)
+        s2 = torch.empty((NH, B), dtype=torch.float32, device=dev)
+        drt = torch.empty((NH, B, S), dtype=torch.float32, device=dev)
+        check(L.sp_head_finish_parts_fwd(None, B, Hm, Wm, 0, NH, HC, ptr(cb_all), int(per_sample), ptr(w2c), ptr(b2), 0, None, None, ptr(mu),
+                                         ptr(s2), ptr(drt), ptr(D), 2, 2, hip.stream()), "sp_head_finish_parts_fwd (duration)")
+        ctx.batch = batch
+        ctx.cfg = (Tn, nsel, B, Hm, Wm, S, HC, per_sample, tuple(w2.shape), tuple(cb.shape))
+        ctx.save_for_backward(s2, drt, w2c)
+        to_bt = lambda v: v.view(Tn, nsel, B).permute(1, 2, 0).contiguous()          # [nsel, B, T]
+        return to_bt(mu), to_bt(s2)
+
+    @staticmethod
+    def backward(ctx, dmu, ds2):
+        Tn, nsel, B, Hm, Wm, S, HC, per_sample, w2shape, cbshape = ctx.cfg
+        s2, drt, w2c = ctx.saved_tensors
+        dev = s2.device
+        NH = Tn * nsel
+        to_tb = lambda v, ref: (v.permute(2, 0, 1).contiguous().view(NH, B) if v is not None else torch.zeros_like(ref))
+        dmu, ds2 = to_tb(dmu, s2), to_tb(ds2, s2)
+        ddpre = torch.empty((NH, B, S), dtype=torch.float32, device=dev)
+        dcbp = torch.empty((B, NH * HC), dtype=torch.float32, device=dev)
+        dw2p = torch.empty((B, NH * 2 * S), dtype=torch.float32, device=dev)
+        db2p = torch.empty((B, NH * 2), dtype=torch.float32, device=dev)
+        live = torch.empty((NH * B,), dtype=torch.int32, device=dev)
+        check(hip.lib().sp_head_finish_parts_bwd(None, None, ptr(dmu), ptr(ds2), None, None, ptr(s2), ptr(drt), B, Hm, Wm, 0, NH, HC, ptr(w2c), 0,
+                                                 None, ptr(dcbp), ptr(dw2p), ptr(db2p), ptr(ddpre), 2, 2, ptr(live), hip.stream()),
+              "sp_head_finish_parts_bwd (duration)")
+        ctx.batch.live = live.view(Tn, nsel * B)          # row t: the flags [nsel][B] of decode step t's drt_direct node
+        # partial sums over the samples (and the T steps): composed bias (only drt_layer_1.bias' entry is non-zero), drt_layer_2
+        if per_sample:
+            dcb = dcbp.view(B, Tn, nsel * HC).sum(1).view(cbshape)
+        else:
+            dcb = _colsum_any(dcbp, NH * HC).view(Tn, nsel * HC).sum(0).view(cbshape)
+        dw2 = _colsum_any(dw2p, NH * 2 * S).view(NH, 2 * S).sum(0)
+        db2 = _colsum_any(db2p, NH * 2).view(NH, 2).sum(0)
+        dd = ddpre.view(Tn, nsel, B, S)
+        return (None, dcb, dw2.reshape(w2shape), db2.reshape(2), None, None) + tuple(dd[t] for t in range(Tn))
+
+
+def drt_heads_batched(batch: DrtBatch, dpres, cb, w2, b2, HC, per_sample=False):
+    """mu, sigma2 [nsel, B, T] of all decode steps registered with `batch` (see DrtBatch)"""
+    return _DrtHeadsBatched.apply(batch, cb, w2, b2, HC, per_sample, *dpres)
 
 
 # ----------------------------------------------------------------------------------------------------

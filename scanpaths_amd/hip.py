@@ -51,7 +51,7 @@ class WgradDesc(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 2      # = SP_ABI_VERSION of include/scanpaths_amd.h (held equal by tests/test_cpu_host.py)
+ABI_VERSION = 3      # = SP_ABI_VERSION of include/scanpaths_amd.h (held equal by tests/test_cpu_host.py)
 
 # name -> (restype, argtypes); must list every symbol include/scanpaths_amd.h declares
 SIGNATURES = {
@@ -120,6 +120,8 @@ SIGNATURES = {
     "sp_lstm_pointwise_bwd_rows": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
     "sp_im2col3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_col2im3x3_1ch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_im2col3x3_multi": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_col2im3x3_multi": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_listatt_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "sp_listatt_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "sp_mulrelu_fwd": (_I, [_P, _P, _L, _L, _P, _P]),
@@ -129,6 +131,9 @@ SIGNATURES = {
     "sp_head_finish_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "sp_head_finish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I,
                                 _P]),
+    "sp_head_finish_parts_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sp_head_finish_parts_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I,
+                                      _I, _P, _P]),
     "sp_head_num_classes": (_I, [_I, _I]),
     "sp_head_compose11_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sp_head_compose11_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -137,6 +142,8 @@ SIGNATURES = {
     "sp_sal_gather_bwd_rows": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "sp_drt_direct_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sp_drt_direct_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "sp_drt_direct_bwd_data_live": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
+    "sp_drt_direct_bwd_weight_live": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sp_drt_direct_bwd_weight_workspace": (_L, [_I, _I, _I, _I, _I]),
     "sp_drt_direct_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sp_drt_direct_bwd_weight_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),

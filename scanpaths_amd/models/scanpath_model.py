@@ -421,7 +421,14 @@ class ScanpathModel(nn.Module):
         spb, seb = rep(self.spatial_embed.bias, T), rep(self.semantic_embed.bias, T)
         mvfs, u_spas, u_sems = rep(mvf, T), rep(u_spa, T), rep(u_sem, T)
         Wrs = [[w] * T if d is not None else rep(w, T) for w, d in zip(Wr, wr_defer)]
-        Wsals, W11s, cbsums, cbs, w2s, b2s = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T), rep(w2, T), rep(b2, T)
+        # The duration branch of predict_head (:155-159) feeds nothing inside the recurrence: its forward runs ONCE for all T steps behind the
+        # loop (F.DrtBatch / F.drt_heads_batched; config drt_batched), the loop keeps the saliency part whose action map the next memory
+        # update reads.  The per-step backward launches stay inside the backward recurrence.
+        dbatch = F.DrtBatch(T) if F.DRT_BATCHED else None
+        Wsals, W11s, cbsums, cbs = rep(Wsal, T), rep(W11, T), rep(cbsum, T), rep(cb, T + (1 if dbatch is not None else 0))
+        w2s, b2s = (None, None) if dbatch is not None else (rep(w2, T), rep(b2, T))
+        dpres = []
+        sal_cache = {}          # split form of the saliency tap GEMM's weight: produced once per forward, not per decode step
 
         def push(amaps, k):       # amaps [S,B,P]; memory update number k (:277-296 / :317-336)
             # entry k of the two memory lists is stacked by this update and every later one (T - k of them: the update after the
@@ -452,25 +459,33 @@ class ScanpathModel(nn.Module):
             parts = [F.gemm(se[s], Wrs[s].pop(), None, "nk", defer=wr_defer[s]).view(B, 3 * 512, 9) for s in range(S)]
             wc = torch.cat(parts + ([zpad] if zpad is not None else []), 2)
             spcol = F.im2col3x3(sp_mem.view(S, B, Hm, Wm), KP)
+            hslot = (dbatch, t_) if dbatch is not None else None          # h_t goes into slot t of ONE [T, B, Hm, Wm, C] buffer
             if F.gateconv_lstm_fusable(h, Wh, spcol):       # the cell as the epilogue of the h-gate conv: no h-gate tensor
-                h, c = F.gateconv_lstm(h, Wh, Xg_t[t], c, spcol, wc, wh_cache, step=t)
+                h, c = F.gateconv_lstm(h, Wh, Xg_t[t], c, spcol, wc, wh_cache, step=t, hslot=hslot)
             else:
                 hg = F.conv2d(h, Wh, None, pad=1, wcache=wh_cache, step=t) if h is not None else None        # step 0: h == 0
-                h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc, step=t)
+                h, c = F.lstm_cell_rank1(Xg_t[t], hg, c, spcol, wc, step=t, hslot=hslot)
             # h has three consumers (two heads now, the h-gate conv of the next step): one fan-in pass for its gradient
             nuse = 3 if t + 1 < T else 2
             # (step=t: under the masked-step sparsity of the backward pass the gradients of step t's heads are exact zeros for the samples
             # whose last loss step is earlier -- their backward kernels and h's fan-in skip those samples, functional.rows_ctx)
             h_sal, h_drt, h = (tuple(F.fanout(h, nuse, step=t)) + (None,))[:3] if h.requires_grad else (h, h, h)
-            logits, amap, mu, s2 = self._heads_step(hp, h_sal, h_drt, Wsals.pop(), W11s.pop(), cbsums.pop(), cbs.pop(), w2s.pop(),
-                                                    b2s.pop(), step=t)
+            if dbatch is not None:
+                Z2 = F.sal_gather(F.conv2d(h_sal, Wsals.pop(), None, pad=0, step=t, wcache=sal_cache), hmap, nh, nsrc, step=t)
+                logits, amap = F.head_sal(Z2, cbs.pop(), nh, HC, not self.training, per_sample=per_sample)
+                dpres.append(F.drt_direct(h_drt, W11s.pop(), cbsums.pop(), hmap, nh, step=t, batch=dbatch))
+            else:
+                logits, amap, mu, s2 = self._heads_step(hp, h_sal, h_drt, Wsals.pop(), W11s.pop(), cbsums.pop(), cbs.pop(), w2s.pop(),
+                                                        b2s.pop(), step=t)
+                outs["mu"].append(mu)
+                outs["s2"].append(s2)
             outs["logits"].append(logits)
             outs["amap"].append(amap)
-            outs["mu"].append(mu)
-            outs["s2"].append(s2)
             if t + 1 < T:
                 sp_mem, se_mem = push(amap, t + 1)
-        stacks = {k: torch.stack(v, 2) for k, v in outs.items()}
+        stacks = {k: torch.stack(v, 2) for k, v in outs.items() if v}
+        if dbatch is not None:
+            stacks["mu"], stacks["s2"] = F.drt_heads_batched(dbatch, dpres, cbs.pop(), w2, b2, HC, per_sample=per_sample)
         if rows is not None and any(v.requires_grad for v in stacks.values()):
             keys = list(stacks)
             stacks = dict(zip(keys, F.output_gate(rows, [stacks[k] for k in keys])))

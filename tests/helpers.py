@@ -199,7 +199,9 @@ def start_full_oracle(background=False):
     import concurrent.futures as cf
     import multiprocessing as mp
     ncpu = os.cpu_count() or 8
-    threads = max(4, min(32, ncpu // 6)) if background else max(4, min(64, ncpu // 3))
+    # (in the background of a whole session the two runs have ten minutes; with 2 x 42 threads the process-spawning DDP tests of the session
+    # took twice as long)
+    threads = max(4, min(20, ncpu // 12)) if background else max(4, min(64, ncpu // 3))
     ex = cf.ProcessPoolExecutor(2, mp_context=mp.get_context("spawn"))
     futs = {tag: ex.submit(oracle_full_case, (dn, threads)) for dn, tag in (("float64", "ref64/"), ("float32", "ref32/"))}
     return ex, futs

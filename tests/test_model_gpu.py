@@ -843,7 +843,7 @@ def test_data_gradient_on_the_side_stream_is_bit_identical_to_the_serial_backwar
     launches of the memory update's and of step t - 1's heads' backward; its only reader, the fan-in of h_{t-1}'s gradients, waits for the
     event the node left in the fan-out's `events`.  Same kernels, same operands: loss and every parameter gradient must equal the serial
     backward (async_dgrad off) bit for bit -- three repetitions (a missing wait or a buffer handed out too early shows as a difference in
-    some run), sparse and dense row contexts, on the benchmark's kernel path (40x64 map, fused cell, deferred hw2 launch).
+    some run; the frozen-encoder variant below adds four more), sparse and dense row contexts, on the benchmark's kernel path (40x64 map, fused cell, deferred hw2 launch).
     Reference semantics: plain autograd of AiR/models/baseline_attention.py:37-56, 303-336."""
     from scanpaths_amd import functional as F
     from scanpaths_amd.models.loss import supervised_loss
@@ -856,7 +856,7 @@ def test_data_gradient_on_the_side_stream_is_bit_identical_to_the_serial_backwar
     # (COCO_Search18's per-sample heads take 2.3 x as long per run: the sparse context with two repetitions; AiR: both contexts, three)
     for sparse in ((True, False) if task == "AiR" else (True,)):
         monkeypatch.setattr(F, "ROW_SPARSITY", sparse)
-        for rep, use_async in enumerate((False, True, True, True) if task == "AiR" else (False, True, True)):
+        for rep, use_async in enumerate((False, True, True)):
             monkeypatch.setattr(F, "ASYNC_DGRAD", use_async)
             model = _build(meta, 40, 64).train()
             F.reset_fusion_counts()
@@ -914,6 +914,47 @@ def test_side_stream_data_gradient_without_the_accidental_keepers_of_its_operand
         else:
             assert got[0] == ref[0]
             _assert_same_grads(got[1], ref[1])
+
+
+@pytest.mark.parametrize("task", ["AiR", "COCO_Search18"])
+def test_batched_duration_branch_equals_the_per_step_form(task, monkeypatch):
+    """config drt_batched (round 6): the duration sites and the duration half of the head epilogue of ALL decode steps run once behind the decode
+    loop (nothing in the recurrence reads mu / sigma2, AiR/models/baseline_attention.py:155-159, 311-336), the hidden states sit in one
+    [T, B, Hm, Wm, C] buffer; the per-step backward launches skip the (sample, head slot) pairs whose duration gradient is exactly zero
+    (`live` flags of the batched duration backward).  Against the per-step form (config off): every forward output and the loss bit for bit
+    (same kernels on the same rows), every parameter gradient to 2e-6 of its norm (the per-step form sums drt_layer_2's and the composed
+    bias' partials per step and then over the steps, the batched one over all T x B rows at once) -- and bit for bit between its own
+    sparse and dense backward."""
+    from scanpaths_amd import functional as F
+    from scanpaths_amd.models.loss import supervised_loss
+    T = 6
+    meta, b = _sparsity_case(task, T=T)
+    monkeypatch.setattr(F, "COST_M_SCALE", 32.0 / 5)
+    res = {}
+    for batched in (False, True):
+        for sparse in (True, False):
+            monkeypatch.setattr(F, "DRT_BATCHED", batched)
+            monkeypatch.setattr(F, "ROW_SPARSITY", sparse)
+            model = _build(meta, 40, 64).train()
+            F.reset_fusion_counts()
+            pred = _call(model, meta, b)
+            loss, _, _ = supervised_loss(pred, b["scanpaths"], b["durations"], b["action_masks"], b["duration_masks"], 1.0)
+            loss.backward()
+            torch.cuda.synchronize()
+            assert F.FUSION_COUNTS["drt_fwd_batched"] == (1 if batched else 0), F.FUSION_COUNTS
+            res[(batched, sparse)] = ({k: v.detach().clone() for k, v in pred.items()}, float(loss), _grads(model))
+    for sparse in (True, False):
+        pa, la, ga = res[(False, sparse)]
+        pb, lb, gb = res[(True, sparse)]
+        assert la == lb, (la, lb)
+        for k in pa:
+            assert torch.equal(pa[k], pb[k]), k
+        assert ga.keys() == gb.keys()
+        for k in ga:
+            d, n = float((ga[k].double() - gb[k].double()).norm()), float(ga[k].double().norm())
+            assert d <= 2e-6 * max(n, 1e-12), (k, d, n)
+    _assert_same_grads(res[(True, True)][2], res[(True, False)][2])
+    assert res[(True, True)][1] == res[(True, False)][1]
 
 
 def test_state_dict_roundtrip_and_no_cpu_path():

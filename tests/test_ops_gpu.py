@@ -1036,7 +1036,12 @@ def test_c_abi_error_codes():
         hip.ptr(torch.zeros(4))                                                            # CPU tensor: no CPU path
 
 
-@pytest.mark.parametrize("path", ["f16x2", "bf16x3", "fp32_mfma"])
+# (the two non-default back-ends at the FULL benchmark size run with SP_ALL_GPU_TESTS=1: test_conv2d_fwd_bwd and the tame model goldens hold
+# all three back-ends to the same bars on every run; 12 s each of the suite's 650-s budget)
+_all_tests = pytest.mark.skipif(not __import__("os").environ.get("SP_ALL_GPU_TESTS"), reason="non-default back-end at full size; set SP_ALL_GPU_TESTS=1")
+
+
+@pytest.mark.parametrize("path", ["f16x2", pytest.param("bf16x3", marks=_all_tests), pytest.param("fp32_mfma", marks=_all_tests)])
 def test_hgate_conv_at_benchmark_size_vs_fp64(path, monkeypatch):
     """The dominant GEMM of the bench line AT ITS SIZE (BASELINE.json config 2: bs 32, 40x64 map): h-gate conv 3x3 512->2048,
     implicit GEMM M = 81 920, N = 2048, K = 4608 -- forward, data gradient and weight gradient of every back-end against a
