@@ -177,7 +177,18 @@ __global__ __launch_bounds__(256) void drt_fwd_kernel(const float* __restrict__ 
                                                       int C4, int nsel, int ncls, AxisCls ay, AxisCls ax,
                                                       float* __restrict__ Dpre) {
     __shared__ float sh4[4];
-    const int s = blockIdx.x, b0 = blockIdx.y * DRT_GB, i0 = blockIdx.z * 2;
+    // Eight site rows (the 40 x 64 map of the benchmark) on eight XCDs: under the round-robin dispatch the workgroups of one XCD then walk
+    // ONE site row -- sites left to right, then the next group of samples -- whose 11-row windows overlap by 6 of 11 columns, so the x-overlap
+    // (2.2 of the 4.9 reads per element of h) is served from that XCD's L2 instead of the fabric (the launch over all T x B hidden states of
+    // a training step read 12.8 GB fabric-side for 2.7 GB of h: profiles/r06_pmc_hbm_kernels.json).  Speed only; any other map keeps the
+    // plain order.
+    int s = blockIdx.x, gy = blockIdx.y;
+    if (ay.n == 8 && ((gridDim.x * gridDim.y) & 7u) == 0) {
+        const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x, q = bid >> 3;
+        s = (int)(bid & 7u) * ax.n + (int)(q % (unsigned)ax.n);
+        gy = (int)(q / (unsigned)ax.n);
+    }
+    const int b0 = gy * DRT_GB, i0 = blockIdx.z * 2;
     const int nb = min(DRT_GB, B - b0);
     const bool two = i0 + 1 < nsel;
     const int Hm = ay.len, Wm = ax.len, S = ay.n * ax.n;

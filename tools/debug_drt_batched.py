@@ -37,3 +37,26 @@ with torch.no_grad():
         D1 = F.drt_direct(h, W11, cbsum, hmap, nsel)
         print("step", t, "Dpre diff", (D1 - db.D[t]).abs().max().item(), "n", int((D1 != db.D[t]).sum()), "h contiguous in buf",
               h.data_ptr() == db.buf[t].data_ptr())
+
+# ---- timing of the one-launch site kernel at the benchmark size (T x B = 512 hidden states of 40 x 64 x 512) --------------------------------
+if len(sys.argv) > 2 and sys.argv[2] == "time":
+    from scanpaths_amd import hip
+    L = hip.lib()
+    Tn, B, Hm, Wm, C = 16, 32, 40, 64, 512
+    h = torch.randn(Tn * B, Hm, Wm, C, device=DEV)
+    ncls = L.sp_head_num_classes(Hm, Wm)
+    W11 = torch.randn(2, ncls, 121, C, device=DEV) * 0.01
+    cbsum = torch.zeros(2, ncls, device=DEV)
+    hmap = torch.arange(2, dtype=torch.int32, device=DEV).repeat(Tn * B, 1).contiguous()
+    S = 8 * 13
+    D = torch.empty(2, Tn * B, S, device=DEV)
+    for nb in (Tn * B, B):
+        for _ in range(2):
+            hip.check(L.sp_drt_direct_fwd(hip.ptr(h), hip.ptr(W11), hip.ptr(cbsum), hip.ptr(hmap), nb, Hm, Wm, C, 2, hip.ptr(D), hip.stream()), "f")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            hip.check(L.sp_drt_direct_fwd(hip.ptr(h), hip.ptr(W11), hip.ptr(cbsum), hip.ptr(hmap), nb, Hm, Wm, C, 2, hip.ptr(D), hip.stream()), "f")
+        e1.record(); torch.cuda.synchronize()
+        print(f"sp_drt_direct_fwd rows {nb}: {e0.elapsed_time(e1) / 5 * 1e3:.1f} us per launch")
