@@ -206,6 +206,18 @@ int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hsplit, const floa
                            void* hout_planes /* nullable: h_out also as a split operand (2*B*P*C fp16 + 64 zero bytes), scale from */,
                            float* hout_scale /* [2] {scale, bound} */, float hout_bound /* >= max|h_out|: t + 1 after t + 1 steps */,
                            void* stream);
+/* Both gradients of the ConvLSTM's rank-1 gate term from ONE pass over the gate gradient (round 6; AiR/models/baseline_attention.py:40-50):
+ *   dsp[b][p][k] = sum_{n < N3} dpre[b][p][n] * wc[b][n][k]        dwc[b][n][k] = sum_p dpre[b][p][n] * spcol[b][p][k]
+ * dpre_planes: the 2xfp16 split operand of the gate gradient [B*P][ldy] (ldy >= N3 channels per row) with its scalar scale; wcT_planes: the
+ * split operand of wc transposed, rows (b, k) = [B*KP][N3], one scale per row (sp_split2_f16_rows); spcol fp32 [B][P][KP]; outputs fp32.
+ * KP in {12, 20}, P % 32 == 0, N3 % 256 == 0 (sp_rank1_grads_applies); workspace >= sp_rank1_grads_workspace bytes (pixel-chunk partials of dwc,
+ * reduced in chunk order: run-to-run identical).  row_last (nullable): samples with row_last[b] < row_step have an exactly-zero dpre: zeros, rows not read.
+ * Replaces one batched sp_conv_igemm_f16x2 + one batched sp_conv_wgrad_f16x2 launch (each re-read the planes) and their operand preparation. */
+int sp_rank1_grads_applies(int B, int P, int N3, int KP, int ldy);
+int64_t sp_rank1_grads_workspace(int B, int P, int N3, int KP);
+int sp_rank1_grads_f16x2(const void* dpre_planes, const float* dpre_scale, int ldy, const void* wcT_planes, const float* wcT_row_scale,
+                         const float* spcol, int B, int P, int N3, int KP, float* dsp, float* dwc, void* workspace, const int* row_last,
+                         int row_step, void* stream);
 
 
 /* column sums of a row-major [M][C] matrix (ld = row stride): out[c] = beta*out[c] + sum_m x[m][c]

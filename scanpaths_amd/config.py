@@ -17,10 +17,10 @@ split_scheme      SP_SPLIT_SCHEME = f16x2 | bf16x3 | f16x1      GEMM back-end: 2
 use_split         SP_NO_SPLIT=1 -> False                        False: every GEMM on the fp32 MFMA kernels
 library           SP_LIBRARY = timing                           "timing": libscanpaths_amd_timing.so (wrong-result timing modes; tools only)
 fused_amax, grad_merge, bn_split, bn_skip_dx, bn_skip_z, lstm_bwd_split, rank1_dsp_split, rank1_dwc_split, lstm_skip_dpre,
-fuse_gate_lstm, lstm_h_planes, defer_wgrad, channel_scales, hw2_single, row_sparsity, direct_grad, skinny_gemm, async_dgrad, drt_batched      fusion switches (SP_NO_AMAX_HINT, SP_GRAD_MERGE, SP_BN_SPLIT, SP_BN_SKIP_DX,
+fuse_gate_lstm, lstm_h_planes, defer_wgrad, channel_scales, hw2_single, row_sparsity, direct_grad, skinny_gemm, async_dgrad, drt_batched, rank1_fused      fusion switches (SP_NO_AMAX_HINT, SP_GRAD_MERGE, SP_BN_SPLIT, SP_BN_SKIP_DX,
                                                                SP_BN_SKIP_Z, SP_LSTM_BWD_SPLIT, SP_RANK1_DSP_SPLIT, SP_RANK1_DWC_SPLIT,
                                                                SP_LSTM_SKIP_DPRE, SP_FUSE_LSTM, SP_LSTM_H_PLANES, SP_DEFER_WGRAD,
-                                                               SP_CHANNEL_SCALES, SP_HW2_SINGLE, SP_ROW_SPARSITY, SP_DIRECT_GRAD, SP_SKINNY_GEMM, SP_ASYNC_DGRAD, SP_DRT_BATCHED: "0" switches off); all default on, results agree to rounding
+                                                               SP_CHANNEL_SCALES, SP_HW2_SINGLE, SP_ROW_SPARSITY, SP_DIRECT_GRAD, SP_SKINNY_GEMM, SP_ASYNC_DGRAD, SP_DRT_BATCHED, SP_RANK1_FUSED: "0" switches off); all default on, results agree to rounding
 """
 from __future__ import annotations
 
@@ -32,7 +32,7 @@ DEFAULTS = {
     "fused_amax": True, "grad_merge": True, "bn_split": True, "bn_skip_dx": True, "bn_skip_z": True, "lstm_bwd_split": True,
     "rank1_dsp_split": True, "rank1_dwc_split": True, "lstm_skip_dpre": True, "fuse_gate_lstm": True, "lstm_h_planes": True,
     "defer_wgrad": True, "channel_scales": True, "hw2_single": True, "row_sparsity": True, "direct_grad": True, "skinny_gemm": True, "async_dgrad": True,
-    "drt_batched": True,
+    "drt_batched": True, "rank1_fused": True,
 }
 _off = lambda v: v != "0"
 _ENV = {       # env name -> (switch, parser)
@@ -43,7 +43,7 @@ _ENV = {       # env name -> (switch, parser)
     "SP_RANK1_DWC_SPLIT": ("rank1_dwc_split", _off), "SP_LSTM_SKIP_DPRE": ("lstm_skip_dpre", _off), "SP_FUSE_LSTM": ("fuse_gate_lstm", _off),
     "SP_LSTM_H_PLANES": ("lstm_h_planes", _off), "SP_DEFER_WGRAD": ("defer_wgrad", _off), "SP_CHANNEL_SCALES": ("channel_scales", _off),
     "SP_HW2_SINGLE": ("hw2_single", _off), "SP_ROW_SPARSITY": ("row_sparsity", _off), "SP_DIRECT_GRAD": ("direct_grad", _off), "SP_SKINNY_GEMM": ("skinny_gemm", _off),
-    "SP_ASYNC_DGRAD": ("async_dgrad", _off), "SP_DRT_BATCHED": ("drt_batched", _off),
+    "SP_ASYNC_DGRAD": ("async_dgrad", _off), "SP_DRT_BATCHED": ("drt_batched", _off), "SP_RANK1_FUSED": ("rank1_fused", _off),
 }
 # timing-library knobs (sp_set_tuning; honoured by libscanpaths_amd_timing.so only): passed through under SP_ALLOW_ENV_TUNING=1
 TIMING_KNOBS = {"SP_H2_DBG": b"h2_dbg", "SP_HW_DBG": b"hw_dbg", "SP_B3_DBG": b"b3_dbg", "SP_HW_SPLITS": b"hw_splits", "SP_H2_HALO": b"h2_halo",

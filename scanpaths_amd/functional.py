@@ -103,7 +103,7 @@ def _apply_config():
                       ("LSTM_SKIP_DPRE", "lstm_skip_dpre"), ("FUSE_GATE_LSTM", "fuse_gate_lstm"), ("LSTM_H_PLANES", "lstm_h_planes"),
                       ("DEFER_WGRAD", "defer_wgrad"), ("CHANNEL_SCALES", "channel_scales"), ("HW2_SINGLE", "hw2_single"),
                       ("ROW_SPARSITY", "row_sparsity"), ("DIRECT_GRAD", "direct_grad"), ("SKINNY_GEMM", "skinny_gemm"), ("ASYNC_DGRAD", "async_dgrad"),
-                      ("DRT_BATCHED", "drt_batched")):
+                      ("DRT_BATCHED", "drt_batched"), ("RANK1_FUSED", "rank1_fused")):
         g[name] = bool(c[key])
 
 
@@ -115,7 +115,7 @@ FUSION_COUNTS = {"lstm_bwd_split": 0, "bn_bwd_split_operand": 0, "gateconv_lstm"
                  "bn_fwd_split": 0, "bn_fwd_split_operand": 0, "bn_skip_z": 0, "bn_bwd_split": 0, "bn_skip_dx": 0,
                  "conv_bn_stats": 0, "grad_merge": 0, "rank1_dsp_split": 0, "rank1_dwc_split": 0, "lstm_skip_dpre": 0, "wgrad_multi": 0,
                  "row_sparse_bwd": 0, "fan_in_rows": 0, "direct_grad": 0, "output_gate": 0, "skinny_gemm": 0, "async_dgrad": 0,
-                 "drt_fwd_batched": 0}
+                 "drt_fwd_batched": 0, "rank1_fused": 0}
 
 
 # ---- parameter gradients written straight into the optimizer's flat gradient buffer -------------------------------------------------
@@ -1650,6 +1650,21 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
     if chint is not None:
         dcp._sp_amax = chint               # max|dc_prev|: the previous step's cell backward bounds its operand with it
     dsp = dwc = None
+    L = hip.lib()
+    if (need_dsp and need_dwc and emit and RANK1_FUSED and RANK1_DSP_SPLIT and RANK1_DWC_SPLIT and rank1_split_ok
+            and L.sp_rank1_grads_applies(B, P, N3, KP, C4)):
+        # both gradients of the rank-1 gate term from ONE pass over the split dpre the cell backward just wrote (csrc/rank1_grads.hip): dsp on
+        # the matrix pipe against the split form of wc^T, dwc on the vector pipe from the same LDS tiles, spcol as it is -- instead of two
+        # launches of the big GEMM kernels that each re-read the 503 MB of planes, and six small launches preparing their operands
+        FUSION_COUNTS["rank1_fused"] += 1
+        ys = dpre._sp_cache["f16x2"]
+        ws = split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")   # [B][KP][3C]: K contiguous, one scale per row
+        dsp, dwc = torch.empty_like(spcol), torch.empty_like(wc)
+        wsp = hip.workspace(L.sp_rank1_grads_workspace(B, P, N3, KP), dpre.device, slot=0)
+        check(L.sp_rank1_grads_f16x2(ptr(ys.buf), ptr(ys.scale), C4, ptr(ws.buf), ptr(ws.scale), ptr(spcol), B, P, N3, KP, ptr(dsp), ptr(dwc),
+                                     ptr(wsp), ptr(rc.last) if rc is not None else None, int(step) if rc is not None else 0, hip.stream()),
+              "sp_rank1_grads_f16x2")
+        return dpre, dcp, dsp, dwc
     if need_dsp:
         dsp = torch.empty_like(spcol)
         if emit and RANK1_DSP_SPLIT and rank1_split_ok:
@@ -1670,7 +1685,6 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
                    nbatch=B, sX=P * C4, sW=N3 * KP, sC=P * KP)
     if need_dwc:
         dwc = torch.empty_like(wc)
-        L = hip.lib()
         if emit and RANK1_DWC_SPLIT and rank1_split_ok:
             # filter gradient of the rank-1 gate term, dwc[b] = dpre[b][:, :3C]^T x spcol[b]: one TN GEMM per sample (K = the sample's
             # pixels) on the split dpre; spcol's KP tap columns are padded to 32 for the 16-channel groups of the split operand, the

@@ -75,6 +75,9 @@ SIGNATURES = {
     "sp_conv_igemm_f16x1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x1": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sp_gateconv_lstm_f16x2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "sp_rank1_grads_applies": (_I, [_I, _I, _I, _I, _I]),
+    "sp_rank1_grads_workspace": (_L, [_I, _I, _I, _I]),
+    "sp_rank1_grads_f16x2": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "sp_conv_igemm_bf16x3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sp_conv_wgrad_bf16x3_workspace": (_L, [C.POINTER(WgradDesc)]),
     "sp_conv_wgrad_bf16x3": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P]),

@@ -525,8 +525,8 @@ def test_air_320x512_matches_oracle():
 
 
 BENCH_PATH_COUNTERS = ("gateconv_lstm", "gateconv_lstm_hplanes", "lstm_bwd_split", "bn_fwd_split", "bn_fwd_split_operand", "bn_skip_z",
-                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split", "lstm_skip_dpre",
-                       "wgrad_multi", "row_sparse_bwd")
+                       "bn_bwd_split", "bn_bwd_split_operand", "bn_skip_dx", "conv_bn_stats", "grad_merge", "rank1_dsp_split", "rank1_dwc_split", "rank1_fused",
+                       "lstm_skip_dpre", "wgrad_multi", "row_sparse_bwd")
 
 
 def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch, request):
@@ -559,7 +559,9 @@ def test_bench_path_at_320x512_T16_matches_oracle_on_every_step(monkeypatch, req
     torch.cuda.empty_cache()
     assert bench_counts["gateconv_lstm"] == T - 1 and bench_counts["gateconv_lstm_hplanes"] == T - 1, bench_counts
     assert bench_counts["lstm_bwd_split"] == T and bench_counts["bn_skip_z"] > 0 and bench_counts["bn_skip_dx"] > 0, bench_counts
-    assert bench_counts["rank1_dsp_split"] == T and bench_counts["rank1_dwc_split"] == T and bench_counts["lstm_skip_dpre"] == T, bench_counts
+    r1 = T if F.RANK1_FUSED else 0                               # both rank-1 gradients in one launch, or the two split GEMMs
+    assert bench_counts["rank1_fused"] == r1 and bench_counts["rank1_dsp_split"] == T - r1 and bench_counts["rank1_dwc_split"] == T - r1, bench_counts
+    assert bench_counts["lstm_skip_dpre"] == T, bench_counts
     assert bench_counts["wgrad_multi"] >= 1, bench_counts          # the T - 1 weight gradients of the h-gate conv in ONE launch (hw2_kernel)
     assert bench_counts["row_sparse_bwd"] == 1, bench_counts       # ... which skips the samples behind their last masked-in step
 

@@ -1229,3 +1229,51 @@ def test_rows_last_reads_the_horizon_off_the_output_gradients():
     am2[0, 5, 2, 0] = 1.0
     (g2[1] * am2.to(dev)).sum().backward()
     assert tok2.rc.last.tolist() == [-1, -1, -1, -1, -1, 2, -1] and outs2[0].grad is None
+
+
+@pytest.mark.parametrize("KP,B,P,Cc", [(20, 3, 256, 256), (12, 2, 512, 256), (20, 2, 2560, 512)])
+def test_rank1_grads_kernel_gives_both_gradients_of_the_rank1_gate_term(KP, B, P, Cc):
+    """csrc/rank1_grads.hip: dsp[b] = dpre[b][:, :3C] x wc[b] and dwc[b] = dpre[b][:, :3C]^T x spcol[b] from ONE pass over the 2xfp16
+    split gate gradient -- against fp64 on the operand the kernel actually reads (decoded planes: the split itself is tested
+    elsewhere), against the two GEMM launches it replaces, with dead samples (row_last) giving exact zeros and run-to-run identical.
+    Reference semantics: the rank-1 gate term of AiR/models/baseline_attention.py:40-50 (conv of the spatial memory per sample)."""
+    from scanpaths_amd import functional as F, hip
+    if F.SPLIT_SCHEME != "f16x2" or not F.USE_BF16X3:
+        pytest.skip("2xfp16 back-end not active")
+    dev, L = _dev(), hip.lib()
+    C4, N3 = 4 * Cc, 3 * Cc
+    assert L.sp_rank1_grads_applies(B, P, N3, KP, C4) == 1
+    assert L.sp_rank1_grads_applies(B, P + 8, N3, KP, C4) == 0 and L.sp_rank1_grads_applies(B, P, N3, 16, C4) == 0
+    dpre = (_rand(B, P, C4, seed=31) * torch.exp(_rand(B, P, 1, seed=32))).to(dev)       # rows of different magnitudes
+    spcol, wc = _rand(B, P, KP, seed=33).to(dev), _rand(B, N3, KP, seed=34, scale=0.2).to(dev)
+    ys = F.split_op(dpre)
+    ws = F.split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")
+    yd = _decode_split(ys, dpre.shape).double()[:, :, :N3]
+    assert float((yd - dpre[:, :, :N3].double()).abs().max()) <= 2.0 ** -20 * float(dpre.abs().max())
+    ref_dsp, ref_dwc = torch.bmm(yd, wc.double()), torch.bmm(yd.transpose(1, 2), spcol.double())
+    wsp = torch.empty(L.sp_rank1_grads_workspace(B, P, N3, KP), dtype=torch.uint8, device=dev)
+
+    def run(last=None, step=0):
+        dsp, dwc = torch.full_like(spcol, float("nan")), torch.full_like(wc, float("nan"))
+        F.check(L.sp_rank1_grads_f16x2(hip.ptr(ys.buf), hip.ptr(ys.scale), C4, hip.ptr(ws.buf), hip.ptr(ws.scale), hip.ptr(spcol), B, P, N3, KP,
+                                       hip.ptr(dsp), hip.ptr(dwc), hip.ptr(wsp), hip.ptr(last) if last is not None else None, step,
+                                       hip.stream()), "sp_rank1_grads_f16x2")
+        torch.cuda.synchronize()
+        return dsp, dwc
+    dsp, dwc = run()
+    # dsp: 3-product split GEMM (the weight operand is split per row: 2^-21 relative of the row's largest product sum); dwc: fp32
+    # accumulation over P pixels of exact operands
+    e_dsp = float((dsp.double() - ref_dsp).abs().max()) / float(ref_dsp.abs().max())
+    e_dwc = float((dwc.double() - ref_dwc).abs().max()) / float(ref_dwc.abs().max())
+    print(f"rank1_grads KP={KP} P={P} C={Cc}: dsp rel err {e_dsp:.2e}  dwc rel err {e_dwc:.2e}")
+    assert e_dsp <= 4e-6 and e_dwc <= 4e-6, (e_dsp, e_dwc)
+    d2, w2 = run()
+    assert torch.equal(d2, dsp) and torch.equal(w2, dwc)
+    # dead samples: sample 0 has no loss gradient at step 5 (its planes are not read: poison them)
+    last = torch.tensor([2] + [9] * (B - 1), dtype=torch.int32, device=dev)
+    keep = ys.buf[:2 * P * C4].clone()
+    ys.buf[:2 * P * C4] = float("nan")
+    d3, w3 = run(last, 5)
+    ys.buf[:2 * P * C4] = keep
+    assert float(d3[0].abs().max()) == 0.0 and float(w3[0].abs().max()) == 0.0
+    assert torch.equal(d3[1:], dsp[1:]) and torch.equal(w3[1:], dwc[1:])

@@ -1,5 +1,7 @@
-"""The cell backward's two rank-1 gradients at the benchmark size (B 32, P 2560, 3C = 1536 of 4C = 2048 channels, KP 20):
-spatial-tap gradient through the fp32-MFMA batched GEMM vs the batched split GEMM; the filter gradient kernel.   python3 tools/bench_rank1.py"""
+#!/usr/bin/env python3
+"""The two gradients of the rank-1 gate term at the benchmark shape (B 32, P 2560, 3C 1536, KP 20), alone on the GPU: the fused kernel
+(csrc/rank1_grads.hip) against the two batched split GEMMs it replaces, with and without their operand preparation, on a full batch and
+on batches where only 24 / 16 / 8 samples still carry loss gradient (row_last).  One JSON line (us per call)."""
 import ctypes as C
 import json
 import os
@@ -7,74 +9,75 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from scanpaths_amd import functional as F, hip  # noqa: E402
-
-dev = torch.device("cuda:0")
-B, P, N3, C4, KP = 32, 2560, 1536, 2048, 20
-g = torch.Generator().manual_seed(0)
-dpre = torch.randn(B * P, C4, generator=g).to(dev)
-wc = (torch.randn(B, N3, KP, generator=g) * 0.05).to(dev)
-spcol = torch.randn(B, P, KP, generator=g).to(dev)
-xs = F.split_op(dpre, "f16x2")
-L = hip.lib()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def timed(fn, reps=20):
-    for _ in range(3):
-        fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
-        fn()
-    e.record()
-    e.synchronize()
-    return round(s.elapsed_time(e) / reps * 1e3, 1)
+def main():
+    from scanpaths_amd import functional as F, hip
+    from scanpaths_amd.hip import ConvDesc
+    dev, L = torch.device("cuda", 0), hip.lib()
+    B, P, Cc, KP = 32, 2560, 512, 20
+    C4, N3 = 4 * Cc, 3 * Cc
+    g = torch.Generator(device="cpu").manual_seed(0)
+    dpre = torch.randn(B, P, C4, generator=g).to(dev)
+    spcol, wc = torch.randn(B, P, KP, generator=g).to(dev), (torch.randn(B, N3, KP, generator=g) * 0.2).to(dev)
+    ys = F.split_op(dpre)
+    wsp = torch.empty(L.sp_rank1_grads_workspace(B, P, N3, KP), dtype=torch.uint8, device=dev)
+    dsp, dwc = torch.empty_like(spcol), torch.empty_like(wc)
+    ptr, st = hip.ptr, hip.stream()
+
+    def fused(prep=True):
+        ws = F.split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")
+        F.check(L.sp_rank1_grads_f16x2(ptr(ys.buf), ptr(ys.scale), C4, ptr(ws.buf), ptr(ws.scale), ptr(spcol), B, P, N3, KP, ptr(dsp), ptr(dwc),
+                                       ptr(wsp), None, 0, st), "fused")
+
+    xs0 = F.split_op(torch.nn.functional.pad(spcol, (0, 32 - KP)), "f16x2")
+    ws0 = F.split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")
+
+    def fused_kernel_only():
+        F.check(L.sp_rank1_grads_f16x2(ptr(ys.buf), ptr(ys.scale), C4, ptr(ws0.buf), ptr(ws0.scale), ptr(spcol), B, P, N3, KP, ptr(dsp), ptr(dwc),
+                                       ptr(wsp), None, 0, st), "fused")
+
+    def pair():
+        ws = F.split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")
+        d = ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
+        d.w_scale_rows = 1
+        F.check(L.sp_conv_igemm_f16x2(C.byref(d), ptr(ys.buf), ptr(ys.scale), ptr(ws.buf), ptr(ws.scale), None, ptr(dsp), st), "igemm")
+        xs = F.split_op(torch.nn.functional.pad(spcol, (0, 32 - KP)), "f16x2")
+        d2 = hip.WgradDesc(1, P // 64, 64, 32, 32, P // 64, 64, N3, C4, 1, 1, 1, 0, 1, KP, 0, 1.0, B, P * 32, P * C4, N3 * KP)
+        F.check(L.sp_conv_wgrad_f16x2(C.byref(d2), ptr(xs.buf), ptr(xs.scale), ptr(ys.buf), ptr(ys.scale), ptr(dwc), None, st), "wgrad")
+
+    def timeit(f, n=30):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) / n * 1e3, 1)
+    out = {"shape": dict(B=B, P=P, N3=N3, KP=KP), "fused_with_prep_us": timeit(fused), "fused_kernel_us": timeit(fused_kernel_only),
+           "two_gemms_with_prep_us": timeit(pair), "planes_bytes_read_once": 2 * 2 * B * P * N3}
+    for live in (24, 16, 8):
+        last = torch.tensor([9] * live + [0] * (B - live), dtype=torch.int32, device=dev)
+        def fk():
+            F.check(L.sp_rank1_grads_f16x2(ptr(ys.buf), ptr(ys.scale), C4, ptr(ws0.buf), ptr(ws0.scale), ptr(spcol), B, P, N3, KP, ptr(dsp), ptr(dwc),
+                                           ptr(wsp), ptr(last), 5, st), "fused")
+        def pr():
+            d = ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
+            d.w_scale_rows = 1
+            d.row_last, d.row_step = last.data_ptr(), 5
+            F.check(L.sp_conv_igemm_f16x2(C.byref(d), ptr(ys.buf), ptr(ys.scale), ptr(ws0.buf), ptr(ws0.scale), None, ptr(dsp), st), "igemm")
+            d2 = hip.WgradDesc(1, P // 64, 64, 32, 32, P // 64, 64, N3, C4, 1, 1, 1, 0, 1, KP, 0, 1.0, B, P * 32, P * C4, N3 * KP)
+            d2.row_last, d2.row_step = last.data_ptr(), 5
+            F.check(L.sp_conv_wgrad_f16x2(C.byref(d2), ptr(xs0.buf), ptr(xs0.scale), ptr(ys.buf), ptr(ys.scale), ptr(dwc), None, st), "wgrad")
+        out["live%d_fused_kernel_us" % live] = timeit(fk)
+        out["live%d_two_gemms_no_prep_us" % live] = timeit(pr)
+    out["fused_kernel_GBps"] = round(out["planes_bytes_read_once"] / out["fused_kernel_us"] / 1e3, 1)
+    print(json.dumps(out))
 
 
-dsp0, dsp1 = torch.empty_like(spcol), torch.empty_like(spcol)
-
-
-def fp32_path():
-    F._igemm(dpre, wc, None, dsp0, N_img=P, Hi=1, Wi=1, Kc=N3, ldx=C4, Ho=1, Wo=1, Nout=KP, ldc=KP, ldw=KP, mode=1, nbatch=B, sX=P * C4, sW=N3 * KP,
-             sC=P * KP)
-
-
-def prep():
-    return F.split_op(wc.transpose(1, 2).contiguous(), "f16x2")
-
-
-ws = prep()
-d = hip.ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
-
-
-def split_gemm():
-    hip.check(L.sp_conv_igemm_f16x2(C.byref(d), hip.ptr(xs.buf), hip.ptr(xs.scale), hip.ptr(ws.buf), hip.ptr(ws.scale), None, hip.ptr(dsp1), hip.stream()), "b")
-
-
-res = {"fp32_batched_us": timed(fp32_path), "split_prep_us": timed(prep), "split_gemm_us": timed(split_gemm)}
-torch.cuda.synchronize()
-ref = torch.einsum("bpk,bkn->bpn", dpre.view(B, P, C4)[:, :, :N3].double().cpu(), wc.double().cpu())
-res["err_fp32"] = float((dsp0.double().cpu() - ref).abs().max() / ref.abs().max())
-res["err_split"] = float((dsp1.double().cpu() - ref).abs().max() / ref.abs().max())
-dwc = torch.empty_like(wc)
-wsb = hip.workspace(L.sp_rank1_dwc_workspace(B, P, N3, KP), dev, slot=0)
-res["rank1_dwc_us"] = timed(lambda: hip.check(L.sp_rank1_dwc(hip.ptr(dpre), hip.ptr(spcol), B, P, C4, N3, KP, hip.ptr(wsb), hip.ptr(dwc), hip.stream()), "r"))
-ys = xs
-dwc1 = torch.empty_like(wc)
-
-
-def dwc_prep():
-    return F.split_op(torch.nn.functional.pad(spcol, (0, 32 - KP)), "f16x2")
-
-
-xsp = dwc_prep()
-dw = hip.WgradDesc(1, P // 64, 64, 32, 32, P // 64, 64, N3, C4, 1, 1, 1, 0, 1, KP, 0, 1.0, B, P * 32, P * C4, N3 * KP)
-res["dwc_split_prep_us"] = timed(dwc_prep)
-res["dwc_split_gemm_us"] = timed(lambda: hip.check(L.sp_conv_wgrad_f16x2(C.byref(dw), hip.ptr(xsp.buf), hip.ptr(xsp.scale), hip.ptr(ys.buf), hip.ptr(ys.scale),
-                                                                      hip.ptr(dwc1), None, hip.stream()), "w"))
-torch.cuda.synchronize()
-refw = torch.einsum("bpc,bpk->bck", dpre.view(B, P, C4)[:, :, :N3].double().cpu(), spcol.double().cpu())
-res["err_dwc_valu"] = float((dwc.double().cpu() - refw).abs().max() / refw.abs().max())
-res["err_dwc_split"] = float((dwc1.double().cpu() - refw).abs().max() / refw.abs().max())
-print(json.dumps(res))
+if __name__ == "__main__":
+    main()
