@@ -160,6 +160,9 @@ int sp_split2_f16_wT(const float* w, int Co, int taps, int Ci, void* out, float*
  * x_scale -> a device 1.0f and a weight operand split with absorb = its col_scale. */
 int sp_split2_f16_rows(const float* w, int64_t rows, int64_t K, int Kc, const float* absorb, void* out, float* row_scale, void* stream);
 int sp_split2_f16_wT_rows(const float* w, int Co, int taps, int Ci, const float* absorb, void* out, float* row_scale, void* stream);
+/* nbatch matrices [Co][taps][Ci] one behind the other -> nbatch * Ci rows (item-major), one scale per row (round 6: the rank-1 filters wc) */
+int sp_split2_f16_wT_rows_batched(const float* w, int nbatch, int Co, int taps, int Ci, const float* absorb, void* out, float* row_scale,
+                                  void* stream);
 int64_t sp_split2_f16_cols_workspace(int64_t rows, int C);
 int sp_split2_f16_cols(const float* x, int64_t rows, int C, void* out, float* col_scale, void* scratch, void* stream);
 int sp_conv_igemm_f16x2(const sp_conv_desc* d, const void* Xsplit, const float* x_scale, const void* Wsplit, const float* w_scale,
@@ -340,6 +343,10 @@ int sp_sempool_bwd(const float* dout, const float* out, const float* a, const fl
  * da / dvf rows are written as zeros, vf is not read */
 int sp_sempool_bwd_rows(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C, float alpha,
                         float* da, float* dvf, const int* row_last, int row_step, void* stream);
+/* round 6: sbc != 0: the pooled rows / their gradient lie [S][B][C] (what the embedding behind them reads) instead of [B][S][C]: no transposed copy */
+int sp_sempool_fwd_sbc(const float* a, const float* vf, int S, int B, int P, int C, float alpha, void* workspace, float* out, int sbc, void* stream);
+int sp_sempool_bwd_rows_sbc(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C, float alpha,
+                            float* da, float* dvf, const int* row_last, int row_step, int sbc, void* stream);
 int sp_lstm_pointwise_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_out, int64_t rows, int C, float* dpre, float* dc_prev,
                           unsigned* dpre_amax /* nullable, as y_amax */, void* stream);
@@ -422,6 +429,11 @@ int sp_head_finish_parts_bwd(const float* dlogits, const float* damap, const flo
                              const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz, int nheads, int HC,
                              const float* w2, int softmax, float* dZ, float* dcb_partial, float* dw2_partial, float* db2_partial,
                              float* ddpre, int zc, int parts, int* live, void* stream);
+/* round 6: dlogits_ld = elements between the (head, sample) rows of dlogits (0 = Hm*Wm + 1): a slice of the stacked outputs' gradient, read in place */
+int sp_head_finish_parts_bwd_ld(const float* dlogits, int64_t dlogits_ld, const float* damap, const float* dmu, const float* dsigma2,
+                                const float* logits, const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
+                                int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial, float* dw2_partial,
+                                float* db2_partial, float* ddpre, int zc, int parts, int* live, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * predict_head without the dense 5x5 GEMM (models/baseline_attention.py:149-158), csrc/head_direct.hip.

@@ -1803,11 +1803,15 @@ __global__ __launch_bounds__(256) void split2_rows_kernel(const float* w, int64_
 
 // w [Co][taps][Ci] -> rows ci, k = (tap, co), value w / absorb[co] (absorb nullable), one scale per row ci.  One block per 4
 // consecutive ci (float4 reads of the source); the maxima first, then the split.
+// (blockIdx.y: batch item -- its own w, its own Ci rows of out and row_scale; the 64-byte zero block follows the last item)
 __global__ __launch_bounds__(256) void split2_wT_rows_kernel(const float* w, int Co, int taps, int Ci, const float* absorb,
                                                              uint16_t* out, float* row_scale) {
     __shared__ float sh4[4];
     const int ci0 = blockIdx.x * 4;
     const int64_t Kt = (int64_t)taps * Co;                         // row length
+    w += (int64_t)blockIdx.y * Kt * Ci;
+    out += (int64_t)blockIdx.y * 2 * Kt * Ci;
+    row_scale += (int64_t)blockIdx.y * Ci;
     float m[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t k = threadIdx.x; k < Kt; k += 256) {
         const int tap = (int)(k / Co), co = (int)(k - (int64_t)tap * Co);
@@ -1834,7 +1838,8 @@ __global__ __launch_bounds__(256) void split2_wT_rows_kernel(const float* w, int
         }
     }
     if (threadIdx.x < 4) row_scale[ci0 + threadIdx.x] = sc[threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<uint2*>(out + 2 * (int64_t)Co * taps * Ci)[threadIdx.x] = make_uint2(0u, 0u);
+    if (blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x < 8)
+        reinterpret_cast<uint2*>(out + 2 * (int64_t)Co * taps * Ci)[threadIdx.x] = make_uint2(0u, 0u);
 }
 
 // column maxima of x [rows][C] (C % 4 == 0), two stages without atomics (a first version with one atomicMax per thread and column spent
@@ -1994,13 +1999,21 @@ extern "C" int sp_split2_f16_rows(const float* w, int64_t rows, int64_t K, int K
     return SP_OK;
 }
 
+extern "C" int sp_split2_f16_wT_rows_batched(const float* w, int nbatch, int Co, int taps, int Ci, const float* absorb, void* out,
+                                             float* row_scale, void* stream);
 // w [Co][taps][Ci] -> rows ci, k = (tap, co): the data gradient's weight operand with one scale per row (input channel);
 // absorb [Co] nullable: the channel scales of the gradient operand it meets
 extern "C" int sp_split2_f16_wT_rows(const float* w, int Co, int taps, int Ci, const float* absorb, void* out, float* row_scale,
                                      void* stream) {
+    return sp_split2_f16_wT_rows_batched(w, 1, Co, taps, Ci, absorb, out, row_scale, stream);
+}
+// nbatch matrices [Co][taps][Ci] one behind the other -> nbatch * Ci rows (item-major), one scale per row: the rank-1 filters wc [B][3C][KP]
+// as the B operand [B*KP][3C] of their data gradient in ONE launch (a transposed copy + sp_split2_f16_rows before)
+extern "C" int sp_split2_f16_wT_rows_batched(const float* w, int nbatch, int Co, int taps, int Ci, const float* absorb, void* out,
+                                             float* row_scale, void* stream) {
     if (!w || !out || !row_scale) return SP_ENULL;
-    if (((int64_t)taps * Co) % 16 || Ci % 4 || Ci < 4 || ((uintptr_t)w & 15)) return SP_EINVAL;
-    hipLaunchKernelGGL(split2_wT_rows_kernel, dim3(Ci / 4), dim3(256), 0, (hipStream_t)stream, w, Co, taps, Ci, absorb, (uint16_t*)out,
+    if (nbatch < 1 || nbatch > 65535 || ((int64_t)taps * Co) % 16 || Ci % 4 || Ci < 4 || ((uintptr_t)w & 15)) return SP_EINVAL;
+    hipLaunchKernelGGL(split2_wT_rows_kernel, dim3(Ci / 4, nbatch), dim3(256), 0, (hipStream_t)stream, w, Co, taps, Ci, absorb, (uint16_t*)out,
                        row_scale);
     SP_LAUNCH_CHECK();
     return SP_OK;

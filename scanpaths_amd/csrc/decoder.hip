@@ -89,20 +89,23 @@ __global__ __launch_bounds__(256) void sempool_fwd_kernel(const float* __restric
     }
     (void)nch;
 }
-// out [B][S][C] = relu(alpha * sum_chunks partial)
+// out (b, s, :) at out + b * osb + s * oss  = relu(alpha * sum_chunks partial [chunk][b][s][c])
 __global__ __launch_bounds__(256) void sempool_finish_kernel(const float* __restrict__ partial, int nch, int64_t n, float alpha,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int S, int C, int64_t osb, int64_t oss) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float s = 0.f;
         for (int k = 0; k < nch; ++k) s += partial[(int64_t)k * n + i];
-        out[i] = fmaxf(alpha * s, 0.f);
+        const int c = (int)(i % C);
+        const int64_t bs = i / C;
+        out[(bs / S) * osb + (bs % S) * oss + c] = fmaxf(alpha * s, 0.f);
     }
 }
-// dz [B][S][C] (already masked by the ReLU), a [S][B][P], vf [B][P][C] -> da [S][B][P], dvf [B][P][C]
+// dz, out: row (b, s) at b * zsb + s * zss; a [S][B][P], vf [B][P][C] -> da [S][B][P], dvf [B][P][C]
 __global__ __launch_bounds__(256) void sempool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ out,
                                                           const float* __restrict__ a, const float* __restrict__ vf, int S,
                                                           int B, int P, int C, float alpha, float* __restrict__ da,
-                                                          float* __restrict__ dvf, const int* __restrict__ row_last, int row_step) {
+                                                          float* __restrict__ dvf, const int* __restrict__ row_last, int row_step,
+                                                          int64_t zsb, int64_t zss) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
     const int nq = C / 4;                         // channel quads; lane handles quads lane, lane+64
@@ -120,15 +123,15 @@ __global__ __launch_bounds__(256) void sempool_bwd_kernel(const float* __restric
         float d0 = 0.f, d1 = 0.f;
         for (int q = lane; q < nq; q += 64) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(vf + bp * C + q * 4);
-            f32x4 g0 = *reinterpret_cast<const f32x4*>(dz + ((int64_t)b * S + 0) * C + q * 4);
-            const f32x4 o0 = *reinterpret_cast<const f32x4*>(out + ((int64_t)b * S + 0) * C + q * 4);
+            f32x4 g0 = *reinterpret_cast<const f32x4*>(dz + (int64_t)b * zsb + q * 4);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(out + (int64_t)b * zsb + q * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g0[e] = o0[e] > 0.f ? g0[e] : 0.f;
             d0 += g0[0] * v[0] + g0[1] * v[1] + g0[2] * v[2] + g0[3] * v[3];
             f32x4 w = a0 * g0;
             if (S > 1) {
-                f32x4 g1 = *reinterpret_cast<const f32x4*>(dz + ((int64_t)b * S + 1) * C + q * 4);
-                const f32x4 o1 = *reinterpret_cast<const f32x4*>(out + ((int64_t)b * S + 1) * C + q * 4);
+                f32x4 g1 = *reinterpret_cast<const f32x4*>(dz + (int64_t)b * zsb + zss + q * 4);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(out + (int64_t)b * zsb + zss + q * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g1[e] = o1[e] > 0.f ? g1[e] : 0.f;
                 d1 += g1[0] * v[0] + g1[1] * v[1] + g1[2] * v[2] + g1[3] * v[3];
@@ -691,7 +694,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
                                                        const float* drt, int B, int Hm, int Wm, int ldz, int HC,
                                                        const float* w2, int softmax, float* dZ, float* dcb_partial,
                                                        float* dw2_partial, float* db2_partial, int dh, int dw, float* ddpre,
-                                                       int zc, int parts, int* live) {
+                                                       int zc, int parts, int* live, int64_t dl_ld) {
+    // dl_ld: elements between the rows (head, sample) of dlogits (P + 1 when dense; a slice of the stacked outputs' gradient is read in place)
     // parts: as head_fwd_kernel.  parts == 1: dZ and dcb[0], dcb[1] (the other dcb entries zero), no duration gradients; parts == 2:
     // ddpre, the dw2 / db2 partials and dcb[IDX_BD] (the other entries zero), no dZ.  live (nullable, parts & 2): live[hd * B + b] = does this
     // (head slot, row) receive ANY duration gradient -- an exact test on dmu / dsigma2 -- so that the duration sites' backward kernels can
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* dlogits, con
         for (int j = threadIdx.x; j < HC; j += 256) dcb[j] = j == IDX_BD ? (float)sumdd : 0.f;
         return;
     }
-    const float* dl = dlogits + ((int64_t)hd * B + b) * (P + 1);
+    const float* dl = dlogits + ((int64_t)hd * B + b) * dl_ld;
     const float* lg = logits + ((int64_t)hd * B + b) * (P + 1);
     const float* am = amap + ((int64_t)hd * B + b) * P;
     float* dz = dZ + (int64_t)b * P * ldz + hd * zc;
@@ -846,30 +850,44 @@ extern "C" int sp_rank1_dwc(const float* dpre, const float* spcol, int B, int P,
     return SP_OK;
 }
 
+extern "C" int sp_sempool_fwd_sbc(const float* a, const float* vf, int S, int B, int P, int C, float alpha, void* workspace, float* out, int sbc,
+                                  void* stream);
+extern "C" int sp_sempool_bwd_rows_sbc(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C, float alpha,
+                                       float* da, float* dvf, const int* row_last, int row_step, int sbc, void* stream);
 extern "C" int64_t sp_sempool_workspace(int S, int B, int P, int C) {
     return (int64_t)((P + SP_PCH - 1) / SP_PCH) * B * S * C * (int64_t)sizeof(float);
 }
 
 extern "C" int sp_sempool_fwd(const float* a, const float* vf, int S, int B, int P, int C, float alpha, void* workspace,
                               float* out, void* stream) {
+    return sp_sempool_fwd_sbc(a, vf, S, B, P, C, alpha, workspace, out, 0, stream);
+}
+extern "C" int sp_sempool_fwd_sbc(const float* a, const float* vf, int S, int B, int P, int C, float alpha, void* workspace,
+                                  float* out, int sbc, void* stream) {
     if (!a || !vf || !workspace || !out) return SP_ENULL;
     if (S < 1 || S > 2 || B < 1 || P < 1 || C % 4 || C > 512) return SP_EINVAL;
+    const int64_t osb = sbc ? C : (int64_t)S * C, oss = sbc ? (int64_t)B * C : C;
     const int nch = (P + SP_PCH - 1) / SP_PCH;
     hipLaunchKernelGGL(sempool_fwd_kernel, dim3(nch, B), dim3(256), 0, (hipStream_t)stream, a, vf, S, B, P, C, (float*)workspace);
     SP_LAUNCH_CHECK();
     const int64_t n = (int64_t)B * S * C;
     hipLaunchKernelGGL(sempool_finish_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nch,
-                       n, alpha, out);
+                       n, alpha, out, S, C, osb, oss);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
 
 extern "C" int sp_sempool_bwd_rows(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C,
                                    float alpha, float* da, float* dvf, const int* row_last, int row_step, void* stream) {
+    return sp_sempool_bwd_rows_sbc(dout, out, a, vf, S, B, P, C, alpha, da, dvf, row_last, row_step, 0, stream);
+}
+extern "C" int sp_sempool_bwd_rows_sbc(const float* dout, const float* out, const float* a, const float* vf, int S, int B, int P, int C,
+                                       float alpha, float* da, float* dvf, const int* row_last, int row_step, int sbc, void* stream) {
     if (!dout || !out || !a || !vf || !da || !dvf) return SP_ENULL;
     if (S < 1 || S > 2 || B < 1 || P < 1 || C % 4) return SP_EINVAL;
+    const int64_t zsb = sbc ? C : (int64_t)S * C, zss = sbc ? (int64_t)B * C : C;
     hipLaunchKernelGGL(sempool_bwd_kernel, dim3(ew_blocks((int64_t)B * P * 64)), dim3(256), 0, (hipStream_t)stream, dout, out, a,
-                       vf, S, B, P, C, alpha, da, dvf, row_last, row_step);
+                       vf, S, B, P, C, alpha, da, dvf, row_last, row_step, zsb, zss);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }
@@ -1022,12 +1040,25 @@ extern "C" int sp_head_finish_fwd(const float* Z, int B, int Hm, int Wm, int ldz
                                     stream);
 }
 
+extern "C" int sp_head_finish_parts_bwd_ld(const float* dlogits, int64_t dlogits_ld, const float* damap, const float* dmu, const float* dsigma2,
+                                           const float* logits, const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm,
+                                           int ldz, int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
+                                           float* dw2_partial, float* db2_partial, float* ddpre, int zc, int parts, int* live, void* stream);
 extern "C" int sp_head_finish_parts_bwd(const float* dlogits, const float* damap, const float* dmu, const float* dsigma2,
                                         const float* logits,
                                         const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm, int ldz,
                                         int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
                                         float* dw2_partial, float* db2_partial, float* ddpre, int zc, int parts, int* live, void* stream) {
+    return sp_head_finish_parts_bwd_ld(dlogits, 0, damap, dmu, dsigma2, logits, amap, sigma2, drt, B, Hm, Wm, ldz, nheads, HC, w2, softmax, dZ,
+                                       dcb_partial, dw2_partial, db2_partial, ddpre, zc, parts, live, stream);
+}
+extern "C" int sp_head_finish_parts_bwd_ld(const float* dlogits, int64_t dlogits_ld, const float* damap, const float* dmu, const float* dsigma2,
+                                           const float* logits, const float* amap, const float* sigma2, const float* drt, int B, int Hm, int Wm,
+                                           int ldz, int nheads, int HC, const float* w2, int softmax, float* dZ, float* dcb_partial,
+                                           float* dw2_partial, float* db2_partial, float* ddpre, int zc, int parts, int* live, void* stream) {
     if (parts < 1 || parts > 3 || B < 1 || nheads < 1) return SP_EINVAL;
+    if (dlogits_ld == 0) dlogits_ld = (int64_t)Hm * Wm + 1;
+    if (dlogits_ld < (int64_t)Hm * Wm + 1) return SP_EINVAL;
     if (!dcb_partial) return SP_ENULL;
     if ((parts & 1) && (!dlogits || !logits || !amap || !dZ)) return SP_ENULL;
     if ((parts & 2) && (!dmu || !dsigma2 || !sigma2 || !drt || !w2 || !dw2_partial || !db2_partial)) return SP_ENULL;
@@ -1038,7 +1069,8 @@ extern "C" int sp_head_finish_parts_bwd(const float* dlogits, const float* damap
         return SP_EINVAL;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B, nheads), dim3(256), 0, (hipStream_t)stream, dlogits, damap, dmu, dsigma2, logits,
                        amap,
-                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw, ddpre, zc, parts, live);
+                       sigma2, drt, B, Hm, Wm, ldz, HC, w2, softmax, dZ, dcb_partial, dw2_partial, db2_partial, dh, dw, ddpre, zc, parts, live,
+                       dlogits_ld);
     SP_LAUNCH_CHECK();
     return SP_OK;
 }

@@ -1600,6 +1600,18 @@ def _cell_bounds(c_prev, c):
 
 
 
+def _split_wcT(wc: torch.Tensor) -> SplitOperand:
+    """the rank-1 filters wc [B, 3C, KP] as the 2xfp16 operand [B*KP rows][3C] of their data gradient, one scale per row -- one launch
+    (a transposed copy and sp_split2_f16_rows before; same planes, same scales)"""
+    B, N3, KP = wc.shape
+    wc = wc.contiguous()
+    out = torch.empty(2 * wc.numel() + 32, dtype=torch.float16, device=wc.device)
+    rscale = torch.empty(B * KP, dtype=torch.float32, device=wc.device)
+    check(hip.lib().sp_split2_f16_wT_rows_batched(ptr(wc), B, N3, 1, KP, None, ptr(out), ptr(rscale), hip.stream()),
+          "sp_split2_f16_wT_rows_batched")
+    return SplitOperand(out, rscale, "f16x2", "rows", None)
+
+
 def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc, cbounds=(None, None), skip_fp32=False, fan=None,
                          step=None):
     """gradients of the cell w.r.t. the gate pre-activations (dpre, carrying its max|.| hint or -- when bounds of max|dh|, max|dc| and
@@ -1658,7 +1670,7 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
         # launches of the big GEMM kernels that each re-read the 503 MB of planes, and six small launches preparing their operands
         FUSION_COUNTS["rank1_fused"] += 1
         ys = dpre._sp_cache["f16x2"]
-        ws = split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")   # [B][KP][3C]: K contiguous, one scale per row
+        ws = _split_wcT(wc)             # [B][KP][3C]: K contiguous, one scale per row
         dsp, dwc = torch.empty_like(spcol), torch.empty_like(wc)
         wsp = hip.workspace(L.sp_rank1_grads_workspace(B, P, N3, KP), dpre.device, slot=0)
         check(L.sp_rank1_grads_f16x2(ptr(ys.buf), ptr(ys.scale), C4, ptr(ws.buf), ptr(ws.scale), ptr(spcol), B, P, N3, KP, ptr(dsp), ptr(dwc),
@@ -1673,7 +1685,7 @@ def _lstm_rank1_backward(gates, c_prev, c, spcol, wc, dh, dc, need_dsp, need_dwc
             # batched GEMM it replaces read the fp32 dpre (0.5 GB) at ~2 TB/s
             FUSION_COUNTS["rank1_dsp_split"] += 1
             xs = dpre._sp_cache["f16x2"]
-            ws = split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")   # [B][KP][3C]: K contiguous, one scale per row
+            ws = _split_wcT(wc)             # [B][KP][3C]: K contiguous, one scale per row
             d = ConvDesc(P, 1, 1, N3, C4, 1, 1, KP, KP, 1, 1, 1, 0, 1, 0, N3, 1.0, 0, 0, B, P * C4, KP * N3, P * KP, 0, None)
             d.w_scale_rows = 1
             if rc is not None:          # one item per sample: items without loss gradient at this step are zero tiles
@@ -1935,18 +1947,19 @@ def mul_relu(a, b):
 
 
 class _SemPool(Function):
-    """amaps [S,B,P], vf [B,P,C] -> relu(mean_p(amaps * vf)) [B,S,C]   (get_channel_semantic + ReLU)"""
+    """amaps [S,B,P], vf [B,P,C] -> relu(mean_p(amaps * vf)) [B,S,C]   (get_channel_semantic + ReLU); sbc: the result as [S,B,C], the
+    row order of the embedding behind it (no transposed copy in forward, none of its gradient in backward: 2 launches per decode step)"""
     @staticmethod
-    def forward(ctx, amaps, vf, step=None):
+    def forward(ctx, amaps, vf, step=None, sbc=False):
         amaps, vf = amaps.contiguous(), vf.contiguous()
         S, B, P = amaps.shape
         Cc = vf.shape[-1]
         L = hip.lib()
-        out = torch.empty((B, S, Cc), dtype=torch.float32, device=vf.device)
+        out = torch.empty((S, B, Cc) if sbc else (B, S, Cc), dtype=torch.float32, device=vf.device)
         ws = hip.workspace(L.sp_sempool_workspace(S, B, P, Cc), vf.device, slot=0)
-        check(L.sp_sempool_fwd(ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(ws), ptr(out), hip.stream()), "sp_sempool_fwd")
+        check(L.sp_sempool_fwd_sbc(ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(ws), ptr(out), int(sbc), hip.stream()), "sp_sempool_fwd_sbc")
         ctx.save_for_backward(amaps, vf, out)
-        ctx.step = step
+        ctx.step, ctx.sbc = step, sbc
         return out
 
     @staticmethod
@@ -1956,16 +1969,16 @@ class _SemPool(Function):
         Cc = vf.shape[-1]
         da, dvf = torch.empty_like(amaps), torch.empty_like(vf)
         rc = rows_ctx(ctx.step, B)      # memory update `step` feeds decode steps >= step only: samples whose last loss step is earlier get zeros
-        check(hip.lib().sp_sempool_bwd_rows(ptr(dout.contiguous()), ptr(out), ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(da), ptr(dvf),
-                                            ptr(rc.last) if rc is not None else None, int(ctx.step) if rc is not None else 0,
-                                            hip.stream()), "sp_sempool_bwd_rows")
+        check(hip.lib().sp_sempool_bwd_rows_sbc(ptr(dout.contiguous()), ptr(out), ptr(amaps), ptr(vf), S, B, P, Cc, 1.0 / P, ptr(da), ptr(dvf),
+                                                ptr(rc.last) if rc is not None else None, int(ctx.step) if rc is not None else 0, int(ctx.sbc),
+                                                hip.stream()), "sp_sempool_bwd_rows_sbc")
         if rc is not None:
             dvf._sp_rows = (rc, int(ctx.step))      # hint for vf's gradient fan-in (dead samples' rows are exact zeros): F._FanOut
-        return da, dvf, None
+        return da, dvf, None, None
 
 
-def semantic_pool(amaps, vf, step=None):
-    return _SemPool.apply(amaps, vf, step)
+def semantic_pool(amaps, vf, step=None, sbc=False):
+    return _SemPool.apply(amaps, vf, step, sbc)
 
 
 class _RowMean(Function):
@@ -2108,15 +2121,20 @@ class _HeadSal(Function):
     def backward(ctx, dlogits, damap):
         B, Hm, Wm, ldz, nheads, HC, softmax, per_sample, cbshape = ctx.cfg
         logits, amap = ctx.saved_tensors
-        dlogits = dlogits.contiguous() if dlogits is not None else torch.zeros_like(logits)
+        if dlogits is None:
+            dlogits = torch.zeros_like(logits)
+        # the gradient of step t's logits is a slice of the stacked outputs' gradient [nh, B, T, 1+P]: rows (head, sample) a constant
+        # distance apart -- read in place (a contiguous copy per decode step before)
+        if not (dlogits.stride(2) == 1 and dlogits.stride(0) == B * dlogits.stride(1) and dlogits.stride(1) >= dlogits.shape[2]):
+            dlogits = dlogits.contiguous()
         damap = damap.contiguous() if damap is not None else None
         dZ = torch.empty((B, Hm, Wm, ldz), dtype=torch.float32, device=logits.device)
         if ldz != nheads * 2:
             dZ.zero_()
         dcbp = torch.empty((B, nheads * HC), dtype=torch.float32, device=logits.device)
-        check(hip.lib().sp_head_finish_parts_bwd(ptr(dlogits), ptr(damap), None, None, ptr(logits), ptr(amap), None, None, B, Hm, Wm, ldz,
-                                                 nheads, HC, None, int(softmax), ptr(dZ), ptr(dcbp), None, None, None, 2, 1, None,
-                                                 hip.stream()), "sp_head_finish_parts_bwd")
+        check(hip.lib().sp_head_finish_parts_bwd_ld(ptr(dlogits), dlogits.stride(1), ptr(damap), None, None, ptr(logits), ptr(amap), None, None,
+                                                    B, Hm, Wm, ldz, nheads, HC, None, int(softmax), ptr(dZ), ptr(dcbp), None, None, None, 2, 1,
+                                                    None, hip.stream()), "sp_head_finish_parts_bwd_ld")
         dcb = dcbp.view(cbshape) if per_sample else _colsum_any(dcbp, nheads * HC).view(nheads, HC)
         return dZ, dcb, None, None, None, None
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sp_split2_f16_wT": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "sp_split2_f16_rows": (_I, [_P, _L, _L, _I, _P, _P, _P, _P]),
     "sp_split2_f16_wT_rows": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "sp_split2_f16_wT_rows_batched": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sp_split2_f16_cols_workspace": (_L, [_L, _I]),
     "sp_split2_f16_cols": (_I, [_P, _L, _I, _P, _P, _P, _P]),
     "sp_conv_wgrad_f16x2_multi_workspace": (_L, [_P, _I]),
@@ -118,6 +119,8 @@ SIGNATURES = {
     "sp_sempool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_sempool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "sp_sempool_bwd_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
+    "sp_sempool_fwd_sbc": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
+    "sp_sempool_bwd_rows_sbc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _P]),
     "sp_lstm_pointwise_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "sp_lstm_pointwise_bwd_split": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
     "sp_lstm_pointwise_bwd_rows": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
@@ -136,6 +139,8 @@ SIGNATURES = {
                                 _P]),
     "sp_head_finish_parts_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sp_head_finish_parts_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I,
+                                      _I, _P, _P]),
+    "sp_head_finish_parts_bwd_ld": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I,
                                       _I, _P, _P]),
     "sp_head_num_classes": (_I, [_I, _I]),
     "sp_head_compose11_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -437,9 +437,9 @@ class ScanpathModel(nn.Module):
             spf = F.mul_relu(amaps, mvfs.pop())
             sp_list.append(rep(F.linear(spf.view(S * B, P), spw.pop(), spb.pop(), defer=sp_defer), T - k))
             vf4 = vfs.pop()           # (4-D as it is: the gradient it returns carries the memory update's row-sparsity mark to vf's fan-in)
-            pooled = F.semantic_pool(amaps, vf4, step=at(k)) if (S <= 2 and Cc <= 512) else \
-                F.gemm(amaps.transpose(0, 1).contiguous(), vf4.view(B, P, Cc), None, "kn", alpha=1.0 / P, relu=True)          # [B,S,C]
-            se_list.append(rep(F.linear(pooled.transpose(0, 1).contiguous().view(S * B, Cc), sew.pop(), seb.pop(), defer=se_defer), T - k))
+            pooled = F.semantic_pool(amaps, vf4, step=at(k), sbc=True) if (S <= 2 and Cc <= 512) else \
+                F.gemm(amaps.transpose(0, 1).contiguous(), vf4.view(B, P, Cc), None, "kn", alpha=1.0 / P, relu=True).transpose(0, 1).contiguous()
+            se_list.append(rep(F.linear(pooled.view(S * B, Cc), sew.pop(), seb.pop(), defer=se_defer), T - k))          # pooled [S,B,C]
             sp_mem = F.list_attention(torch.stack([a.pop() for a in sp_list], 0), u_spas.pop())        # [S*B,P]
             se_mem = F.list_attention(torch.stack([a.pop() for a in se_list], 0), u_sems.pop())        # [S*B,C]
             return sp_mem, se_mem

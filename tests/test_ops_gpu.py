@@ -841,6 +841,40 @@ def test_semantic_pool(S, B, P, C):
     _close(out, ref, 3e-6, "pooled")
     _close(ad.grad, ar.grad, 3e-6, "d amaps")
     _close(vd.grad, vr.grad, 3e-6, "d vf")
+    # the [S,B,C] row order the decode loop asks for (no transposed copies): the same numbers, bit for bit
+    a2, v2 = a.to(dev).requires_grad_(True), vf.to(dev).requires_grad_(True)
+    out2 = F.semantic_pool(a2, v2, sbc=True)
+    assert out2.shape == (S, B, C) and torch.equal(out2.transpose(0, 1), out)
+    (out2 * g.to(dev).transpose(0, 1)).sum().backward()
+    assert torch.equal(a2.grad, ad.grad) and torch.equal(v2.grad, vd.grad)
+
+
+def test_round6_launch_savers_equal_the_forms_they_replace():
+    """three per-decode-step PyTorch copies removed in round 6, each against the form it replaces, bit for bit: the rank-1 filters'
+    transposed split in one launch (was: transposed copy + row split); the saliency head's backward reading its logits gradient as
+    a slice of the stacked gradient [nh, B, T, 1+P] (was: a contiguous copy of the slice)"""
+    from scanpaths_amd import functional as F
+    dev = _dev()
+    B, N3, KP = 3, 768, 20
+    wc = (_rand(B, N3, KP, seed=41) * torch.exp(_rand(B, 1, KP, seed=42))).to(dev)
+    new = F._split_wcT(wc)
+    old = F.split_w(wc.transpose(1, 2).contiguous().view(B * KP, N3), "f16x2")
+    assert torch.equal(new.buf, old.buf) and torch.equal(new.scale, old.scale)
+    nh, B, Hm, Wm, T = 2, 3, 10, 16, 4
+    HC = 64
+    Z = _rand(B, Hm, Wm, nh * 2, seed=43).to(dev)
+    cb = _rand(nh, HC, seed=44).to(dev)
+    gl = _rand(nh, B, T, Hm * Wm + 1, seed=45).to(dev)
+    ga = _rand(nh, B, Hm * Wm, seed=46).to(dev)
+    res = []
+    for strided in (True, False):
+        z, c = Z.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+        logits, amap = F.head_sal(z, c, nh, HC, False, per_sample=False)
+        gsl = gl[:, :, 2]
+        assert not gsl.is_contiguous()
+        torch.autograd.backward([logits, amap], [gsl if strided else gsl.contiguous(), ga])
+        res.append((z.grad, c.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 def test_batched_pointwise_gemm_with_per_item_weights_on_wider_rows():
