@@ -228,3 +228,60 @@ def oracle_full_case(args):
         loss, la, ld = O.supervised_loss(tr, rows)
     enc = eo["enc"]
     return ({k: v.double().numpy() for k, v in tr.items()}, (float(loss), float(la), float(ld)), enc[0].double().numpy())
+
+
+# ---- the RL phase's eval-mode backward (tests/test_rl_gpu.py::test_eval_mode_backward_matches_oracle): oracle side ---------------------------
+RL_EVAL_CASE = dict(T=1, NB=2, H=240, W=320, Hm=30, Wm=40, seed=21)
+
+
+def rl_eval_objective_weights():
+    import torch
+    c = RL_EVAL_CASE
+    g = torch.Generator().manual_seed(c["seed"])
+    P1 = c["Hm"] * c["Wm"] + 1
+    return {k: torch.randn(s, generator=g) for k, s in (("good_all_actions_prob", (c["NB"], c["T"], P1)), ("poor_all_actions_prob", (c["NB"], c["T"], P1)),
+                                                         ("good_log_normal_mu", (c["NB"], c["T"])), ("poor_log_normal_sigma2", (c["NB"], c["T"])))}
+
+
+def start_rl_eval_oracle(background=False):
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 8
+    threads = max(4, min(12, ncpu // 16)) if background else max(4, min(32, ncpu // 3))
+    ex = cf.ProcessPoolExecutor(1, mp_context=mp.get_context("spawn"))
+    return ex, ex.submit(rl_eval_oracle_case, threads)
+
+
+def rl_eval_oracle_case(threads):
+    """(runs in a spawned worker process) -> (calibrated running statistics, fp64 gradients, fp64 objective, fp32 gradients, fp32 objective)
+    of a weighted sum of the EVAL-mode outputs (AiR/train.py:244-251), as numpy arrays.
+    Random weights with the initial running statistics (mean 0, var 1) let activations explode layer by layer; the LSTM gates then saturate
+    everywhere and the few gradients that survive depend on WHICH element is accidentally unsaturated (rounding noise of pre-activations of
+    size 1e9).  The running statistics are calibrated to this batch instead (one train-mode pass of the oracle, momentum undone), as
+    trained checkpoints have them."""
+    import torch
+    from oracle import scanpath_oracle as O
+    from scanpaths_amd.spec import is_buffer
+    from scanpaths_amd.synth import make_batch
+    torch.set_num_threads(threads)
+    c = RL_EVAL_CASE
+    T = c["T"]
+    b = make_batch("AiR", c["NB"], c["H"], c["W"], T, seed=c["seed"])
+    w = rl_eval_objective_weights()
+    base = oracle_state("AiR", "resnet50", c["seed"], c["Hm"], c["Wm"], dtype=torch.float64)
+    bn_new = {}
+    with torch.no_grad():
+        O.forward(base, "AiR", b["images"].double(), b["attention_maps"].double(), b["performances"], training=True, T=T, bn_new=bn_new)
+    calib = {k: (v - 0.9 * base[k]) / 0.1 for k, v in bn_new.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    out = []
+    for dt in (torch.float64, torch.float32):
+        sd = oracle_state("AiR", "resnet50", c["seed"], c["Hm"], c["Wm"], dtype=dt)
+        sd.update({k: v.to(dt) for k, v in calib.items()})
+        for k, v in sd.items():
+            if v.is_floating_point() and not is_buffer(k):
+                v.requires_grad_(True)
+        pred = O.forward(sd, "AiR", b["images"].to(dt), b["attention_maps"].to(dt), None, training=False, T=T)
+        val = sum((pred[k] * w[k].to(dt)).sum() for k in w)
+        val.backward()
+        out += [{k: v.grad.numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}, float(val.detach())]
+    return ({k: v.numpy() for k, v in calib.items()},) + tuple(out)

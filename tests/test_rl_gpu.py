@@ -129,49 +129,32 @@ def test_rl_step_redraws_samples_with_non_finite_or_overlong_durations():
     assert info["resamples"] >= 2 and np.isfinite(float(loss))
 
 
-def test_eval_mode_backward_matches_oracle():
+def test_eval_mode_backward_matches_oracle(request):
     """The RL phase differentiates the EVAL-mode forward (softmax heads, running-stat BatchNorm; AiR/train.py:244-251).  One
     decode step at 240x320: a weighted sum of the eval outputs and its parameter gradients against the fp64 oracle; bar =
     20x the fp32 oracle's own error or 1e-4 of the largest gradient norm (the bars of tests/test_model_gpu.py)."""
-    from helpers import oracle_state
-    from oracle import scanpath_oracle as O
-    from scanpaths_amd.spec import is_buffer
+    from helpers import RL_EVAL_CASE, rl_eval_objective_weights, start_rl_eval_oracle
     from scanpaths_amd.synth import make_batch
     from test_model_gpu import _build
-    T = 1
-    meta = dict(task="AiR", arch="resnet50", T=T, weight_seed=21)
-    b = make_batch("AiR", 2, 240, 320, T, seed=21)
-    g = torch.Generator().manual_seed(21)
-    w = {k: torch.randn(s, generator=g) for k, s in (("good_all_actions_prob", (2, T, 1201)), ("poor_all_actions_prob", (2, T, 1201)),
-                                                      ("good_log_normal_mu", (2, T)), ("poor_log_normal_sigma2", (2, T)))}
+    c = RL_EVAL_CASE
+    T = c["T"]
+    meta = dict(task="AiR", arch="resnet50", T=T, weight_seed=c["seed"])
+    b = make_batch("AiR", c["NB"], c["H"], c["W"], T, seed=c["seed"])
+    w = rl_eval_objective_weights()
 
     def objective(pred, dt, dev):
         return sum((pred[k] * w[k].to(dt).to(dev)).sum() for k in w)
 
-    # Random weights with the initial running statistics (mean 0, var 1) let activations explode layer by layer; the LSTM
-    # gates then saturate everywhere and the few gradients that survive depend on WHICH element is accidentally
-    # unsaturated (rounding noise of pre-activations of size 1e9).  Calibrate the running statistics to this batch instead
-    # (one train-mode pass of the oracle, momentum undone), as trained checkpoints have them.
-    base = oracle_state("AiR", "resnet50", 21, 30, 40, dtype=torch.float64)
-    bn_new = {}
-    with torch.no_grad():
-        O.forward(base, "AiR", b["images"].double(), b["attention_maps"].double(), b["performances"], training=True, T=T,
-                  bn_new=bn_new)
-    calib = {}
-    for k, v in bn_new.items():
-        if k.endswith("running_mean") or k.endswith("running_var"):
-            calib[k] = (v - 0.9 * base[k]) / 0.1
-    grads = {}
-    for dt in (torch.float64, torch.float32):
-        sd = oracle_state("AiR", "resnet50", 21, 30, 40, dtype=dt)
-        sd.update({k: v.to(dt) for k, v in calib.items()})
-        for k, v in sd.items():
-            if v.is_floating_point() and not is_buffer(k):
-                v.requires_grad_(True)
-        pred = O.forward(sd, "AiR", b["images"].to(dt), b["attention_maps"].to(dt), None, training=False, T=T)
-        val = objective(pred, dt, "cpu")
-        val.backward()
-        grads[dt] = ({k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}, float(val))
+    # the oracle side (fp64 calibration pass, fp64 and fp32 eval forward + backward: ~35 s of host work) runs in a worker process,
+    # started with the session when the test is part of one (tests/conftest.py)
+    bo = getattr(request.config, "_rl_oracle", None)
+    ex, fut = bo if bo is not None else start_rl_eval_oracle()
+    calib_np, g64_np, v64, g32_np, v32 = fut.result(timeout=1500)
+    if bo is None:
+        ex.shutdown(wait=False)
+    calib = {k: torch.from_numpy(v) for k, v in calib_np.items()}
+    grads = {torch.float64: ({k: torch.from_numpy(v) for k, v in g64_np.items()}, v64),
+             torch.float32: ({k: torch.from_numpy(v) for k, v in g32_np.items()}, v32)}
     model = _build(meta, 30, 40)
     model.load_state_dict({k: v.float() for k, v in calib.items()}, strict=False)
     model = model.to(DEV).eval()

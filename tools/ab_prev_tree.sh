@@ -8,6 +8,6 @@ O=gpurun_out/ab_prev; mkdir -p $O
 line() { grep '^{' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], 'img/s', d['ms_per_step'], 'ms; dgrad', [g['avg_ms'] for g in d.get('timed_gemms', []) if 'dgrad' in g.get('name','')][:1])"; }
 for r in $(seq 1 $ROUNDS); do
   (cd _prev_tree && python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin-leg 2>/dev/null | line "prev round $r")
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin-leg 2>/dev/null | line "this round $r"
+  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin-leg --no-length-leg 2>/dev/null | line "this round $r"
   if [ -n "$VAR" ]; then env $VAR=0 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin-leg 2>/dev/null | line "this, $VAR=0 round $r"; fi
 done | tee $O/ab.log

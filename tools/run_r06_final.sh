@@ -14,6 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o p -- py
 f=$(find $O/prof_bench -name "p_kernel_trace.csv" | head -1); python3 tools/summarize_prof.py "${f%_kernel_trace.csv}" $O/r06 > $O/summ_bench.log 2>&1
 python3 tools/trace_gaps.py "$f" > $O/gaps.log 2>&1
 python3 tools/trace_bwd_steps.py "$f" > $O/bwd_steps.log 2>&1
+python3 tools/launch_census.py "${f%_kernel_trace.csv}_kernel_stats.csv" 7 > $O/launch_census.log 2>&1
+python3 tools/aten_census.py > $O/aten_census.log 2>&1
+python3 tools/bench_rank1.py > $O/bench_rank1.json 2> $O/bench_rank1.err
 find $O -name "*trace.csv" -delete
 python3 bench.py --steps 10 --warmup 3 --height 240 --width 320 --no-cpu-baseline > $O/bench_240x320.json 2> $O/bench_240x320.err
 python3 bench.py --steps 10 --warmup 3 --task osie --arch resnet18 --T 8 --batch 4 --height 240 --width 320 --no-cpu-baseline > $O/bench_osie_r18.json 2> $O/bench_osie_r18.err
