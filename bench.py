@@ -494,6 +494,14 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, hip.TIMER = hip.TIMER, None
+    # host time to enqueue ONE step onto an idle device (outside the timed region): inside the timed loop the host is held back by the
+    # device's queue once it is far enough ahead, so host_s / steps tends to the device time of a step however fast the host is
+    host_idle = []
+    for _ in range(2):
+        th = time.perf_counter()
+        step()
+        host_idle.append(time.perf_counter() - th)
+        sync()
     if world > 1 and args.mode == "train":
         # after W + K optimiser steps every rank must hold the same parameters (same reduced gradients, same Adam state): a drifted
         # replica means a collective was skipped or mis-ordered on some rank
@@ -701,6 +709,7 @@ def main():
                       "loss": round(float(loss.detach()), 5) if args.mode == "train" else None,
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                       "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 2),
+                      "host_enqueue_ms_one_step_on_idle_device": round(min(host_idle) * 1e3, 2),
                       "arithmetic": arith,
                       # switches that differ from the package defaults (scanpaths_amd.config; environment variables are honoured
                       # only under SP_ALLOW_ENV_TUNING=1): {} for the headline line
