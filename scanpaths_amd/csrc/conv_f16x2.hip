@@ -143,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
 #ifdef SP_TIMING_VARIANTS
     // probe (wrong results unless only the stagger bits are set): bit 0 = no epilogue loads, bit 1 = no epilogue stores, bit 2 = no epilogue
     // at all; bits 8.. = first-round stagger: G = (probe >> 8) & 15 groups of CUs start (group index) x 2 us x ((probe >> 12) & 31) late
-    const int probe = LSTM ? p.l_probe : 0;
-    if (LSTM && (probe >> 8) && blockIdx.x < 256) {
+    const int probe = p.l_probe;      // (launches without the cell epilogue: the stagger bits only)
+    if ((probe >> 8) && blockIdx.x < 256) {
         const int G = (probe >> 8) & 15, step_us = 2 * ((probe >> 12) & 31);
         const long long wait = (long long)((blockIdx.x >> 3) % G) * step_us * 100;      // s_memrealtime: 100 MHz
         const long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -2097,6 +2097,7 @@ static int conv_igemm_f16(const sp_conv_desc* d, const void* Xs, const float* x_
         return cbm_ok ? launch_h2<0, 3, true>(a, st) : launch_h2<0, 3, false>(a, st);
     }
 #ifdef SP_TIMING_VARIANTS      // wrong-result timing modes of the tap-major build (A/B tools only; sp_set_tuning("h2_dbg", n))
+    if (sp_tuning_get(SP_TUNE_H2_DBG, 0) >= 256) a.l_probe = sp_tuning_get(SP_TUNE_H2_DBG, 0) & ~255;      // first-round stagger of the CUs (correct results)
     switch (sp_tuning_get(SP_TUNE_H2_DBG, 0)) {
         case 6: return f ? launch_h2<0, 3, false, false, false, 1>(a, st) : launch_h2<1, 3, false, false, false, 1>(a, st);      // no loads
         case 7: return f ? launch_h2<0, 3, false, false, false, 2>(a, st) : launch_h2<1, 3, false, false, false, 2>(a, st);      // no MFMAs
