@@ -405,6 +405,22 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
     // fragment read offsets: row r, chunk c = (k-group >> 1) * 4 + plane * 2 + (k-group & 1) stored at position c ^ ((r>>1)&7); lane = (row l16,
     // k-group g4) of the 32-k block; the four 16-row tiles of a wave are reached by constant offsets
     const int l16 = lane & 15, g4 = lane >> 4;
+    // per-row weight scales of the lane's four output columns: requested HERE, ahead of the K loop's LDS-DMA pieces (loads return in
+    // order: the counted waits are unaffected), used by the epilogue -- requested there, their latency was exposed once per tile
+    float pre_sw[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (!LSTM && !HALO) {
+        if (p.sw_rows) {
+            int64_t r0 = 0;
+            if constexpr (!CBM) {
+                if (p.w_bstride) r0 = (m0 / p.rows_per_batch) * (int64_t)p.Nout;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l16;
+                if (n < p.Nout) pre_sw[j] = p.sw[r0 + n];
+            }
+        }
+    }
     const int rot = (l16 >> 1) & 7;
     int offA[2], offB[2];            // [plane]
 #pragma unroll
@@ -835,6 +851,7 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
         const bool stats = MODE == 0 && p.st_partial != nullptr;        // scalar
         const bool wide = (p.ldc & 3) == 0 && (p.Nout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
         float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 68);
+        const bool full_m = m0 + HBM <= p.M;                             // (scalar)
         double cs[4], cq[4];
         float cmn[4], cmx[4];
 #pragma unroll
@@ -842,11 +859,39 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             const int n = n0 + wn * 64 + j * 16 + l16;
             const bool n_ok = n < p.Nout;
             const float bv = (n_ok && p.bias) ? p.bias[n] : 0.f;
-            const float iswn = (p.sw_rows && n_ok) ? 1.f / p.sw[swrow0 + n] : isw;
+            const float iswn = (p.sw_rows && n_ok) ? 1.f / ((!LSTM && !HALO) ? pre_sw[j] : p.sw[swrow0 + n]) : isw;
             cs[j] = 0.0;
             cq[j] = 0.0;
             cmn[j] = INFINITY;
             cmx[j] = -INFINITY;
+            // The common case -- float4 stores, every row of the tile inside the matrix -- without per-element control flow (round 6: the general
+            // loop below tests `wide`, `stats` and the bounds per element, 2-3 scalar branches for each of a lane's 64 values: 5.8 us of a
+            // short-K tile's 21 us went into the epilogue's ARITHMETIC, not its stores; profiles/r06_pointwise_modes.log).  Same values, same
+            // order of the statistics' sums.  (Lanes whose column does not exist write nothing: their staging slots are never read.)
+            if (wide && full_m) {
+                if (n_ok) {
+                    if (stats) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * iswn) + bv;
+                                stg[(i * 16 + 4 * g4 + r) * 68 + j * 16 + l16] = v;
+                                cs[j] += (double)v;
+                                cq[j] += (double)v * (double)v;
+                                cmn[j] = fminf(cmn[j], v);
+                                cmx[j] = fmaxf(cmx[j], v);
+                            }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                stg[(i * 16 + 4 * g4 + r) * 68 + j * 16 + l16] = p.alpha * (((tot4[i][j][r] + acc4[i][j][r]) * isx) * iswn) + bv;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -874,6 +919,13 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private staging: no barrier
             const int cq4 = lane & 15, rsub = lane >> 4;
             const int n = n0 + wn * 64 + 4 * cq4;
+            if (full_m && n0 + HBN <= p.Nout && !p.beta && !p.relu) {       // (scalar) the whole tile exists, plain store: 16 x {read 16 B, store 16 B}
+                float* dst0 = p.C + (m0 + wm * 64 + rsub) * p.ldc + n;
+                const float* src0 = stg + rsub * 68 + 4 * cq4;
+#pragma unroll
+                for (int ps = 0; ps < 16; ++ps)
+                    *reinterpret_cast<float4*>(dst0 + (int64_t)(ps * 4) * p.ldc) = *reinterpret_cast<const float4*>(src0 + ps * 4 * 68);
+            } else
 #pragma unroll
             for (int ps = 0; ps < 16; ++ps) {
                 const int row = ps * 4 + rsub;
@@ -893,7 +945,9 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             }
         }
         if (stats) {
-            __syncthreads();                                         // every wave is done with its staging slice
+            // (raw barriers with lgkmcnt(0): the hazards are LDS ones; __syncthreads() would also wait until the tile's stores are acknowledged)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // every wave is done with its staging slice
             double* sh_s = reinterpret_cast<double*>(smem);          // [4 wm][128 col][2]
             float* sh_m = reinterpret_cast<float*>(smem + 4 * HBN * 2 * sizeof(double));
 #pragma unroll
@@ -913,7 +967,8 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
                     sh_m[(wm * HBN + col) * 2 + 1] = cmx[j];
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (t < HBN && n0 + t < p.Nout) {
                 double a = 0.0, b = 0.0;
                 float mn = INFINITY, mx = -INFINITY;
