@@ -919,12 +919,24 @@ __global__ __launch_bounds__(512, 2) void h2_kernel(H2Args p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private staging: no barrier
             const int cq4 = lane & 15, rsub = lane >> 4;
             const int n = n0 + wn * 64 + 4 * cq4;
-            if (full_m && n0 + HBN <= p.Nout && !p.beta && !p.relu) {       // (scalar) the whole tile exists, plain store: 16 x {read 16 B, store 16 B}
+            if (full_m && n0 + HBN <= p.Nout && !p.relu) {                  // (scalar) the whole tile exists: 16 x {read 16 B, store 16 B}
                 float* dst0 = p.C + (m0 + wm * 64 + rsub) * p.ldc + n;
                 const float* src0 = stg + rsub * 68 + 4 * cq4;
+                if (!p.beta) {
 #pragma unroll
-                for (int ps = 0; ps < 16; ++ps)
-                    *reinterpret_cast<float4*>(dst0 + (int64_t)(ps * 4) * p.ldc) = *reinterpret_cast<const float4*>(src0 + ps * 4 * 68);
+                    for (int ps = 0; ps < 16; ++ps)
+                        *reinterpret_cast<float4*>(dst0 + (int64_t)(ps * 4) * p.ldc) = *reinterpret_cast<const float4*>(src0 + ps * 4 * 68);
+                } else {       // accumulate into the tensor that is there (a data gradient merged into the other consumer's): the 16 reads first
+                    float4 o[16];
+#pragma unroll
+                    for (int ps = 0; ps < 16; ++ps) o[ps] = *reinterpret_cast<const float4*>(dst0 + (int64_t)(ps * 4) * p.ldc);
+#pragma unroll
+                    for (int ps = 0; ps < 16; ++ps) {
+                        float4 v = *reinterpret_cast<const float4*>(src0 + ps * 4 * 68);
+                        v.x += o[ps].x; v.y += o[ps].y; v.z += o[ps].z; v.w += o[ps].w;
+                        *reinterpret_cast<float4*>(dst0 + (int64_t)(ps * 4) * p.ldc) = v;
+                    }
+                }
             } else
 #pragma unroll
             for (int ps = 0; ps < 16; ++ps) {
