@@ -611,7 +611,7 @@ def main():
         fam = kind.split("_")[0]
         nprod = PRODUCTS.get(fam)
         peak = PEAK_F16_MFMA_TFLOPS if nprod else PEAK_FP32_MFMA_TFLOPS
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy = None, None, None
         # the committed PMC passes were taken on the h-gate conv shape (tools/bench_hconv_steps.py: M = 81920 pixels per application,
         # N = 2048, K = 4608; the deferred weight gradient hw2_kernel covers all T - 1 applications in one launch)
         hgate = (dom_key[2], dom_key[3]) == (2048, 4608) and dom_key[1] in (81920, 81920 * (args.T - 1))
@@ -623,6 +623,7 @@ def main():
                     fused = [k for k in keys if PMC_FUSED_FWD in k]
                     key = fused[0] if (kind == "h2_fwd" and fused) else keys[0]
                     traffic, traffic_src = round(pmc[key].get("hbm_side_bytes_per_launch_calibrated", pmc[key]["hbm_side_bytes_per_launch"])), fn
+                    mfma_busy = pmc[key].get("mfma_busy_pct")
                     break
                 except Exception:
                     continue
@@ -643,6 +644,10 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(dom["tflops"] / peak, 4),
+            # what the counters say about "bound": the matrix pipe is busy for this share of the launch (same PMC passes as `traffic`); the rest is the
+            # K loop waiting for its LDS-DMA ring -- two 48-KB K-tiles in flight per CU over ~2 us of fabric-side latency = ~45 GB/s per CU, the
+            # rate every big GEMM kernel of this path sits at -- and, for the fused-cell forward, its epilogue (~0.5 ms of 3.4-3.6)
+            "mfma_busy_pct_measured": round(mfma_busy, 1) if mfma_busy is not None else None,
             "traffic": traffic,
             "traffic_note": (f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/{traffic_src}); "
                              "includes Infinity-Cache hits; algorithmic bytes/launch = split operands once + fp32 output = 0.88 GB per application "
