@@ -317,7 +317,7 @@ int64_t r1_slab_bytes(int B, int P, int N3, int KP) {
 }  // namespace
 
 extern "C" int sp_rank1_grads_applies(int B, int P, int N3, int KP, int ldy) {
-    return (KP == 20 || KP == 12) && B >= 1 && P >= R1_PX && P % R1_PX == 0 && N3 >= R1_CH && N3 % R1_CH == 0 && ldy >= N3 && ldy % 16 == 0 &&
+    return (KP == 20 || KP == 12) && B >= 1 && B <= 65535 && P >= R1_PX && P % R1_PX == 0 && N3 >= R1_CH && N3 % R1_CH == 0 && ldy >= N3 && ldy % 16 == 0 &&
            4LL * KP * N3 < (1LL << 31) && 4LL * B * P * ldy + 64 < (1LL << 40);
 }
 extern "C" int64_t sp_rank1_grads_workspace(int B, int P, int N3, int KP) {
