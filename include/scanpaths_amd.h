@@ -213,7 +213,7 @@ int sp_gateconv_lstm_f16x2(const sp_conv_desc* d, const void* Hsplit, const floa
  *   dsp[b][p][k] = sum_{n < N3} dpre[b][p][n] * wc[b][n][k]        dwc[b][n][k] = sum_p dpre[b][p][n] * spcol[b][p][k]
  * dpre_planes: the 2xfp16 split operand of the gate gradient [B*P][ldy] (ldy >= N3 channels per row) with its scalar scale; wcT_planes: the
  * split operand of wc transposed, rows (b, k) = [B*KP][N3], one scale per row (sp_split2_f16_rows); spcol fp32 [B][P][KP]; outputs fp32.
- * KP in {12, 20}, P % 32 == 0, N3 % 256 == 0 (sp_rank1_grads_applies); workspace >= sp_rank1_grads_workspace bytes (pixel-chunk partials of dwc,
+ * KP in {12, 20}, P % 32 == 0, N3 % 256 == 0, B <= 65535 (sp_rank1_grads_applies); workspace >= sp_rank1_grads_workspace bytes (pixel-chunk partials of dwc,
  * reduced in chunk order: run-to-run identical).  row_last (nullable): samples with row_last[b] < row_step have an exactly-zero dpre: zeros, rows not read.
  * Replaces one batched sp_conv_igemm_f16x2 + one batched sp_conv_wgrad_f16x2 launch (each re-read the planes) and their operand preparation. */
 int sp_rank1_grads_applies(int B, int P, int N3, int KP, int ldy);
